@@ -1,0 +1,411 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the upstream reference on CPU.
+
+Runs ONLY in the build container (needs /root/reference).  The reference's own
+`Trainer` methods (`custom_collate`, `valid_frames_trimin`, `predict_poses`,
+`generate_images_pred`, `compute_losses`, `x_min_opt`) and `layers`/`networks`
+classes are imported unmodified (tools/refshim.py) and executed on seeded synthetic
+batches; inputs and every output the parity tests need are written as small `.npz`
+fixtures under tests/golden/.  A fixture is data only - no reference source text.
+
+    python tools/make_golden.py            # regenerate everything
+    python tools/make_golden.py --only md2 # cases whose name contains "md2"
+
+Key encoding inside the npz files (tuple keys of the reference become paths):
+    in/color/<f>/<s>      uint8 [n,3,h,w]   image * 255 (exact: images are k/255)
+    in/K, in/inv_K, in/stereo_T             float32
+    meta/m                int  [B]          per-sample max frame offset (0 = stereo only)
+    disp/<s>              float32 [B,1,h,w] leaf
+    T/<f>                 float32 [n,4,4]   leaf (direct-pose cases)
+    noise                 float32 [B,H,W]   identity noise per sample (already * 1e-5)
+    out/...               forward results;  grad/... gradients of losses["loss"]
+"""
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+from fake_nets import FakePoseEncoder, fill_deterministic  # noqa: E402
+
+OUT_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+torch.set_num_threads(1)  # the reference trains with one CPU thread (train.py:23)
+
+
+# --------------------------------------------------------------------------- synthetic data
+def kitti_intrinsics(H, W):
+    """Same numbers and float32 op order as the reference loader (kitti_dataset.py:14-23)."""
+    K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                 dtype=np.float32)
+    K[0, :] *= W
+    K[1, :] *= H
+    return K, np.linalg.pinv(K)
+
+
+def smooth_field(gen, c, H, W, cells=6):
+    low = torch.rand(1, c, max(2, H // cells), max(2, W // cells), generator=gen)
+    return F.interpolate(low, size=(H, W), mode="bicubic", align_corners=True)[0].clamp(0, 1)
+
+
+def synth_scene(gen, H, W, frames):
+    """A textured scene; frame f is the scene shifted by ~1.3*f px plus sensor noise."""
+    pad = 16
+    base = 0.7 * smooth_field(gen, 3, H, W + 2 * pad) + 0.3 * torch.rand(3, H, W + 2 * pad, generator=gen)
+    out = {}
+    for f in frames:
+        shift = 0 if f == 0 else (4 if f == "s" else int(round(1.3 * f)))
+        img = base[:, :, pad + shift: pad + shift + W]
+        img = (img + 0.02 * torch.randn(3, H, W, generator=gen)).clamp(0, 1)
+        out[f] = torch.round(img * 255).to(torch.uint8)
+    return out
+
+
+def u8_to_f32(u8):
+    return u8.float().div(255)  # what torchvision ToTensor does
+
+
+def make_item(gen, m, H, W, scales, to_use, cutt, flip_sign=1.0):
+    """Per-sample dict in the shape the reference loader returns (mono_dataset.py:76-146)."""
+    frames = sorted(range(-m, m + 1), key=abs)
+    if m < 3:
+        frames.append("s")
+    scene = synth_scene(gen, H, W, frames)
+    item = {}
+    for f in frames:
+        img = u8_to_f32(scene[f])
+        item[("color", f, 0)] = img
+        if f != "s":
+            item[("color_aug", f, 0)] = img.clone()
+    for s in scales:
+        if s == 0:
+            continue
+        small = F.interpolate(item[("color", 0, 0)][None], size=(H >> s, W >> s), mode="area")[0]
+        item[("color", 0, s)] = u8_to_f32(torch.round(small * 255).to(torch.uint8))
+    K, inv_K = kitti_intrinsics(H, W)
+    item[("K", 0)] = torch.from_numpy(K)
+    item[("inv_K", 0)] = torch.from_numpy(inv_K)
+    stereo_T = np.eye(4, dtype=np.float32)
+    stereo_T[0, 3] = flip_sign * 0.1
+    item["stereo_T"] = torch.from_numpy(stereo_T)
+    item["frames"] = torch.tensor([-50 if f == "s" else f for f in frames])
+    item["cutt_off"] = torch.tensor(cutt)
+    item["to_use"] = torch.tensor(to_use)
+    return item
+
+
+def synth_disp(gen, B, H, W, scales):
+    out = {}
+    for s in scales:
+        h, w = H >> s, W >> s
+        d = torch.stack([0.02 + 0.3 * smooth_field(gen, 1, h, w, cells=4) for _ in range(B)])
+        d = (d + 0.01 * torch.rand(B, 1, h, w, generator=gen)).clamp(1e-3, 1.0)
+        out[s] = d.clone().requires_grad_(True)
+    return out
+
+
+# --------------------------------------------------------------------------- reference driver
+def make_opt(H, W, B, scales, trimin, decomp, incremental=False, partial=False, pose_error=5.5):
+    return types.SimpleNamespace(
+        height=H, width=W, batch_size=B, scales=list(scales), frame_ids=[0, -1, 1],
+        min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False, SQL=False,
+        trimin=trimin, decomp=decomp, pose_error=pose_error,
+        incremental_skip=incremental, partial_skip=partial)
+
+
+def make_ref_trainer(rt, rl, opt):
+    """Reference Trainer without its __init__ (which needs wandb/datasets/gt files)."""
+    tr = rt.Trainer.__new__(rt.Trainer)
+    tr.opt = opt
+    tr.device = torch.device("cpu")
+    tr.num_scales = 4  # frozen at init from the default --scales (trainer.py:44)
+    tr.ssim = rl.SSIM()
+    tr.backproject_depth = {0: rl.BackprojectDepth(opt.batch_size, opt.height, opt.width)}
+    tr.project_3d = {0: rl.Project3D(opt.batch_size, opt.height, opt.width)}
+    tr.models = {}
+    return tr
+
+
+def sort_frame_ids(frames):
+    return sorted(frames, key=lambda it: float("inf") if isinstance(it, str) else abs(it))  # trainer.py:245-250
+
+
+@contextlib.contextmanager
+def record_calls(log):
+    """Record the inputs/outputs of torch.min(x, dim=1) and torch.randn inside compute_losses."""
+    orig_min, orig_randn = torch.min, torch.randn
+
+    def min_(*a, **k):
+        out = orig_min(*a, **k)
+        if isinstance(out, tuple) or hasattr(out, "indices"):
+            log["min"].append((a[0].detach().clone(), out[0].detach().clone(), out[1].detach().clone()))
+        return out
+
+    def randn_(*a, **k):
+        t = orig_randn(*a, **k)
+        log["randn"].append(t.clone())
+        return t
+
+    torch.min, torch.randn = min_, randn_
+    try:
+        yield
+    finally:
+        torch.min, torch.randn = orig_min, orig_randn
+
+
+def fkey(f):
+    return "s" if f == "s" else str(int(f))
+
+
+def run_case(rt, rl, rn, spec):
+    name = spec["name"]
+    H, W, ms = spec["H"], spec["W"], spec["m"]
+    scales = spec.get("scales", [0, 1, 2, 3])
+    B = len(ms)
+    gen = torch.Generator().manual_seed(spec.get("seed", 1234))
+    torch.manual_seed(spec.get("seed", 1234) + 1)
+    opt = make_opt(H, W, B, scales, spec["trimin"], spec["decomp"],
+                   incremental=spec.get("incremental", False), partial=spec.get("partial", False))
+    tr = make_ref_trainer(rt, rl, opt)
+    cutt = spec.get("cutt", 0.3)
+    to_use = max(max(ms), 1)
+    items = [make_item(gen, m, H, W, scales, to_use, cutt, flip_sign=(-1.0 if i % 2 else 1.0))
+             for i, m in enumerate(ms)]
+    inputs = tr.custom_collate(items)
+    rec = {}
+    for key, val in inputs.items():
+        if isinstance(key, tuple) and key[0] in ("color", "color_aug"):
+            rec["in/%s/%s/%d" % (key[0], fkey(key[1]), key[2])] = torch.round(val * 255).to(torch.uint8).numpy()
+    rec["in/K"] = inputs[("K", 0)].numpy()
+    rec["in/inv_K"] = inputs[("inv_K", 0)].numpy()
+    rec["in/stereo_T"] = inputs["stereo_T"].numpy()
+    rec["meta/m"] = np.array(ms, dtype=np.int64)
+    rec["meta/cutt"] = np.float32(cutt)
+    rec["meta/to_use"] = np.int64(to_use)
+    rec["meta/scales"] = np.array(scales, dtype=np.int64)
+    rec["meta/flags"] = np.array([spec["trimin"], spec["decomp"], spec.get("incremental", False),
+                                  spec.get("partial", False)], dtype=np.int64)
+    rec["meta/frames"] = np.array([-50 if f == "s" else f for f in inputs["frames"]], dtype=np.int64)
+
+    # run_epoch :250, process_batch :292-293
+    tr.opt.frame_ids = sort_frame_ids(inputs["frames"])
+    tr.valid_frames = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
+    tr.valid_frames_trimin(inputs)
+    mask_dict = tr.valid_tri_mask_dict if opt.trimin else tr.valid_mask_dict
+
+    disp = synth_disp(gen, B, H, W, scales)
+    for s in scales:
+        rec["disp/%d" % s] = disp[s].detach().numpy()
+    outputs = {}
+    params = {}
+    if spec["pose"] == "direct":
+        tr.maxing_valid_frames = False
+        T_leaf = {}
+        for f in sorted([f for f in tr.valid_frames if f != "s"], key=lambda f: (abs(f), f)):
+            n = int(sum(mask_dict[abs(f)]))
+            aa = 0.01 * torch.randn(n, 1, 3, generator=gen)
+            tt = 0.02 * abs(f) * torch.randn(n, 1, 3, generator=gen)
+            tt[..., 0] += 0.03 * f
+            T = rl.transformation_from_parameters(aa, tt, invert=(f < 0)).detach().clone().requires_grad_(True)
+            T_leaf[f] = T
+            outputs[("cam_T_cam", 0, f)] = T
+            if opt.decomp:  # trainer.py:403-405
+                Te = T.clone().detach()
+                Te[:, :3, 3:] /= opt.pose_error
+                outputs[("cam_T_cam_error", 0, f)] = Te
+            rec["T/%s" % fkey(f)] = T.detach().numpy()
+    else:
+        penc = FakePoseEncoder()
+        pdec = rn.PoseDecoder(penc.num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
+        fill_deterministic(penc, 0.1)
+        fill_deterministic(pdec, 0.2)   # weights are closed-form: not stored in the fixture
+        tr.models = {"pose_encoder": penc, "pose": pdec}
+        for mname, mod in tr.models.items():
+            for k, p in mod.named_parameters():
+                params["%s/%s" % (mname, k)] = p
+        outputs = tr.predict_poses(inputs)
+        for key, val in outputs.items():
+            rec["out/%s/%s/%s" % (key[0], fkey(key[1]), fkey(key[2]))] = val.detach().numpy().copy()
+
+    for s in scales:
+        outputs[("disp", s)] = disp[s]
+    outputs.update(tr.generate_images_pred(inputs, outputs))
+    log = {"min": [], "randn": []}
+    with record_calls(log):
+        losses = tr.compute_losses(inputs, outputs)
+    losses["loss"].backward()
+
+    # --- group bookkeeping (same expressions as trainer.py:516-517 / :521) so rows map to samples
+    if opt.trimin:
+        iterds = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
+        temp_positive = [f for f in iterds if f == "s" or f > 0]
+    else:
+        temp_positive = [f for f in tr.valid_frames if f == "s" or f > 0]
+    group_rows = [[b for b in range(B) if ms[b] == (0 if g == "s" else g)] for g in temp_positive]
+    assert len(log["randn"]) == len(temp_positive), (len(log["randn"]), temp_positive)
+    noise = torch.zeros(B, H, W)
+    for rows, t in zip(group_rows, log["randn"]):
+        noise[rows] = (t * 0.00001)[:, 0]
+    rec["noise"] = noise.numpy()
+    assert len(log["min"]) == len(temp_positive) * len(scales)
+    it = iter(log["min"])
+    for s in scales:
+        tmin = torch.zeros(B, H, W)
+        targ = torch.zeros(B, H, W, dtype=torch.uint8)
+        margin = torch.zeros(B, H, W)
+        ncand = torch.zeros(B, dtype=torch.int64)
+        for rows in group_rows:
+            cat, val, idx = next(it)
+            tmin[rows] = val
+            targ[rows] = idx.to(torch.uint8)
+            ncand[rows] = cat.shape[1]
+            two = torch.topk(cat, 2, dim=1, largest=False).values
+            margin[rows] = two[:, 1] - two[:, 0]
+        rec["out/min/%d" % s] = tmin.numpy()
+        rec["out/argmin/%d" % s] = targ.numpy()
+        rec["out/margin/%d" % s] = margin.numpy()
+        rec["out/ncand"] = ncand.numpy()
+        if spec.get("store_depth", True):
+            rec["out/depth/%d" % s] = outputs[("depth", 0, s)].detach().numpy()
+        rec["out/loss/%d" % s] = losses["loss/%d" % s].detach().numpy()
+        rec["grad/disp/%d" % s] = disp[s].grad.numpy()
+    rec["out/loss"] = losses["loss"].detach().numpy()
+    if spec["pose"] == "direct":
+        for f, T in T_leaf.items():
+            rec["grad/T/%s" % fkey(f)] = (T.grad if T.grad is not None else torch.zeros_like(T)).numpy()
+    else:
+        for k, p in params.items():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            if g.numel() <= 4096:          # small tensors whole, big ones as two checksums
+                rec["grad/w/%s" % k] = g.numpy()
+            else:
+                rec["gradsum/w/%s" % k] = np.array([g.double().sum().item(), g.double().abs().sum().item()])
+    if spec.get("store_warps", True):
+        for key, val in outputs.items():
+            if key[0] in ("color", "color_D"):
+                rec["out/%s/%s/%d" % (key[0], fkey(key[1]), key[2])] = val.detach().numpy()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s loss=%.8f  groups=%s  %.1f KB" % (name, float(losses["loss"].detach()), temp_positive,
+                                                  os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------- per-layer vectors
+def run_layers(rl, rn):
+    gen = torch.Generator().manual_seed(77)
+    rec = {}
+    H, W, n = 16, 24, 3
+    disp = torch.rand(n, 1, H, W, generator=gen)
+    sd, depth = rl.disp_to_depth(disp, 0.1, 100.0)
+    rec["d2d/disp"], rec["d2d/scaled"], rec["d2d/depth"] = disp.numpy(), sd.numpy(), depth.numpy()
+    for s in (1, 2):
+        small = torch.rand(n, 1, H >> s, W >> s, generator=gen)
+        rec["up/in/%d" % s] = small.numpy()
+        rec["up/out/%d" % s] = F.interpolate(small, [H, W], mode="bilinear", align_corners=False).numpy()
+    aa = 0.3 * torch.randn(n, 1, 3, generator=gen)
+    tt = torch.randn(n, 1, 3, generator=gen)
+    rec["tfp/aa"], rec["tfp/t"] = aa.numpy(), tt.numpy()
+    rec["tfp/M"] = rl.transformation_from_parameters(aa, tt, invert=False).numpy()
+    rec["tfp/Minv"] = rl.transformation_from_parameters(aa, tt, invert=True).numpy()
+    K, inv_K = kitti_intrinsics(H, W)
+    K = torch.from_numpy(K)[None].repeat(n, 1, 1)
+    inv_K = torch.from_numpy(inv_K)[None].repeat(n, 1, 1)
+    bp, pj = rl.BackprojectDepth(4, H, W), rl.Project3D(4, H, W)
+    depth = 0.5 + 5 * torch.rand(n, 1, H, W, generator=gen)
+    T = rl.transformation_from_parameters(0.02 * torch.randn(n, 1, 3, generator=gen),
+                                          0.1 * torch.randn(n, 1, 3, generator=gen))
+    pts = bp(depth, inv_K)
+    grid = pj(pts, K, T)
+    img = torch.rand(n, 3, H, W, generator=gen)
+    warped = F.grid_sample(img, grid, align_corners=True, padding_mode="border")
+    rec.update({"geo/K": K.numpy(), "geo/inv_K": inv_K.numpy(), "geo/depth": depth.numpy(),
+                "geo/T": T.numpy(), "geo/points": pts.numpy(), "geo/grid": grid.numpy(),
+                "geo/img": img.numpy(), "geo/warped": warped.numpy()})
+    x = torch.rand(n, 3, H, W, generator=gen)
+    y = (x + 0.1 * torch.randn(n, 3, H, W, generator=gen)).clamp(0, 1)
+    rec["ssim/x"], rec["ssim/y"] = x.numpy(), y.numpy()
+    rec["ssim/out"] = rl.SSIM()(x, y).numpy()
+    tr = types.SimpleNamespace(opt=types.SimpleNamespace(no_ssim=False), ssim=rl.SSIM())
+    rt = sys.modules["trainer"]
+    rec["reproj/out"] = rt.Trainer.compute_reprojection_loss(tr, x, y).numpy()
+    d = torch.rand(n, 1, H, W, generator=gen)
+    rec["smooth/disp"] = d.numpy()
+    rec["smooth/out"] = rl.get_smooth_loss(d, x).numpy()
+    # decoders: state dict + one forward
+    torch.manual_seed(5)
+    num_ch_enc = np.array([64, 64, 128, 256, 512])
+    dec = fill_deterministic(rn.DepthDecoder(num_ch_enc, [0, 1, 2, 3]), 0.3)
+    feats = [torch.randn(1, c, 32 >> i, 64 >> i, generator=gen) for i, c in enumerate(num_ch_enc)]
+    out = dec(feats)
+    for i, f in enumerate(feats):
+        rec["dec/feat/%d" % i] = f.numpy()
+    rec["dec/keys"] = np.array(sorted(dec.state_dict().keys()))
+    for s in range(4):
+        rec["dec/disp/%d" % s] = out[("disp", s)].detach().numpy()
+    pose = fill_deterministic(rn.PoseDecoder(num_ch_enc, num_input_features=1, num_frames_to_predict_for=2), 0.4)
+    aa_o, t_o = pose([feats])
+    rec["pose/keys"] = np.array(sorted(pose.state_dict().keys()))
+    rec["pose/aa"], rec["pose/t"] = aa_o.detach().numpy(), t_o.detach().numpy()
+    path = os.path.join(OUT_DIR, "layers.npz")
+    np.savez_compressed(path, **rec)
+    print("%-28s %.1f KB" % ("layers", os.path.getsize(path) / 1024))
+
+
+CASES = [
+    # MD2 path (no trimin / decomp), trainer.py:549-555
+    dict(name="md2_b2_32x64", H=32, W=64, m=[1, 1], trimin=False, decomp=False, pose="direct"),
+    dict(name="md2_mixed_b3_32x64", H=32, W=64, m=[2, 1, 2], trimin=False, decomp=False, pose="direct", seed=21),
+    dict(name="md2_b1_192x640", H=192, W=640, m=[1], trimin=False, decomp=False, pose="direct",
+         store_warps=False, store_depth=False, seed=3),
+    # boosted: tri-minimisation + error-induced warps, trainer.py:983-1047
+    dict(name="tri_3105_32x64", H=32, W=64, m=[3, 1, 0, 5], trimin=True, decomp=True, pose="direct", seed=5),
+    dict(name="tri_7765_32x64", H=32, W=64, m=[7, 7, 6, 5], trimin=True, decomp=True, pose="direct",
+         scales=[0], seed=6),
+    dict(name="tri_2102_32x64", H=32, W=64, m=[2, 1, 0, 2], trimin=True, decomp=True, pose="direct", seed=7),
+    dict(name="tri_nodecomp_3210_32x64", H=32, W=64, m=[3, 2, 1, 0], trimin=True, decomp=False,
+         pose="direct", scales=[0, 1], seed=8),
+    dict(name="tri_4444_16x32", H=16, W=32, m=[4, 4, 4, 4], trimin=True, decomp=True, pose="direct",
+         scales=[0], seed=9, store_warps=False),
+    dict(name="tri_6123_16x32", H=16, W=32, m=[6, 1, 2, 3], trimin=True, decomp=True, pose="direct",
+         scales=[0], seed=10, store_warps=False),
+    dict(name="tri_0000_16x32", H=16, W=32, m=[0, 0], trimin=True, decomp=True, pose="direct",
+         scales=[0, 1], seed=11, store_warps=False),
+    dict(name="tri_1357_16x32", H=16, W=32, m=[1, 3, 5, 7], trimin=True, decomp=True, pose="direct",
+         scales=[0], seed=12, store_warps=False),
+    # pose-net driven cases (predict_poses three modes, trainer.py:310-419)
+    dict(name="pose_plain_3105_32x64", H=32, W=64, m=[3, 1, 0, 5], trimin=True, decomp=True, pose="net",
+         cutt=0.3, seed=13, store_warps=False),
+    dict(name="pose_incr_3215_32x64", H=32, W=64, m=[3, 2, 1, 5], trimin=True, decomp=True, pose="net",
+         incremental=True, cutt=0.9, scales=[0], seed=14, store_warps=False),
+    dict(name="pose_incr_partial_4327_32x64", H=32, W=64, m=[4, 3, 2, 7], trimin=True, decomp=True,
+         pose="net", incremental=True, partial=True, cutt=1.2, scales=[0], seed=15, store_warps=False),
+    dict(name="pose_md2_b2_32x64", H=32, W=64, m=[1, 1], trimin=False, decomp=False, pose="net",
+         cutt=0.1, seed=16, store_warps=False),
+]
+
+
+def main():
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        # the reference iterates list(set(...)) containing 's': fix str hashing so that
+        # regenerated fixtures are byte-reproducible (CPU-only tool, no GPU in this process)
+        os.execve(sys.executable, [sys.executable] + sys.argv, dict(os.environ, PYTHONHASHSEED="0"))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    rt, rl, rn = refshim.import_reference()
+    if args.only is None or "layers" in args.only:
+        run_layers(rl, rn)
+    for spec in CASES:
+        if args.only is None or args.only in spec["name"]:
+            run_case(rt, rl, rn, spec)
+
+
+if __name__ == "__main__":
+    main()
