@@ -1,0 +1,93 @@
+"""ctypes binding of the C-ABI shared library (include/bbd_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `baseboostdepth_amd/csrc/build.py`
+(`hipcc --offload-arch=gfx950`).  There is NO fallback: if the library is missing or a call
+fails, a RuntimeError is raised - the product path never silently runs anything else.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it owns the process's libamdhip64.so)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbbd_hip.so")
+
+MAX_FRAME_SLOTS = 16
+MAX_CAND = 20
+POSE_STRIDE = 40
+KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
+ABI_VERSION = 1
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_d = ctypes.c_double
+
+# name -> argtypes, exactly the prototypes of include/bbd_hip.h
+SIGNATURES = {
+    "bbd_abi_version": [],
+    "bbd_tile_w": [],
+    "bbd_tile_h": [],
+    "bbd_num_tiles": [_i, _i],
+    "bbd_identity_loss_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
+    "bbd_warp_ssim_min_fwd": [_p] * 12 + [_i] * 6 + [_p],
+    "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],
+    "bbd_disp_to_depth_fwd": [_p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
+    "bbd_disp_to_depth_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
+    "bbd_backproject_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_project3d_fwd": [_p, _p, _p, _p, _i, _i, _i, _d, _p],
+    "bbd_ssim_fwd": [_p, _p, _p, _i, _i, _i, _p],
+}
+
+
+class BbdError(RuntimeError):
+    pass
+
+
+class HipLibrary:
+    """Thin typed wrapper; every call checks the int status the ABI returns."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.isfile(path):
+            raise BbdError(
+                "HIP extension %s not found - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(self._dll, name)   # AttributeError here = header/library mismatch
+            fn.argtypes = argtypes
+            fn.restype = _i
+        if self._dll.bbd_abi_version() != ABI_VERSION:
+            raise BbdError("libbbd_hip.so ABI version mismatch")
+        self.tile_w = self._dll.bbd_tile_w()
+        self.tile_h = self._dll.bbd_tile_h()
+
+    def num_tiles(self, H, W):
+        return self._dll.bbd_num_tiles(H, W)
+
+    def call(self, name, *args):
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            raise BbdError("%s failed with status %d" % (name, rc))
+
+    @staticmethod
+    def stream_for(tensor):
+        return ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+
+
+_LIB = None
+
+
+def get_lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLibrary()
+    return _LIB
+
+
+def ptr(t):
+    """Device (or host, for the test port) address of a contiguous tensor; None -> NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_contiguous(), "C-ABI tensors must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())

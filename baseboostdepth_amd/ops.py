@@ -1,0 +1,212 @@
+"""torch.autograd wrappers around the C-ABI kernels (include/bbd_hip.h).
+
+PyTorch is plumbing here (device memory, streams, autograd tape); all arithmetic of the hot
+path runs in baseboostdepth_amd/csrc/bbd_kernels.hip.  `HipBackend` is the only backend the
+product has: it refuses non-GPU tensors and raises if the extension is missing.  (The CPU test
+tier injects a host build of the same arithmetic through the `backend=` seam - see
+tests/host_port.py - but nothing in this package can fall back to it.)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import POSE_STRIDE, MAX_FRAME_SLOTS, ptr
+from .plan import frame_slot
+
+
+class HipBackend:
+    """Launches on the current torch HIP stream of the tensors' device."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.get_lib()
+
+    def num_tiles(self, H, W):
+        return self.lib.num_tiles(H, W)
+
+    @staticmethod
+    def _check(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise _lib.BbdError("the HIP hot path needs GPU tensors (got %s); there is no CPU path"
+                                    % t.device)
+
+    def run(self, name, anchor, *args):
+        self.lib.call(name, *args, self.lib.stream_for(anchor))
+
+
+_BACKEND = None
+
+
+def default_backend():
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def frame_pointer_array(frame_tensors):
+    """Host array[MAX_FRAME_SLOTS] of base addresses; `frame_tensors` maps frame id -> [n,3,H,W]."""
+    arr = (ctypes.c_void_p * MAX_FRAME_SLOTS)()
+    for f, t in frame_tensors.items():
+        assert t.is_contiguous() and t.dtype == torch.float32
+        arr[frame_slot(f)] = t.data_ptr()
+    return arr
+
+
+# ---------------------------------------------------------------------------- disp -> depth
+class _DispToDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, H, W, min_depth, max_depth, backend):
+        B, one, h, w = disp.shape
+        assert one == 1
+        disp = disp.contiguous()
+        depth = torch.empty(B, 1, H, W, device=disp.device, dtype=torch.float32)
+        backend._check(disp)
+        backend.run("bbd_disp_to_depth_fwd", disp, ptr(disp), ptr(depth), B, h, w, H, W,
+                    float(min_depth), float(max_depth))
+        ctx.save_for_backward(disp)
+        ctx.meta = (H, W, float(min_depth), float(max_depth), backend)
+        return depth
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        (disp,) = ctx.saved_tensors
+        H, W, lo, hi, backend = ctx.meta
+        B, _, h, w = disp.shape
+        grad_depth = grad_depth.contiguous()
+        grad_disp = torch.empty_like(disp)
+        backend.run("bbd_disp_to_depth_bwd", disp, ptr(disp), ptr(grad_depth), ptr(grad_disp), B, h, w, H, W,
+                    lo, hi)
+        return grad_disp, None, None, None, None, None
+
+
+def disp_to_depth_fullres(disp, H, W, min_depth, max_depth, backend=None):
+    """F.interpolate(bilinear, align_corners=False) + layers.disp_to_depth (trainer.py:455-461)."""
+    return _DispToDepth.apply(disp, H, W, min_depth, max_depth, backend or default_backend())
+
+
+class _DispPyramidToDepth(torch.autograd.Function):
+    """All scales at once: S low-res disparity maps -> one [S,B,H,W] depth buffer (no cat copy)."""
+
+    @staticmethod
+    def forward(ctx, H, W, min_depth, max_depth, backend, *disps):
+        disps = [d.contiguous() for d in disps]
+        B = disps[0].shape[0]
+        depth = torch.empty(len(disps), B, H, W, device=disps[0].device, dtype=torch.float32)
+        backend._check(*disps)
+        for i, d in enumerate(disps):
+            backend.run("bbd_disp_to_depth_fwd", d, ptr(d), ptr(depth[i]), B, d.shape[2], d.shape[3], H, W,
+                        float(min_depth), float(max_depth))
+        ctx.save_for_backward(*disps)
+        ctx.meta = (H, W, float(min_depth), float(max_depth), backend)
+        return depth
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        disps = ctx.saved_tensors
+        H, W, lo, hi, backend = ctx.meta
+        grad_depth = grad_depth.contiguous()
+        grads = []
+        for i, d in enumerate(disps):
+            g = torch.empty_like(d)
+            backend.run("bbd_disp_to_depth_bwd", d, ptr(d), ptr(grad_depth[i]), ptr(g), d.shape[0], d.shape[2],
+                        d.shape[3], H, W, lo, hi)
+            grads.append(g)
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def disp_pyramid_to_depth(disps, H, W, min_depth, max_depth, backend=None):
+    """[("disp", s)] list -> depth [S,B,H,W]; depth[i] is the reference's outputs[("depth",0,s_i)]."""
+    return _DispPyramidToDepth.apply(H, W, min_depth, max_depth, backend or default_backend(), *disps)
+
+
+# ---------------------------------------------------------------------------- identity pre-pass
+def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
+    """[NI,H,W] identity photometric losses (no gradient: inputs are images)."""
+    backend = backend or default_backend()
+    B, _, H, W = target.shape
+    tb = plan.tables(target.device)
+    ident = torch.empty(plan.NI, H, W, device=target.device, dtype=torch.float32)
+    backend._check(target, *frame_tensors.values())
+    frames = frame_pointer_array(frame_tensors)
+    backend.run("bbd_identity_loss_fwd", target, frames, ptr(target), ptr(tb["items"]), plan.NI, ptr(ident),
+                H, W, int(no_ssim))
+    return ident
+
+
+# ---------------------------------------------------------------------------- pose table
+def pose_table(plan, K, inv_K, poses):
+    """[NP,40] rows  K[:3,:] | T | inv_K[:3,:3] | pad, differentiable w.r.t. the poses.
+
+    `poses[(kind, f)]` is the [n_job,4,4] transform of warp job (kind, f) with rows in
+    plan.jobs[f] order.  K/inv_K rows are taken by count like the reference (trainer.py:431-432).
+    The kernels form P = (K@T)[:3,:] themselves (reference CPU rounding order, bbd_math.h).
+    """
+    tb = plan.tables(K.device)
+    NP = plan.NP
+    T_all = torch.cat([poses[job] for job in plan.pose_jobs], dim=0)
+    K_all = K.index_select(0, tb["k_rows"])
+    iK_all = inv_K.index_select(0, tb["k_rows"])
+    pad = torch.zeros(NP, POSE_STRIDE - 37, device=K.device, dtype=torch.float32)
+    return torch.cat([K_all[:, :3, :].reshape(NP, 12), T_all.reshape(NP, 16),
+                      iK_all[:, :3, :3].reshape(NP, 9), pad], dim=1).contiguous()
+
+
+# ---------------------------------------------------------------------------- fused warp+SSIM+min
+class _FusedReprojectionMin(torch.autograd.Function):
+    """depth [S,B,H,W], pose table [NP,40] -> per-scale sum of the per-pixel minimum loss."""
+
+    @staticmethod
+    def forward(ctx, depth, proj, target, ident, noise, plan, frame_tensors, no_ssim, materialize, backend):
+        S, B, H, W = depth.shape
+        dev = depth.device
+        tb = plan.tables(dev)
+        ntiles = backend.num_tiles(H, W)
+        depth, proj = depth.contiguous(), proj.contiguous()
+        min_loss = torch.empty(S, B, H, W, device=dev, dtype=torch.float32)
+        argmin = torch.empty(S, B, H, W, device=dev, dtype=torch.uint8)
+        partial = torch.empty(S, B, ntiles, device=dev, dtype=torch.float32)
+        warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
+        backend._check(depth, proj, target, ident, noise, *frame_tensors.values())
+        frames = frame_pointer_array(frame_tensors)
+        backend.run("bbd_warp_ssim_min_fwd", depth, frames, ptr(target), ptr(depth), ptr(proj), ptr(ident),
+                    ptr(noise), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial),
+                    ptr(warped), S, B, plan.NP, H, W, int(no_ssim))
+        ctx.save_for_backward(depth, proj, target, argmin)
+        ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, ntiles)
+        ctx.mark_non_differentiable(min_loss, argmin)
+        outs = (partial.view(S, -1).sum(dim=1), min_loss, argmin)
+        if materialize:
+            ctx.mark_non_differentiable(warped)
+            return outs + (warped,)
+        return outs + (None,)
+
+    @staticmethod
+    def backward(ctx, g_sum, *_unused):
+        depth, proj, target, argmin = ctx.saved_tensors
+        plan, frame_tensors, frames, no_ssim, backend, ntiles = ctx.meta
+        S, B, H, W = depth.shape
+        dev = depth.device
+        tb = plan.tables(dev)
+        gscale = g_sum.contiguous().to(torch.float32)
+        grad_depth = torch.empty_like(depth)
+        gp_partial = torch.empty(S, plan.NP, ntiles, 12, device=dev, dtype=torch.float32)
+        backend.run("bbd_warp_ssim_min_bwd", depth, frames, ptr(target), ptr(depth), ptr(proj), ptr(tb["cand"]),
+                    ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_depth), ptr(gp_partial),
+                    S, B, plan.NP, H, W, no_ssim)
+        # dL/dT = K[:3,:]^T @ dL/dP  (P = (K@T)[:3,:]); K and inv_K columns get no gradient
+        gP = gp_partial.sum(dim=(0, 2)).view(plan.NP, 3, 4)
+        gT = torch.matmul(proj[:, :12].view(plan.NP, 3, 4).transpose(1, 2), gP)
+        grad_pose = torch.zeros_like(proj)
+        grad_pose[:, 12:28] = gT.reshape(plan.NP, 16)
+        return grad_depth, grad_pose, None, None, None, None, None, None, None, None
+
+
+def fused_reprojection_min(depth, proj, target, ident, noise, plan, frame_tensors, no_ssim=False,
+                           materialize=False, backend=None):
+    """Returns (loss_sum [S], min_loss [S,B,H,W], argmin u8 [S,B,H,W], warped [S,NP,3,H,W] | None)."""
+    return _FusedReprojectionMin.apply(depth, proj, target, ident, noise, plan, frame_tensors, bool(no_ssim),
+                                       bool(materialize), backend or default_backend())

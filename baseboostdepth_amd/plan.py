@@ -1,0 +1,154 @@
+"""Index tables that replace the reference's boolean sub-batch masks.
+
+The reference expresses "which source frame is warped for which target sample, and which
+losses compete at a pixel" with ~10 dicts of Python bool lists rebuilt every batch
+(`Trainer.valid_frames_trimin`, trainer.py:888-981) and four copy-pasted `torch.cat`/`torch.min`
+branches (`x_min_opt`, trainer.py:983-1100).  Here the same semantics become one small integer
+table per batch `ordering`, uploaded once and consumed by a single kernel launch:
+
+    cand[b][k] = (kind, frame slot, source row, pose row)    k = arg-min id of the reference
+
+so no gathered image copies and no concatenated loss stacks are ever materialised.
+"""
+import numpy as np
+import torch
+
+from ._lib import MAX_CAND, MAX_FRAME_SLOTS, KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD
+
+STEREO = "s"
+
+
+def frame_slot(f):
+    """Slot of frame id f in the frame pointer array: -7..7 -> 0..14, 's' -> 15."""
+    if f == STEREO:
+        return MAX_FRAME_SLOTS - 1
+    if not -7 <= f <= 7:
+        raise ValueError("frame offset %r outside the supported range -7..7" % (f,))
+    return f + 7
+
+
+def sample_max_offsets(ordering):
+    """ordering (trainer.py:870): [0,'s'] -> 0 ; [0, m, -m] -> m."""
+    return [0 if o[1] == STEREO else int(o[1]) for o in ordering]
+
+
+def reprojection_frames(m, trimin):
+    """Source frames competing for a sample whose largest usable offset is m, in the
+    reference's arg-min order (trainer.py:987, :993-995, :1006-1010, :1025-1030; MD2 :549-554)."""
+    if m == 0:
+        return [STEREO]
+    if not trimin:
+        return [m, -m]
+    if m <= 2:
+        temporal = [f for k in range(m, 0, -1) for f in (k, -k)]
+        return temporal + [STEREO]
+    return [f for k in (m, m - 1, m - 2) for f in (k, -k)]
+
+
+class ReprojectionPlan:
+    """Everything about a batch that depends only on its `ordering` and the trimin/decomp flags."""
+
+    def __init__(self, ordering, trimin, decomp):
+        self.ms = sample_max_offsets(ordering)
+        self.B = len(self.ms)
+        self.trimin = bool(trimin)
+        self.decomp = bool(trimin and decomp)   # error-induced warps exist only on the tri-min path
+        per_sample = [reprojection_frames(m, self.trimin) for m in self.ms]
+
+        # warp jobs: frame -> target samples (batch order), as the reference's mask dicts select them
+        self.jobs = {}
+        for b, frames in enumerate(per_sample):
+            for f in frames:
+                self.jobs.setdefault(f, []).append(b)
+        self.frames = sorted(self.jobs, key=lambda f: (99, 0) if f == STEREO else (abs(f), f < 0))
+        # reference `valid_frames` after the extension at trainer.py:961-981
+        self.valid_frames = list(self.frames)
+
+        # projection-table rows: all true-pose jobs, then all error-induced jobs
+        self.pose_jobs = [("T", f) for f in self.frames]
+        if self.decomp:
+            self.pose_jobs += [("E", f) for f in self.frames if f != STEREO]
+        self.pose_offset, off = {}, 0
+        for job in self.pose_jobs:
+            self.pose_offset[job] = off
+            off += len(self.jobs[job[1]])
+        self.NP = off
+        # K / inv_K are sliced by COUNT in the reference (trainer.py:431-432), not by mask
+        self.k_rows = np.concatenate([np.arange(len(self.jobs[f])) for _, f in self.pose_jobs]).astype(np.int64)
+
+        # identity items: one per (sample, frame) pair
+        self.ident_items, self.ident_index = [], {}
+        for b, frames in enumerate(per_sample):
+            for f in frames:
+                self.ident_index[(b, f)] = len(self.ident_items)
+                self.ident_items.append((b, frame_slot(f), self.source_row(f, b), 0))
+        self.NI = len(self.ident_items)
+
+        cand = np.zeros((self.B, MAX_CAND, 4), dtype=np.int32)
+        ncand = np.zeros(self.B, dtype=np.int32)
+        self.cand_names = []
+        for b, frames in enumerate(per_sample):
+            entries, names = [], []
+            for f in frames:
+                flag = FLAG_NO_POSE_GRAD if f == STEREO else 0
+                entries.append((KIND_WARP | flag, frame_slot(f), self.source_row(f, b), self.pose_row("T", f, b)))
+                names.append(("T", f))
+            if self.decomp:
+                for f in frames:
+                    if f == STEREO:
+                        continue
+                    entries.append((KIND_WARP | FLAG_NO_POSE_GRAD, frame_slot(f), self.source_row(f, b),
+                                    self.pose_row("E", f, b)))
+                    names.append(("E", f))
+            for f in frames:
+                entries.append((KIND_IDENT, 0, self.ident_index[(b, f)], 0))
+                names.append(("I", f))
+            if len(entries) > MAX_CAND:
+                raise ValueError("too many candidates")
+            cand[b, :len(entries)] = np.array(entries, dtype=np.int32)
+            ncand[b] = len(entries)
+            self.cand_names.append(names)
+        self.cand_np, self.ncand_np = cand, ncand
+        self._dev = {}
+
+    # ------------------------------------------------------------------ row bookkeeping
+    def owners(self, f):
+        """Samples that own a tensor row in inputs[("color", f, 0)] (custom_collate, trainer.py:882)."""
+        if f == STEREO:
+            return [b for b, m in enumerate(self.ms) if m < 3]
+        return [b for b, m in enumerate(self.ms) if m >= abs(f)]
+
+    def source_row(self, f, b):
+        return self.owners(f).index(b)
+
+    def pose_row(self, kind, f, b):
+        return self.pose_offset[(kind, f)] + self.jobs[f].index(b)
+
+    def job_rows_in_source(self, f):
+        """Rows of inputs[("color", f, 0)] that take part in frame f's warp job
+        (the reference's valid_tri_mask / valid_mask over the n_f rows)."""
+        own = self.owners(f)
+        return [own.index(b) for b in self.jobs[f]]
+
+    # ------------------------------------------------------------------ device tables
+    def tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = dict(
+                cand=torch.from_numpy(self.cand_np).to(device).contiguous(),
+                ncand=torch.from_numpy(self.ncand_np).to(device).contiguous(),
+                items=torch.tensor(self.ident_items, dtype=torch.int32).reshape(-1, 4).to(device).contiguous(),
+                k_rows=torch.from_numpy(self.k_rows).to(device))
+        return self._dev[key]
+
+
+_PLAN_CACHE = {}
+
+
+def get_plan(ordering, trimin, decomp):
+    key = (tuple(sample_max_offsets(ordering)), bool(trimin), bool(decomp))
+    if key not in _PLAN_CACHE:
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        _PLAN_CACHE[key] = ReprojectionPlan(ordering, trimin, decomp)
+    return _PLAN_CACHE[key]

@@ -1,0 +1,317 @@
+"""`Trainer` with the reference's step interface (trainer.py:29-570), MI355X-native inside.
+
+Kept from the reference (so train/eval scripts are drop-in): `Trainer(opts)`, `.models`,
+`.process_batch(inputs, batch_idx=None, is_train=True) -> (outputs, losses)`, `.predict_poses`,
+`.generate_images_pred`, `.compute_losses`, `.compute_reprojection_loss`, `.valid_frames_trimin`,
+`.set_train/.set_eval`, `.save_model/.load_model`, the `outputs` / `losses` key conventions and the
+checkpoint layout.  Different by design: the sub-batch masks become one index table
+(`plan.ReprojectionPlan`), and warping + SSIM/L1 + per-pixel min over all candidates run as ONE
+fused HIP launch per step (forward) and one for its backward; warped images are materialised
+only on request (`opt.materialize_warps`) because nothing in the loss needs them.
+"""
+import json
+import os
+
+import torch
+import torch.optim as optim
+
+from . import networks, ops
+from .layers import (SSIM, BackprojectDepth, Project3D, disp_to_depth, get_smooth_loss,
+                     transformation_from_parameters)
+from .plan import STEREO, get_plan
+
+
+def _frame_sort_key(item):
+    return float("inf") if isinstance(item, str) else abs(item)
+
+
+class Trainer:
+    def __init__(self, options, backend=None):
+        self.opt = options
+        opt = self.opt
+        self.log_path = os.path.join(getattr(opt, "log_dir", "."), getattr(opt, "model_name", "mdp"))
+        assert opt.height % 32 == 0, "'height' must be a multiple of 32"
+        assert opt.width % 32 == 0, "'width' must be a multiple of 32"
+        self.device = torch.device("cpu" if getattr(opt, "no_cuda", False) else "cuda:%d" % getattr(opt, "cuda", 0))
+        self.num_scales = len(opt.scales)          # frozen here; compute_losses divides by it (trainer.py:44,568)
+        self.num_pose_frames = 2
+        self.backend = backend
+
+        self.models = {}
+        self.parameters_to_train = []
+        self.models["encoder"] = networks.ResnetEncoder(opt.num_layers, opt.weights_init == "pretrained")
+        self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, opt.scales)
+        self.models["pose_encoder"] = networks.ResnetEncoder(18, opt.weights_init == "pretrained",
+                                                             num_input_images=self.num_pose_frames)
+        self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc,
+                                                   num_input_features=1, num_frames_to_predict_for=2)
+        for name in ("encoder", "depth", "pose_encoder", "pose"):
+            self.models[name].to(self.device)
+            self.parameters_to_train += list(self.models[name].parameters())
+        self.model_optimizer = optim.Adam(self.parameters_to_train, opt.learning_rate)
+        self.model_lr_scheduler = optim.lr_scheduler.MultiStepLR(
+            self.model_optimizer, milestones=[11, 13, 15, 16, 17, 18, 19], gamma=0.4)
+        if getattr(opt, "load_weights_folder", "None") not in (None, "None"):
+            self.load_model()
+
+        self.ssim = SSIM()
+        self.backproject_depth = {0: BackprojectDepth(opt.batch_size, opt.height, opt.width)}
+        self.project_3d = {0: Project3D(opt.batch_size, opt.height, opt.width)}
+        self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+        self.grad_sync = None      # set by distributed.attach(): called between backward and optimizer.step
+        self.epoch, self.step = 0, 0
+
+    # ------------------------------------------------------------------ mode switches
+    def set_train(self):
+        for m in self.models.values():
+            m.train()
+
+    def set_eval(self):
+        for m in self.models.values():
+            m.eval()
+
+    def _backend(self):
+        if self.backend is None:
+            self.backend = ops.default_backend()
+        return self.backend
+
+    # ------------------------------------------------------------------ the step (trainer.py:250-263)
+    def train_step(self, inputs):
+        """One optimisation step on a collated batch, as the body of `run_epoch` does it."""
+        if "frames" in inputs:
+            self.opt.frame_ids = sorted(inputs["frames"], key=_frame_sort_key)
+        outputs, losses = self.process_batch(inputs)
+        self.model_optimizer.zero_grad(set_to_none=False)
+        losses["loss"].backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self.model_optimizer.step()
+        self.step += 1
+        return outputs, losses
+
+    def process_batch(self, inputs, batch_idx=None, is_train=True):
+        for key, ipt in inputs.items():
+            if key not in ["frames", "ordering", "cutt"] and torch.is_tensor(ipt):
+                inputs[key] = ipt.to(self.device, non_blocking=True)
+        if is_train:
+            self.valid_frames = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
+            self.valid_frames_trimin(inputs)
+            outputs = self.predict_poses(inputs)
+            feats = self.models["encoder"](inputs["color_aug", 0, 0])
+            outputs.update(self.models["depth"](feats))
+            outputs.update(self.generate_images_pred(inputs, outputs))
+            losses = self.compute_losses(inputs, outputs)
+        else:
+            outputs = {}
+            feats = self.models["encoder"](inputs["color", 0, 0])
+            outputs.update(self.models["depth"](feats))
+            _, outputs["depth", 0, 0] = disp_to_depth(outputs["disp", 0], self.opt.min_depth, self.opt.max_depth)
+            losses = None
+        return outputs, losses
+
+    # ------------------------------------------------------------------ index table (a11)
+    def valid_frames_trimin(self, inputs):
+        """Builds the candidate/index table for this batch's `ordering` (replaces the mask dicts of
+        trainer.py:888-981) and extends `valid_frames` like :961-981."""
+        self.plan = get_plan(inputs["ordering"], self.opt.trimin, self.opt.decomp)
+        self.valid_frames = list(self.plan.valid_frames)
+        return self.plan
+
+    def _rows(self, tensor, rows):
+        if len(rows) == tensor.shape[0] and list(rows) == list(range(tensor.shape[0])):
+            return tensor
+        idx = torch.as_tensor(rows, dtype=torch.long, device=tensor.device)
+        return tensor.index_select(0, idx)
+
+    # ------------------------------------------------------------------ poses (trainer.py:310-419)
+    def _pose_pair(self, first, second, invert):
+        feats = [self.models["pose_encoder"](torch.cat([first, second], 1))]
+        axisangle, translation = self.models["pose"](feats)
+        return transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=invert)
+
+    def _error_pose(self, T):
+        Te = T.clone().detach()                       # no pose gradient through the error-induced warp
+        Te[:, :3, 3:] /= self.opt.pose_error
+        return Te
+
+    def predict_poses(self, inputs):
+        plan, opt = self.plan, self.opt
+        outputs = {}
+        self.maxing_valid_frames = inputs["cutt"].item() > 0.5
+        self.valid_frames_pose = [f for f in plan.frames if f != STEREO]
+        temporal = [f for f in opt.frame_ids[1:] if f != STEREO]
+        incremental = bool(opt.incremental_skip and self.maxing_valid_frames)
+
+        if incremental:
+            # one pose-net call per ADJACENT pair, chained back to frame 0 (trainer.py:348-388)
+            for f in temporal:
+                cur = inputs["color_aug", f, 0]
+                if abs(f) == 1:
+                    ref = inputs["color_aug", 0, 0]
+                    T = self._pose_pair(cur, ref, True) if f < 0 else self._pose_pair(ref, cur, False)
+                    outputs[("cam_T_cam", 0, f)] = T
+                    outputs[("cam_T_cam_step", 0, f)] = T.clone()
+                else:
+                    nb = f + 1 if f < 0 else f - 1
+                    own_f, own_nb = plan.owners(f), plan.owners(nb)
+                    near = self._rows(inputs["color_aug", nb, 0], [own_nb.index(b) for b in own_f])
+                    step = self._pose_pair(cur, near, True) if f < 0 else self._pose_pair(near, cur, False)
+                    outputs[("cam_T_cam_step", nb, f)] = step
+                    if f not in self.valid_frames_pose:
+                        continue
+                    T = torch.eye(4, device=self.device).unsqueeze(0).expand(step.shape[0], -1, -1)
+                    # the reference chains with range(f, 0, -1), which is EMPTY for negative f:
+                    # negative offsets beyond -1 keep the identity pose (reference behaviour, kept)
+                    for k in range(f, 0, -1):
+                        S_k = outputs[("cam_T_cam_step", k - 1, k)]
+                        S_k = self._rows(S_k, [plan.owners(k).index(b) for b in own_f])
+                        T = torch.matmul(T, S_k)
+                    outputs[("cam_T_cam", 0, f)] = T
+                if opt.decomp:
+                    outputs[("cam_T_cam_error", 0, f)] = self._error_pose(outputs[("cam_T_cam", 0, f)])
+        else:
+            # one call per warp job on the already selected sub-batch (trainer.py:390-405)
+            for f in self.valid_frames:
+                if f == STEREO:
+                    continue
+                mid = self._rows(inputs["color_aug", 0, 0], plan.jobs[f])
+                other = self._rows(inputs["color_aug", f, 0], plan.job_rows_in_source(f))
+                T = self._pose_pair(other, mid, True) if f < 0 else self._pose_pair(mid, other, False)
+                outputs[("cam_T_cam", 0, f)] = T
+                if opt.decomp:
+                    outputs[("cam_T_cam_error", 0, f)] = self._error_pose(T)
+
+        if opt.partial_skip and self.maxing_valid_frames:
+            # direct 0->f pose supplies the translation column except where |f| == m-2 (trainer.py:407-418)
+            assert incremental, "--partial_skip needs --incremental_skip (the reference's shapes only fit then)"
+            nonstereo = [m for m in plan.ms if m != 0]
+            for f in self.valid_frames:
+                if f == STEREO or abs(f) <= 1:
+                    continue
+                mid = self._rows(inputs["color_aug", 0, 0], plan.owners(f))
+                cur = inputs["color_aug", f, 0]
+                direct = self._pose_pair(cur, mid, True) if f < 0 else self._pose_pair(mid, cur, False)
+                chained = outputs[("cam_T_cam", 0, f)]
+                replaced = torch.cat([chained[:, :, :3], direct[:, :, 3:]], dim=2)
+                # the reference indexes its all-sample list by ROW number of the n_f-row tensor
+                keep = torch.tensor([abs(f) == nonstereo[r] - 2 for r in range(chained.shape[0])],
+                                    device=self.device).view(-1, 1, 1)
+                outputs[("cam_T_cam", 0, f)] = torch.where(keep, chained, replaced)
+        return outputs
+
+    # ------------------------------------------------------------------ warp + loss (trainer.py:444-570)
+    def _job_poses(self, inputs, outputs):
+        plan = self.plan
+        per_source_rows = bool(self.opt.incremental_skip and self.maxing_valid_frames)
+        poses = {}
+        for kind, f in plan.pose_jobs:
+            if f == STEREO:
+                poses[(kind, f)] = self._rows(inputs["stereo_T"], plan.jobs[f])
+                continue
+            T = outputs[("cam_T_cam" if kind == "T" else "cam_T_cam_error", 0, f)]
+            if per_source_rows:                        # poses have n_f rows: select the job's (trainer.py:468)
+                T = self._rows(T, plan.job_rows_in_source(f))
+            poses[(kind, f)] = T
+        return poses
+
+    def generate_images_pred(self, inputs, outputs):
+        """Depth per scale, pose table, identity pre-pass and the fused warp+SSIM+min launch.
+        Fills `("depth",0,s)`; `("color"/"color_D",f,s)` only with `opt.materialize_warps`."""
+        opt, plan, be = self.opt, self.plan, self._backend()
+        H, W = opt.height, opt.width
+        scales = list(opt.scales)
+        target = inputs[("color", 0, 0)]
+        new = {}
+        depth = ops.disp_pyramid_to_depth([outputs[("disp", s)] for s in scales], H, W,
+                                          opt.min_depth, opt.max_depth, be)          # [S,B,H,W]
+        for i, s in enumerate(scales):
+            new[("depth", 0, s)] = depth[i].unsqueeze(1)
+        proj = ops.pose_table(plan, inputs[("K", 0)], inputs[("inv_K", 0)], self._job_poses(inputs, outputs))
+        frame_tensors = {f: inputs[("color", f, 0)] for f in plan.frames}
+        noise = inputs.get("noise")
+        if noise is None:   # trainer.py:518-523 draws randn*1e-5 per positive group; one draw covers the batch
+            noise = torch.randn(plan.B, H, W, device=target.device) * 0.00001
+        ident = ops.identity_losses(plan, frame_tensors, target, opt.no_ssim, be)
+        materialize = bool(getattr(opt, "materialize_warps", False))
+        loss_sum, min_loss, argmin, warped = ops.fused_reprojection_min(
+            depth, proj, target, ident, noise, plan, frame_tensors, opt.no_ssim, materialize, be)
+        new[("bbd", "loss_sum")] = loss_sum
+        new[("bbd", "to_optimise")] = min_loss
+        new[("bbd", "argmin")] = argmin
+        new[("bbd", "identity")] = ident
+        if materialize:
+            for kind, f in plan.pose_jobs:
+                off, n = plan.pose_offset[(kind, f)], len(plan.jobs[f])
+                for i, s in enumerate(scales):
+                    new[("color" if kind == "T" else "color_D", f, s)] = warped[i, off:off + n]
+        return new
+
+    def compute_reprojection_loss(self, pred, target):
+        """0.85*SSIM + 0.15*L1 map, [n,3,H,W] x2 -> [n,1,H,W]  (trainer.py:477-486); forward-only."""
+        l1 = torch.abs(target - pred).mean(1, True)
+        if self.opt.no_ssim:
+            return l1
+        return 0.85 * self.ssim(pred, target, backend=self._backend()).mean(1, True) + 0.15 * l1
+
+    def compute_losses(self, inputs, outputs):
+        opt = self.opt
+        if ("bbd", "loss_sum") not in outputs:
+            raise RuntimeError("compute_losses needs the outputs of generate_images_pred (fused launch)")
+        losses, total = {}, 0
+        n_px = self.plan.B * opt.height * opt.width
+        for i, s in enumerate(opt.scales):
+            loss = outputs[("bbd", "loss_sum")][i] / n_px                     # to_optimise.mean(), :557
+            disp, color = outputs[("disp", s)], inputs[("color", 0, s)]
+            norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
+            loss = loss + opt.disparity_smoothness * get_smooth_loss(norm_disp, color) / (2 ** s)
+            total = total + loss
+            losses["loss/{}".format(s)] = loss
+        losses["loss"] = total / self.num_scales
+        return losses
+
+    def argmin_masks(self, outputs, scale_index=0):
+        """The reference's `self.ident` bookkeeping (trainer.py:1002-1003 etc.): per sample, where a
+        true-pose reprojection ('norm') or an error-induced one ('guide') won the arg-min."""
+        arg = outputs[("bbd", "argmin")][scale_index]
+        norm, guide = [], []
+        for b, names in enumerate(self.plan.cand_names):
+            n_t = sum(1 for k, _ in names if k == "T")
+            n_e = sum(1 for k, _ in names if k == "E")
+            norm.append(arg[b] < n_t)
+            guide.append((arg[b] >= n_t) & (arg[b] < n_t + n_e))
+        return torch.stack(norm), torch.stack(guide)
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:774-829)
+    def save_opts(self):
+        folder = os.path.join(self.log_path, "models")
+        os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, "opt.json"), "w") as f:
+            json.dump({k: v for k, v in vars(self.opt).items()}, f, indent=2, default=str)
+
+    def save_model(self, name=None):
+        folder = os.path.join(self.log_path, "models", "weights_{}".format(self.epoch if name is None else name))
+        os.makedirs(folder, exist_ok=True)
+        for model_name, model in self.models.items():
+            to_save = model.state_dict()
+            if model_name == "encoder":               # consumers read the training resolution from here
+                to_save["height"] = self.opt.height
+                to_save["width"] = self.opt.width
+            torch.save(to_save, os.path.join(folder, "{}.pth".format(model_name)))
+        torch.save(self.model_optimizer.state_dict(), os.path.join(folder, "adam.pth"))
+        return folder
+
+    def load_model(self):
+        folder = os.path.expanduser(self.opt.load_weights_folder)
+        assert os.path.isdir(folder), "Cannot find folder {}".format(folder)
+        for n in getattr(self.opt, "models_to_load", ["encoder", "depth", "pose_encoder", "pose"]):
+            path = os.path.join(folder, "{}.pth".format(n))
+            model_dict = self.models[n].state_dict()
+            pretrained = torch.load(path, map_location=self.device)
+            model_dict.update({k: v for k, v in pretrained.items() if k in model_dict})
+            self.models[n].load_state_dict(model_dict)
+        adam = os.path.join(folder, "adam.pth")
+        if os.path.isfile(adam):
+            try:
+                self.model_optimizer.load_state_dict(torch.load(adam, map_location=self.device))
+            except ValueError:
+                pass    # parameter grouping differs: start Adam fresh, like the reference's fallback

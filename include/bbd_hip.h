@@ -1,0 +1,136 @@
+/*
+ * bbd_hip.h - C ABI of the MI355X-native photometric-reprojection hot path.
+ *
+ * The upstream reference (kieran514/baseboostdepth) has no FFI / plugin interface: its
+ * seam is Python (`Trainer.process_batch`, trainer.py:286-308).  This header is the drop-in
+ * boundary the build adds underneath that seam: every entry point replaces a group of
+ * eager PyTorch calls in the reference and cites them.  Rules for every function:
+ *
+ *   - plain pointers and sizes only (no torch types); all pointers are DEVICE pointers
+ *     unless the parameter is documented "host";
+ *   - no allocation, no synchronisation: work is enqueued on `stream` (a hipStream_t passed
+ *     as void*; NULL = the null stream) and the call returns immediately;
+ *   - return value 0 = enqueued, >0 = hipError_t from the launch, <0 = BBD_E_* argument error;
+ *   - tensors are fp32, contiguous, NCHW like the reference's batch dict.
+ *
+ * Python binding: baseboostdepth_amd/_lib.py (ctypes).  See INTEGRATION.md for the stub a
+ * reference maintainer would add.
+ */
+#ifndef BBD_HIP_H
+#define BBD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBD_ABI_VERSION 1
+
+/* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
+ * trainer.py:428).  A "slot" indexes a host array of their base pointers. */
+#define BBD_MAX_FRAME_SLOTS 16   /* f = -7..7 and 's' */
+#define BBD_MAX_CAND 20          /* reference maximum is 18 (trainer.py:1025-1042) */
+
+#define BBD_KIND_WARP 0          /* reprojection or error-induced candidate */
+#define BBD_KIND_IDENT 1         /* identity candidate (+ noise) */
+#define BBD_FLAG_NO_POSE_GRAD 0x100 /* warp row whose pose is a constant (stereo_T, T_error) */
+
+#define BBD_E_BADARG (-1)
+#define BBD_E_TOOMANY (-2)
+
+/* One arg-min candidate of one target sample; candidates are stored [B][BBD_MAX_CAND] in
+ * the reference's arg-min id order (trainer.py:549-555, 983-1100).
+ *   WARP : slot/row select the source image frames[slot] + row*3*H*W; `pose` is the row of
+ *          the pose table; kind may be OR-ed with BBD_FLAG_NO_POSE_GRAD.
+ *   IDENT: `row` is the row of the identity-loss tensor [NI,H,W]. */
+typedef struct bbd_cand {
+  int32_t kind;
+  int32_t slot;
+  int32_t row;
+  int32_t pose;
+} bbd_cand_t;
+
+/* Row of the pose table (40 floats) of one (warp job, sample):  K[:3,:] row-major (12),
+ * T row-major (16), inv_K[:3,:3] row-major (9), 3 pad.  The kernels form P = (K@T)[:3,:]
+ * themselves with the reference's CPU rounding order; replaces the per-warp matmul chain of
+ * layers.py:163-165 and :182-185. */
+#define BBD_POSE_STRIDE 40
+
+/* Geometry of the launch tiling, so callers can size scratch buffers. */
+int bbd_abi_version(void);
+int bbd_tile_w(void);
+int bbd_tile_h(void);
+int bbd_num_tiles(int H, int W);
+
+/* Identity photometric loss  0.85*mean_c SSIM(src, tgt) + 0.15*mean_c |tgt - src|
+ * for NI (target sample, source image) pairs.  Replaces trainer.py:501-508
+ * (compute_reprojection_loss on un-warped sources; layers.py:219-249).
+ *   frames  host array[BBD_MAX_FRAME_SLOTS] of device pointers to [n_f,3,H,W] tensors
+ *   target  [B,3,H,W]
+ *   items   device int32 [NI][4] = {target sample, slot, row, 0}
+ *   ident   out [NI,H,W]                                                            */
+int bbd_identity_loss_fwd(const void* const* frames, const float* target,
+                          const int32_t* items, int NI, float* ident,
+                          int H, int W, int no_ssim, void* stream);
+
+/* Fused forward:  back-project -> project -> bilinear border sample -> SSIM+L1 ->
+ * per-pixel min/arg-min over the sample's candidate list, for S scales x B samples.
+ * Replaces trainer.py:421-442 (warping_block), :477-486, :525-557 and x_min_opt :983-1100,
+ * i.e. layers.BackprojectDepth/Project3D/SSIM + F.grid_sample + cat + torch.min.
+ *   depth      [S,B,H,W]   full-resolution depth per scale (outputs[("depth",0,s)])
+ *   pose       [NP,40]     pose table (see BBD_POSE_STRIDE)
+ *   ident      [NI,H,W]    identity losses from bbd_identity_loss_fwd
+ *   noise      [B,H,W]     identity noise per sample (trainer.py:518-523), may be NULL
+ *   cand/ncand [B][BBD_MAX_CAND] / [B]
+ *   min_loss   out [S,B,H,W]   value of the winning candidate (to_optimise)
+ *   argmin     out [S,B,H,W]   u8 id of the winning candidate (ident, trainer.py:546)
+ *   partial    out [S,B,ntiles] per-tile sums of min_loss (deterministic 2-stage mean)
+ *   warped     out [S,NP,3,H,W] or NULL: materialise outputs[("color"/"color_D",f,s)]      */
+int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const float* depth,
+                          const float* pose, const float* ident, const float* noise,
+                          const bbd_cand_t* cand, const int32_t* ncand,
+                          float* min_loss, uint8_t* argmin, float* partial, float* warped,
+                          int S, int B, int NP, int H, int W, int no_ssim, void* stream);
+
+/* Fused backward of the above w.r.t. depth and P = (K@T)[:3,:] of every pose-table row.
+ * Replaces the autograd of min.dim, avg_pool2d, reflection_pad2d, grid_sampler_2d and bmm
+ * (SURVEY.md Appendix A4-A6).  Gradient flows only to the arg-min candidate of each pixel.
+ *   gscale       [S]           d loss / d min_loss[s,...] (one scalar per scale, device)
+ *   grad_depth   out [S,B,H,W]
+ *   grad_proj    out [S,NP,ntiles,12]  per-tile partial sums of dL/dP (caller reduces over
+ *                               tiles and applies dL/dT = K[:3,:]^T dL/dP; rows never visited
+ *                               are written as zeros)                                        */
+int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth,
+                          const float* pose, const bbd_cand_t* cand, const int32_t* ncand,
+                          const uint8_t* argmin, const float* gscale,
+                          float* grad_depth, float* grad_proj,
+                          int S, int B, int NP, int H, int W, int no_ssim, void* stream);
+
+/* disp -> full-resolution depth:  bilinear upsample (align_corners=False) then
+ * depth = 1 / (1/max + (1/min - 1/max) * disp).  Replaces trainer.py:455-461 and
+ * layers.disp_to_depth (layers.py:13-22).  disp [B,h,w] -> depth [B,H,W].           */
+int bbd_disp_to_depth_fwd(const float* disp, float* depth, int B, int h, int w, int H, int W,
+                          double min_depth, double max_depth, void* stream);
+/* grad_disp [B,h,w] is OVERWRITTEN with the adjoint (gather form, deterministic). */
+int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp,
+                          int B, int h, int w, int H, int W,
+                          double min_depth, double max_depth, void* stream);
+
+/* Stand-alone forward kernels behind the reference's layer classes (API surface only; the
+ * training step uses the fused entry points above and never materialises these tensors).
+ *   bbd_backproject_fwd : layers.BackprojectDepth.forward (layers.py:160-167)
+ *                         depth [n,H,W], inv_K [n,4,4] -> points [n,4,H*W]
+ *   bbd_project3d_fwd   : layers.Project3D.forward (layers.py:181-195)
+ *                         points [n,4,H*W], K [n,4,4], T [n,4,4] -> grid [n,H,W,2] in [-1,1]
+ *   bbd_ssim_fwd        : layers.SSIM.forward (layers.py:235-249)  x,y [n,3,H,W] -> [n,3,H,W] */
+int bbd_backproject_fwd(const float* depth, const float* inv_K, float* points, int n, int H, int W,
+                        void* stream);
+int bbd_project3d_fwd(const float* points, const float* K, const float* T, float* grid,
+                      int n, int H, int W, double eps, void* stream);
+int bbd_ssim_fwd(const float* x, const float* y, float* out, int n, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBD_HIP_H */

@@ -1,0 +1,255 @@
+// Host-side execution of the product's per-pixel arithmetic (baseboostdepth_amd/csrc/bbd_math.h).
+//
+// TEST-ONLY: built with g++ by tests/host_port.py so that the CPU test tier (no GPU in the build
+// container) can check the exact math the HIP kernels run - projection, bilinear taps, SSIM/L1,
+// arg-min, and the hand-derived backward - against the oracle before any GPU time is spent.
+// The product never loads this library; it has the same C signatures as include/bbd_hip.h
+// (prefix hp_, host pointers, no stream) but uses plain loops: the backward is written in
+// SCATTER form, independently of the kernels' gather form.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../baseboostdepth_amd/csrc/bbd_math.h"
+#include "../../include/bbd_hip.h"
+
+namespace {
+
+inline float texel(const float* img, int ch, int y, int x, int H, int W) {
+  return img[((size_t)ch * H + bbd_reflect(y, H)) * W + bbd_reflect(x, W)];
+}
+
+// photometric loss at (y,x) between planar images px (prediction) and py (target)
+float photometric(const float* px, const float* py, int y, int x, int H, int W, int no_ssim) {
+  float ssim[3], l1[3];
+  for (int ch = 0; ch < 3; ++ch) {
+    float sx = 0, sxx = 0, sxy = 0, sy = 0, syy = 0;
+    for (int dr = -1; dr <= 1; ++dr)
+      for (int dc = -1; dc <= 1; ++dc) {
+        const float xv = texel(px, ch, y + dr, x + dc, H, W), yv = texel(py, ch, y + dr, x + dc, H, W);
+        sx += xv; sxx += xv * xv; sxy += xv * yv; sy += yv; syy += yv * yv;
+      }
+    float mu_y, sg_y;
+    bbd_ystats(sy, syy, &mu_y, &sg_y);
+    ssim[ch] = no_ssim ? 0.0f : bbd_ssim(sx, sxx, sxy, mu_y, sg_y);
+    l1[ch] = fabsf(py[((size_t)ch * H + y) * W + x] - px[((size_t)ch * H + y) * W + x]);
+  }
+  return bbd_combine(ssim, l1, no_ssim);
+}
+
+void warp_image(const float* src, const float* depth, const float* pose_row, int H, int W, float* out) {
+  float proj[21];
+  bbd_make_proj(pose_row, proj);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      BbdSample sm;
+      bbd_project(proj, x, y, depth[(size_t)y * W + x], H, W, &sm);
+      BbdTaps t;
+      bbd_taps(sm.ix, sm.iy, &t);
+      for (int ch = 0; ch < 3; ++ch) {
+        float v[4];
+        bbd_fetch4(src + (size_t)ch * H * W, H, W, &t, v);
+        out[((size_t)ch * H + y) * W + x] = bbd_bilerp(v, &t);
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hp_identity_loss_fwd(const void* const* frames, const float* target, const int32_t* items, int NI,
+                         float* ident, int H, int W, int no_ssim) {
+  const size_t img = (size_t)3 * H * W;
+  for (int i = 0; i < NI; ++i) {
+    const float* tg = target + (size_t)items[i * 4] * img;
+    const float* src = static_cast<const float*>(frames[items[i * 4 + 1]]) + (size_t)items[i * 4 + 2] * img;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) ident[((size_t)i * H + y) * W + x] = photometric(src, tg, y, x, H, W, no_ssim);
+  }
+  return 0;
+}
+
+int hp_warp_ssim_min_fwd(const void* const* frames, const float* target, const float* depth, const float* proj,
+                         const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
+                         float* min_loss, uint8_t* argmin, float* partial, float* warped, int S, int B, int NP,
+                         int H, int W, int no_ssim) {
+  const size_t hw = (size_t)H * W, img = 3 * hw;
+  std::vector<float> wbuf(img);
+  for (int s = 0; s < S; ++s)
+    for (int b = 0; b < B; ++b) {
+      const size_t sb = (size_t)s * B + b;
+      float* best = min_loss + sb * hw;
+      uint8_t* arg = argmin + sb * hw;
+      std::vector<int> argi(hw, 0);
+      for (size_t p = 0; p < hw; ++p) best[p] = INFINITY;
+      for (int c = 0; c < ncand[b]; ++c) {
+        const bbd_cand_t cd = cand[b * BBD_MAX_CAND + c];
+        if ((cd.kind & 0xff) == BBD_KIND_WARP) {
+          const float* src = static_cast<const float*>(frames[cd.slot]) + (size_t)cd.row * img;
+          warp_image(src, depth + sb * hw, proj + (size_t)cd.pose * BBD_POSE_STRIDE, H, W, wbuf.data());
+          if (warped) memcpy(warped + ((size_t)s * NP + cd.pose) * img, wbuf.data(), img * sizeof(float));
+          for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+              const float l = photometric(wbuf.data(), target + (size_t)b * img, y, x, H, W, no_ssim);
+              bbd_min_update(l, c, &best[(size_t)y * W + x], &argi[(size_t)y * W + x]);
+            }
+        } else {
+          for (size_t p = 0; p < hw; ++p) {
+            const float l = ident[(size_t)cd.row * hw + p] + (noise ? noise[(size_t)b * hw + p] : 0.0f);
+            bbd_min_update(l, c, &best[p], &argi[p]);
+          }
+        }
+      }
+      double tot = 0;
+      for (size_t p = 0; p < hw; ++p) { arg[p] = (uint8_t)argi[p]; tot += best[p]; }
+      if (partial) partial[sb] = (float)tot;   // host port: one "tile" per (scale, sample)
+    }
+  return 0;
+}
+
+// grad_proj here is [S,NP,12] (already reduced over the image).
+int hp_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth, const float* proj,
+                         const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
+                         float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim) {
+  const size_t hw = (size_t)H * W, img = 3 * hw;
+  std::vector<float> wbuf(img), gx(img);
+  memset(grad_depth, 0, sizeof(float) * S * B * hw);
+  memset(grad_proj, 0, sizeof(float) * S * NP * 12);
+  for (int s = 0; s < S; ++s)
+    for (int b = 0; b < B; ++b) {
+      const size_t sb = (size_t)s * B + b;
+      const float g = gscale[s];
+      const float w_ssim = no_ssim ? 0.0f : g * 0.85f / 3.0f;
+      const float w_l1 = no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
+      const float* tg = target + (size_t)b * img;
+      const float* dep = depth + sb * hw;
+      for (int c = 0; c < ncand[b]; ++c) {
+        const bbd_cand_t cd = cand[b * BBD_MAX_CAND + c];
+        if ((cd.kind & 0xff) != BBD_KIND_WARP) continue;
+        const float* src = static_cast<const float*>(frames[cd.slot]) + (size_t)cd.row * img;
+        const float* pose_row = proj + (size_t)cd.pose * BBD_POSE_STRIDE;
+        float pj[21];
+        bbd_make_proj(pose_row, pj);
+        warp_image(src, dep, pose_row, H, W, wbuf.data());
+        std::fill(gx.begin(), gx.end(), 0.0f);
+        // scatter d loss_p / d warped texels for every pixel p this candidate won
+        for (int y = 0; y < H; ++y)
+          for (int x = 0; x < W; ++x) {
+            if (argmin[sb * hw + (size_t)y * W + x] != c) continue;
+            for (int ch = 0; ch < 3; ++ch) {
+              const float* wx = wbuf.data();
+              if (!no_ssim) {
+                float sx = 0, sxx = 0, sxy = 0, sy = 0, syy = 0;
+                for (int dr = -1; dr <= 1; ++dr)
+                  for (int dc = -1; dc <= 1; ++dc) {
+                    const float xv = texel(wx, ch, y + dr, x + dc, H, W), yv = texel(tg, ch, y + dr, x + dc, H, W);
+                    sx += xv; sxx += xv * xv; sxy += xv * yv; sy += yv; syy += yv * yv;
+                  }
+                float mu_y, sg_y, A, Bc, Cc;
+                bbd_ystats(sy, syy, &mu_y, &sg_y);
+                bbd_ssim_grad(sx, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
+                for (int dr = -1; dr <= 1; ++dr)
+                  for (int dc = -1; dc <= 1; ++dc) {
+                    const int ry = bbd_reflect(y + dr, H), rx = bbd_reflect(x + dc, W);
+                    const size_t qi = ((size_t)ch * H + ry) * W + rx;
+                    gx[qi] += w_ssim * (A + Bc * wx[qi] + Cc * tg[qi]) * (1.0f / 9.0f);
+                  }
+              }
+              const size_t qi = ((size_t)ch * H + y) * W + x;
+              const float df = wx[qi] - tg[qi];
+              gx[qi] += w_l1 * (df > 0 ? 1.0f : (df < 0 ? -1.0f : 0.0f));
+            }
+          }
+        // chain to depth and P
+        for (int y = 0; y < H; ++y)
+          for (int x = 0; x < W; ++x) {
+            BbdSample sm;
+            bbd_project(pj, x, y, dep[(size_t)y * W + x], H, W, &sm);
+            BbdTaps t;
+            bbd_taps(sm.ix, sm.iy, &t);
+            float gix = 0, giy = 0;
+            for (int ch = 0; ch < 3; ++ch) {
+              float v[4];
+              bbd_fetch4(src + (size_t)ch * hw, H, W, &t, v);
+              bbd_bilerp_grad(v, &t, gx[((size_t)ch * H + y) * W + x], &gix, &giy);
+            }
+            float gd, gp[12];
+            bbd_project_grad(pj, &sm, gix, giy, &gd, gp);
+            grad_depth[sb * hw + (size_t)y * W + x] += gd;
+            if (!(cd.kind & BBD_FLAG_NO_POSE_GRAD))
+              for (int k = 0; k < 12; ++k) grad_proj[((size_t)s * NP + cd.pose) * 12 + k] += gp[k];
+          }
+      }
+    }
+  return 0;
+}
+
+int hp_disp_to_depth_fwd(const float* disp, float* depth, int B, int h, int w, int H, int W, double min_depth,
+                         double max_depth) {
+  const float lo = (float)(1.0 / max_depth), span = (float)(1.0 / min_depth - 1.0 / max_depth);
+  for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const float* d = disp + (size_t)b * h * w;
+        float v;
+        if (h == H && w == W) {
+          v = d[(size_t)y * w + x];
+        } else {
+          int y0, y1, x0, x1;
+          float ly0, ly1, lx0, lx1;
+          bbd_up_src(y, h, H, &y0, &y1, &ly0, &ly1);
+          bbd_up_src(x, w, W, &x0, &x1, &lx0, &lx1);
+          v = bbd_up_blend(d[(size_t)y0 * w + x0], d[(size_t)y0 * w + x1], d[(size_t)y1 * w + x0],
+                           d[(size_t)y1 * w + x1], ly0, ly1, lx0, lx1, (H + W) <= 128);
+        }
+        depth[((size_t)b * H + y) * W + x] = 1.0f / (lo + span * v);
+      }
+  return 0;
+}
+
+// scatter-form adjoint (the kernel uses a gather)
+int hp_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp, int B, int h, int w, int H,
+                         int W, double min_depth, double max_depth) {
+  const float lo = (float)(1.0 / max_depth), span = (float)(1.0 / min_depth - 1.0 / max_depth);
+  memset(grad_disp, 0, sizeof(float) * B * h * w);
+  for (int b = 0; b < B; ++b)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const float* d = disp + (size_t)b * h * w;
+        float* gd = grad_disp + (size_t)b * h * w;
+        int y0 = y, y1 = y, x0 = x, x1 = x;
+        float ly0 = 1, ly1 = 0, lx0 = 1, lx1 = 0;
+        if (!(h == H && w == W)) {
+          bbd_up_src(y, h, H, &y0, &y1, &ly0, &ly1);
+          bbd_up_src(x, w, W, &x0, &x1, &lx0, &lx1);
+        }
+        const float sc = lo + span * bbd_up_blend(d[(size_t)y0 * w + x0], d[(size_t)y0 * w + x1],
+                                                  d[(size_t)y1 * w + x0], d[(size_t)y1 * w + x1], ly0, ly1, lx0, lx1, (H + W) <= 128);
+        const float gv = grad_depth[((size_t)b * H + y) * W + x] * (-span / (sc * sc));
+        gd[(size_t)y0 * w + x0] += gv * ly0 * lx0;
+        gd[(size_t)y0 * w + x1] += gv * ly0 * lx1;
+        gd[(size_t)y1 * w + x0] += gv * ly1 * lx0;
+        gd[(size_t)y1 * w + x1] += gv * ly1 * lx1;
+      }
+  return 0;
+}
+
+// exhaustive-ish check helpers for the constant divisions
+int hp_check_div(uint32_t start, uint32_t count, uint32_t stride) {
+  int bad = 0;
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t bits = start + k * stride;
+    float x;
+    memcpy(&x, &bits, 4);
+    if (!(x == x) || fabsf(x) > 1e30f || (fabsf(x) < 1e-30f && x != 0.0f)) continue;
+    if (bbd_div9(x) != x / 9.0f) ++bad;
+    if (bbd_div3(x) != x / 3.0f) ++bad;
+  }
+  return bad;
+}
+
+}  // extern "C"
