@@ -1,0 +1,242 @@
+"""GPU tier (-m gpu): the HIP kernels, called through the C ABI, against the reference's golden
+vectors and the oracle.  Forward results must match BIT FOR BIT (see bbd_math.h)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import Case, DIRECT_CASES, GOLDEN_DIR
+from fused_runner import run_direct_case, compare_with_golden, compare_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from baseboostdepth_amd import ops
+    return ops.default_backend()
+
+
+@pytest.fixture(scope="module")
+def layers_z():
+    return np.load(os.path.join(GOLDEN_DIR, "layers.npz"))
+
+
+def g(z, k):
+    return torch.from_numpy(z[k]).to(DEV)
+
+
+def test_native_library_is_loaded_and_single_hip_runtime(backend):
+    maps = open("/proc/self/maps").read()
+    assert "libbbd_hip.so" in maps
+    runtimes = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
+    assert len(runtimes) == 1, runtimes      # our .so must share torch's HIP runtime
+
+
+@pytest.mark.parametrize("name", DIRECT_CASES)
+def test_fused_path_matches_reference_bit_for_bit(name, backend):
+    case = Case(name, device=DEV)
+    tr, inputs, outputs, losses = run_direct_case(case, backend, device=DEV)
+    report = compare_with_golden(case, tr, outputs, losses, exact=True)
+    losses["loss"].backward()
+    torch.cuda.synchronize()
+    compare_grads(case, report)
+
+
+@pytest.mark.parametrize("name", ["md2_b2_32x64", "tri_3105_32x64"])
+def test_without_materialised_warps_same_result(name, backend):
+    a = Case(name, device=DEV)
+    _, _, out_a, loss_a = run_direct_case(a, backend, device=DEV, materialize=True)
+    b = Case(name, device=DEV)
+    _, _, out_b, loss_b = run_direct_case(b, backend, device=DEV, materialize=False)
+    assert ("color", 1, 0) in out_a and ("color", 1, 0) not in out_b
+    assert torch.equal(out_a[("bbd", "to_optimise")], out_b[("bbd", "to_optimise")])
+    assert torch.equal(out_a[("bbd", "argmin")], out_b[("bbd", "argmin")])
+    assert float(loss_a["loss"]) == float(loss_b["loss"])
+
+
+def test_standalone_layers(layers_z, backend):
+    from baseboostdepth_amd import layers as L
+    z = layers_z
+    depth, K, iK, T = g(z, "geo/depth"), g(z, "geo/K"), g(z, "geo/inv_K"), g(z, "geo/T")
+    n, _, H, W = depth.shape
+    pts = L.BackprojectDepth(4, H, W)(depth, iK)
+    assert torch.equal(pts.cpu(), torch.from_numpy(z["geo/points"]))
+    grid = L.Project3D(4, H, W)(pts, K, T)
+    assert torch.equal(grid.cpu(), torch.from_numpy(z["geo/grid"]))
+    x, y = g(z, "ssim/x"), g(z, "ssim/y")
+    assert torch.equal(L.SSIM()(x, y).cpu(), torch.from_numpy(z["ssim/out"]))
+    assert float(L.SSIM()(x, x).abs().max()) == 0.0                      # KAT K2
+    sd, dp = L.disp_to_depth(g(z, "d2d/disp"), 0.1, 100.0)
+    assert torch.allclose(dp.cpu(), torch.from_numpy(z["d2d/depth"]), rtol=1e-6)
+    M = L.transformation_from_parameters(g(z, "tfp/aa"), g(z, "tfp/t"))
+    Mi = L.transformation_from_parameters(g(z, "tfp/aa"), g(z, "tfp/t"), invert=True)
+    assert torch.allclose(M.cpu(), torch.from_numpy(z["tfp/M"]), atol=1e-6)
+    assert torch.allclose(Mi.cpu(), torch.from_numpy(z["tfp/Minv"]), atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        L.SSIM()(x.clone().requires_grad_(True), y)
+
+
+def test_disp_to_depth_kernel(layers_z, backend):
+    from baseboostdepth_amd import ops
+    from oracle import hotpath_ref as O
+    z = layers_z
+    H, W = z["d2d/disp"].shape[-2:]
+    d0 = g(z, "d2d/disp")
+    assert torch.equal(ops.disp_to_depth_fullres(d0, H, W, 0.1, 100.0, backend).cpu(),
+                       torch.from_numpy(z["d2d/depth"]))
+    for s in (1, 2):
+        small = torch.from_numpy(z["up/in/%d" % s])
+        want = O.disp_to_depth(torch.from_numpy(z["up/out/%d" % s]))[1]
+        got = ops.disp_to_depth_fullres(small.to(DEV), H, W, 0.1, 100.0, backend)
+        assert torch.equal(got.cpu(), want)
+    # adjoint against autograd of the oracle, at the real pyramid sizes (generic ATen kernel path)
+    gen = torch.Generator().manual_seed(3)
+    for s in (0, 1, 2, 3):
+        disp = torch.rand(2, 1, 192 >> s, 640 >> s, generator=gen)
+        up = torch.rand(2, 1, 192, 640, generator=gen)
+        dc = disp.clone().requires_grad_(True)
+        ref = O.disp_to_depth(O.upsample_disp(dc, 192, 640))[1]
+        (ref * up).sum().backward()
+        dg = disp.clone().to(DEV).requires_grad_(True)
+        got = ops.disp_to_depth_fullres(dg, 192, 640, 0.1, 100.0, backend)
+        assert torch.equal(got.detach().cpu(), ref.detach())
+        (got * up.to(DEV)).sum().backward()
+        err = float((dg.grad.cpu() - dc.grad).abs().max()) / float(dc.grad.abs().max())
+        assert err < 1e-5, (s, err)
+
+
+def _random_batch(B, H, W, ms, gen, trimin, decomp):
+    """Seeded synthetic batch in the reference's post-collate layout (full resolution)."""
+    from make_golden import kitti_intrinsics, synth_scene, u8_to_f32
+    from oracle import hotpath_ref as O
+    frames = sorted({f for m in ms for f in O.candidate_frames(m, trimin)} | {0}, key=lambda f: (f == "s", f))
+    inputs = {}
+    owners = {f: [b for b, m in enumerate(ms) if (m < 3 if f == "s" else m >= abs(f))] for f in frames}
+    scenes = [synth_scene(gen, H, W, [f for f in frames if b in owners[f]]) for b in range(B)]
+    for f in frames:
+        inputs[("color", f, 0)] = torch.stack([u8_to_f32(scenes[b][f]) for b in owners[f]])
+    K, iK = kitti_intrinsics(H, W)
+    inputs[("K", 0)] = torch.from_numpy(K)[None].repeat(B, 1, 1)
+    inputs[("inv_K", 0)] = torch.from_numpy(iK)[None].repeat(B, 1, 1)
+    sT = torch.eye(4)[None].repeat(B, 1, 1)
+    sT[:, 0, 3] = 0.1
+    inputs["stereo_T"] = sT
+    inputs["ordering"] = [[0, "s"] if m == 0 else [0, m, -m] for m in ms]
+    inputs["frames"] = [f for f in frames]
+    return inputs
+
+
+@pytest.mark.parametrize("ms,trimin,decomp,scales", [
+    ([1, 1], False, False, [0, 1, 2, 3]),
+    ([7, 3], True, True, [0]),
+])
+def test_full_resolution_against_oracle(ms, trimin, decomp, scales, backend):
+    """BASELINE sizes (192x640): HIP vs the oracle run on this box's CPU, bit for bit."""
+    import types
+    from make_golden import synth_disp
+    from oracle import hotpath_ref as O
+    from fused_runner import bare_trainer
+    from baseboostdepth_amd.layers import transformation_from_parameters as tfp
+    H, W, B = 192, 640, len(ms)
+    gen = torch.Generator().manual_seed(11)
+    inputs = _random_batch(B, H, W, ms, gen, trimin, decomp)
+    for s in scales:
+        if s:
+            inputs[("color", 0, s)] = torch.nn.functional.interpolate(inputs[("color", 0, 0)], size=(H >> s, W >> s), mode="area")
+    disp = synth_disp(gen, B, H, W, scales)
+    jobs = O.warp_jobs(ms, trimin)
+    poses = {}
+    for f, rows in jobs.items():
+        if f == "s":
+            continue
+        aa = 0.01 * torch.randn(len(rows), 1, 3, generator=gen)
+        tt = 0.02 * abs(f) * torch.randn(len(rows), 1, 3, generator=gen)
+        poses[f] = tfp(aa, tt, invert=(f < 0)).detach().requires_grad_(True)
+    perr = {}
+    for f, T in poses.items():
+        Te = T.clone().detach()
+        Te[:, :3, 3:] /= 5.5
+        perr[f] = Te
+    noise = torch.randn(B, H, W, generator=gen) * 0.00001
+    ref = O.hot_path(inputs, disp, poses, ms, scales, trimin, decomp, noise, H, W, poses_error=perr)
+    ref["loss"].backward()
+
+    opt = types.SimpleNamespace(height=H, width=W, batch_size=B, scales=scales, frame_ids=[0], min_depth=0.1,
+                                max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False, trimin=trimin,
+                                decomp=decomp, pose_error=5.5, incremental_skip=False, partial_skip=False,
+                                materialize_warps=False)
+    tr = bare_trainer(opt, backend, DEV)
+    gin = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    gin["noise"] = noise.to(DEV)
+    tr.valid_frames_trimin(gin)
+    gdisp = {s: disp[s].detach().clone().to(DEV).requires_grad_(True) for s in scales}
+    gpose = {f: T.detach().clone().to(DEV).requires_grad_(True) for f, T in poses.items()}
+    outputs = {("disp", s): gdisp[s] for s in scales}
+    for f in gpose:
+        outputs[("cam_T_cam", 0, f)] = gpose[f]
+        outputs[("cam_T_cam_error", 0, f)] = perr[f].to(DEV)
+    outputs.update(tr.generate_images_pred(gin, outputs))
+    losses = tr.compute_losses(gin, outputs)
+    losses["loss"].backward()
+    for i, s in enumerate(scales):
+        assert torch.equal(outputs[("bbd", "to_optimise")][i].cpu(), ref["min/%d" % s])
+        assert torch.equal(outputs[("bbd", "argmin")][i].cpu(), ref["argmin/%d" % s])
+        ge = disp[s].grad
+        err = float((gdisp[s].grad.cpu() - ge).abs().max()) / float(ge.abs().max())
+        assert err < 1e-3, ("disp grad", s, err)
+    assert abs(float(losses["loss"]) - float(ref["loss"])) < 1e-5
+    for f, T in poses.items():
+        if T.grad is None:
+            continue
+        err = float((gpose[f].grad.cpu() - T.grad).abs().max()) / (float(T.grad.abs().max()) + 1e-12)
+        assert err < 2e-3, ("pose grad", f, err)
+
+
+def test_full_size_properties(backend):
+    """Size-independent properties at BASELINE config 2 size (B=12, 4 scales, 192x640)."""
+    import types
+    from make_golden import synth_disp
+    from fused_runner import bare_trainer
+    H, W, B = 192, 640, 12
+    gen = torch.Generator().manual_seed(5)
+    inputs = _random_batch(B, H, W, [1] * B, gen, False, False)
+    scales = [0, 1, 2, 3]
+    gin = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    for s in scales[1:]:
+        gin[("color", 0, s)] = torch.nn.functional.interpolate(gin[("color", 0, 0)], size=(H >> s, W >> s), mode="area")
+    gin["noise"] = (torch.randn(B, H, W, generator=gen) * 0.00001).to(DEV)
+    opt = types.SimpleNamespace(height=H, width=W, batch_size=B, scales=scales, frame_ids=[0, -1, 1], min_depth=0.1,
+                                max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False, trimin=False,
+                                decomp=False, pose_error=5.5, incremental_skip=False, partial_skip=False,
+                                materialize_warps=True)
+    tr = bare_trainer(opt, backend, DEV)
+    tr.valid_frames_trimin(gin)
+    disp = synth_disp(gen, B, H, W, scales)
+    outputs = {("disp", s): disp[s].detach().to(DEV) for s in scales}
+    # identity pose for +1, a pure x-translation giving an integer pixel shift for -1 (KAT K1/K3)
+    eye = torch.eye(4, device=DEV)[None].repeat(B, 1, 1)
+    outputs[("cam_T_cam", 0, 1)] = eye
+    outputs[("cam_T_cam", 0, -1)] = eye.clone()
+    res1 = tr.generate_images_pred(gin, dict(outputs))
+    res2 = tr.generate_images_pred(gin, dict(outputs))
+    # (1) determinism: two launches agree bit for bit
+    for k in (("bbd", "to_optimise"), ("bbd", "argmin"), ("bbd", "loss_sum")):
+        assert torch.equal(res1[k], res2[k])
+    # (2) checksum of checksums: per-tile partial sums add up to the sum of the map
+    tot = res1[("bbd", "to_optimise")].double().sum(dim=(1, 2, 3))
+    assert torch.allclose(res1[("bbd", "loss_sum")].double(), tot, rtol=1e-5)
+    # (3) identity pose reproduces the source image (KAT K1, tolerance from SURVEY 4)
+    w = res1[("color", 1, 0)]
+    assert float((w - gin[("color", 1, 0)]).abs().max()) < 2e-3
+    # (4) the winning value is never above any identity candidate (min property)
+    ident = res1[("bbd", "identity")]
+    plan = tr.plan
+    for b in range(B):
+        for f in (1, -1):
+            cand = ident[plan.ident_index[(b, f)]] + gin["noise"][b]
+            assert bool((res1[("bbd", "to_optimise")][0, b] <= cand).all())
+    # (5) arg-min ids stay inside the candidate list
+    assert int(res1[("bbd", "argmin")].max()) < 4

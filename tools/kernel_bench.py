@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the hot-path kernels alone (no networks): times the fused forward, its
+backward and the identity pre-pass with HIP events and prints achieved algorithmic GB/s
+(SURVEY.md 8d byte model).  bench.py is the contract benchmark; this is the tuning loop."""
+import argparse
+import json
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from baseboostdepth_amd import ops  # noqa: E402
+from baseboostdepth_amd.synthetic import synthetic_batch, synthetic_disp, synthetic_poses  # noqa: E402
+from baseboostdepth_amd.trainer import Trainer  # noqa: E402
+
+
+def algorithmic_bytes(plan, S, H, W):
+    """forward / backward / identity compulsory bytes for one step."""
+    P = H * W
+    fwd = bwd = 0
+    for names in plan.cand_names:
+        c_src = len({f for k, f in names if k in ("T", "E")})
+        c_id = sum(1 for k, _ in names if k == "I")
+        fwd += P * (25 + 12 * c_src + 4 * c_id)
+        bwd += P * (21 + 12 * c_src)
+    return fwd * S, bwd * S, 28 * P * plan.NI
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="md2", choices=["md2", "boost7", "boost_e15"])
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    args = ap.parse_args()
+    dev = "cuda:0"
+    H, W, B = 192, 640, args.batch
+    if args.config == "md2":
+        ms, trimin, decomp, scales = [1] * B, False, False, [0, 1, 2, 3]
+    elif args.config == "boost7":
+        ms, trimin, decomp, scales = [7] * B, True, True, [0]
+    else:
+        import random
+        rnd = random.Random(15)
+        probs = [.050, .050, .077, .094, .139, .142, .448]
+        ms = [rnd.choices(range(1, 8), probs)[0] for _ in range(B)]
+        trimin, decomp, scales = True, True, [0]
+    inputs = synthetic_batch(ms, H, W, scales, device=dev, seed=42)
+    opt = types.SimpleNamespace(height=H, width=W, batch_size=B, scales=scales, frame_ids=[0], min_depth=0.1,
+                                max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False, trimin=trimin,
+                                decomp=decomp, pose_error=5.5, incremental_skip=False, partial_skip=False,
+                                materialize_warps=False)
+    tr = Trainer.__new__(Trainer)
+    tr.opt, tr.device, tr.num_scales, tr.backend, tr.maxing_valid_frames = opt, torch.device(dev), 4, None, False
+    be = tr._backend()
+    plan = tr.valid_frames_trimin(inputs)
+    disp = synthetic_disp(B, H, W, scales, device=dev, seed=1)
+    poses = synthetic_poses(plan, device=dev, seed=2, pose_error=5.5)
+    outputs = {("disp", s): disp[s].requires_grad_(True) for s in scales}
+    outputs.update(poses)
+    S = len(scales)
+
+    def fwd():
+        o = tr.generate_images_pred(inputs, dict(outputs))
+        return o[("bbd", "loss_sum")]
+
+    def time_it(fn, n):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    # isolate the three kernels
+    target = inputs[("color", 0, 0)]
+    frame_tensors = {f: inputs[("color", f, 0)] for f in plan.frames}
+    depth = ops.disp_pyramid_to_depth([disp[s] for s in scales], H, W, 0.1, 100.0, be).detach()
+    table = ops.pose_table(plan, inputs[("K", 0)], inputs[("inv_K", 0)], tr._job_poses(inputs, outputs)).detach()
+    ident = ops.identity_losses(plan, frame_tensors, target, False, be)
+    noise = inputs["noise"]
+    fb, bb, ib = algorithmic_bytes(plan, S, H, W)
+
+    def k_ident():
+        ops.identity_losses(plan, frame_tensors, target, False, be)
+
+    def k_fwd():
+        return ops.fused_reprojection_min(depth, table, target, ident, noise, plan, frame_tensors, False, False, be)
+
+    d2 = depth.clone().requires_grad_(True)
+    t2 = table.clone().requires_grad_(True)
+    ls, _, _, _ = ops.fused_reprojection_min(d2, t2, target, ident, noise, plan, frame_tensors, False, False, be)
+    gsum = torch.full_like(ls, 1.0 / (B * H * W))
+
+    def k_bwd():
+        torch.autograd.grad(ls, [d2, t2], gsum, retain_graph=True)
+
+    res = {"config": args.config, "batch": B, "scales": scales, "NP": plan.NP, "NI": plan.NI,
+           "cands_per_sample": [len(n) for n in plan.cand_names]}
+    for name, fn, nbytes in (("identity", k_ident, ib), ("fwd", k_fwd, fb), ("bwd(+reduce)", k_bwd, bb)):
+        for _ in range(args.warmup):
+            fn()
+        ms_ = time_it(fn, args.iters)
+        res[name] = {"ms": round(ms_, 4), "alg_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / ms_ / 1e6, 1),
+                     "frac_of_8TBps": round(nbytes / ms_ / 1e6 / 8000, 4)}
+    for _ in range(args.warmup):
+        fwd()
+    res["generate_images_pred_total_ms"] = round(time_it(fwd, args.iters), 4)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
