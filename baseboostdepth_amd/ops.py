@@ -15,6 +15,36 @@ from ._lib import POSE_STRIDE, MAX_FRAME_SLOTS, ptr
 from .plan import frame_slot
 
 
+class KernelTimer:
+    """HIP-event timing of individual C-ABI launches, on the stream they are launched on.
+
+    Used by bench.py to measure the fused kernels' own duration inside the full training step
+    (torch.cuda.Event records on torch's current stream, which is the stream `HipBackend` launches
+    on).  Off by default: `backend.timer = KernelTimer()` turns it on."""
+
+    def __init__(self):
+        self.events = {}
+
+    def launch(self, name, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.events.setdefault(name, []).append((e0, e1))
+
+    def reset(self):
+        self.events = {}
+
+    def summary(self):
+        """{kernel: (launches, mean ms)} - call after a device synchronise."""
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+
 class HipBackend:
     """Launches on the current torch HIP stream of the tensors' device."""
 
@@ -22,6 +52,7 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.get_lib()
+        self.timer = None
 
     def num_tiles(self, H, W):
         return self.lib.num_tiles(H, W)
@@ -34,7 +65,10 @@ class HipBackend:
                                     % t.device)
 
     def run(self, name, anchor, *args):
-        self.lib.call(name, *args, self.lib.stream_for(anchor))
+        if self.timer is not None:
+            self.timer.launch(name, lambda: self.lib.call(name, *args, self.lib.stream_for(anchor)))
+        else:
+            self.lib.call(name, *args, self.lib.stream_for(anchor))
 
 
 _BACKEND = None

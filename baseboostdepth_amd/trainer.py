@@ -59,6 +59,7 @@ class Trainer:
         self.project_3d = {0: Project3D(opt.batch_size, opt.height, opt.width)}
         self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
         self.grad_sync = None      # set by distributed.attach(): called between backward and optimizer.step
+        self.flat_grads = None
         self.epoch, self.step = 0, 0
 
     # ------------------------------------------------------------------ mode switches
@@ -81,7 +82,10 @@ class Trainer:
         if "frames" in inputs:
             self.opt.frame_ids = sorted(inputs["frames"], key=_frame_sort_key)
         outputs, losses = self.process_batch(inputs)
-        self.model_optimizer.zero_grad(set_to_none=False)
+        if self.flat_grads is not None:
+            self.flat_grads.zero()                 # one memset of the contiguous gradient buffer
+        else:
+            self.model_optimizer.zero_grad(set_to_none=False)
         losses["loss"].backward()
         if self.grad_sync is not None:
             self.grad_sync()
@@ -131,7 +135,9 @@ class Trainer:
 
     def _error_pose(self, T):
         Te = T.clone().detach()                       # no pose gradient through the error-induced warp
-        Te[:, :3, 3:] /= self.opt.pose_error
+        # tensor / tensor: a Python-scalar divisor would be turned into a multiply by 1/pose_error on
+        # the GPU, which rounds differently from the reference's CPU division (trainer.py:377)
+        Te[:, :3, 3:] = Te[:, :3, 3:] / torch.full((), float(self.opt.pose_error), device=Te.device)
         return Te
 
     def predict_poses(self, inputs):

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Contract benchmark: training images/sec of the MD2 ResNet-18 step at 640x192 on N MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is the reference's own definition (trainer.py:233,260-264): process_batch + zero_grad
++ backward + optimizer.step on one pre-resident synthetic KITTI-shaped batch (BASELINE.json
+configs[1]: MD2 ResNet-18 encoder + DepthDecoder + pose nets, 640x192, batch 12 per GPU, frames
+[0,-1,1], 4 scales, fp32), bracketed by barrier + device synchronise; value = global images / max
+over ranks of the wall time.  Rank 0 prints ONE JSON line carrying, besides the contract keys:
+
+  roofline      the hot path's most expensive HIP kernel inside the timed steps: algorithmic bytes
+                per launch (SURVEY.md 8d byte model) / its mean HIP-event duration, vs 8 TB/s HBM
+  kernels       the same for each of the three hot-path kernels
+  cpu_baseline  the oracle (PyTorch-CPU restatement of the reference step, BASELINE.json
+                configs[0]: batch 4) timed on this box's host cores, bounded to a few steps
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 192, 640
+SCALES = [0, 1, 2, 3]
+
+
+def make_options(batch, device_index, config):
+    import types
+    boosted = config != "md2"
+    return types.SimpleNamespace(
+        height=H, width=W, batch_size=batch, scales=([0] if boosted else list(SCALES)), frame_ids=[0, -1, 1],
+        min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False,
+        trimin=boosted, decomp=boosted, pose_error=5.5, incremental_skip=boosted, partial_skip=boosted,
+        materialize_warps=False, num_layers=18, weights_init="scratch", learning_rate=1e-4,
+        no_cuda=False, cuda=device_index, load_weights_folder="None", log_dir="/tmp", model_name="bench")
+
+
+def algorithmic_bytes(plan, S):
+    """Compulsory HBM bytes per launch of each hot-path kernel."""
+    P = H * W
+    fwd = bwd = 0
+    for names in plan.cand_names:
+        c_src = len({f for k, f in names if k in ("T", "E")})
+        c_id = sum(1 for k, _ in names if k == "I")
+        fwd += P * (25 + 12 * c_src + 4 * c_id)
+        bwd += P * (21 + 12 * c_src)
+    return {"bbd_warp_ssim_min_fwd": fwd * S, "bbd_warp_ssim_min_bwd": bwd * S,
+            "bbd_identity_loss_fwd": 28 * P * plan.NI}
+
+
+def cpu_baseline(batch=4, budget_s=25.0):
+    """The oracle's full MD2 step (networks + hot path + Adam) on the host CPU, all cores, then
+    one step at the reference's own setting of ONE thread (train.py:23) if the budget allows."""
+    from baseboostdepth_amd import networks
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    from oracle.step_ref import md2_step
+    ms = [1] * batch
+    torch.manual_seed(42)
+    models = {"encoder": networks.ResnetEncoder(18, False), "pose_encoder": networks.ResnetEncoder(18, False, 2)}
+    models["depth"] = networks.DepthDecoder(models["encoder"].num_ch_enc, SCALES)
+    models["pose"] = networks.PoseDecoder(models["pose_encoder"].num_ch_enc, 1, 2)
+    params = [p for m in models.values() for p in m.parameters()]
+    opt = torch.optim.Adam(params, 1e-4)
+    inputs = synthetic_batch(ms, H, W, SCALES, device="cpu", seed=42)
+    noise = inputs.pop("noise")
+    cores = torch.get_num_threads()
+    md2_step(models, opt, inputs, ms, SCALES, H, W, noise)          # warm-up (allocator, MKL-DNN primitives)
+    times, t_all = [], time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < budget_s * 0.6:
+        t0 = time.perf_counter()
+        md2_step(models, opt, inputs, ms, SCALES, H, W, noise)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    out = {"value": round(batch / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "%d full MD2 steps (ResNet-18 nets + oracle hot path + Adam), batch %d, 640x192, "
+                     "4 scales, median step %.3f s" % (len(times), batch, med)}
+    if (time.perf_counter() - t_all) < budget_s * 0.5:
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        md2_step(models, opt, inputs, ms, SCALES, H, W, noise)
+        out["one_thread_images_per_sec"] = round(batch / (time.perf_counter() - t0), 3)
+        torch.set_num_threads(cores)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
+    ap.add_argument("--config", default="md2", choices=["md2", "boosted"],
+                    help="md2 = BASELINE configs[1]/[3] (the headline); boosted = configs[2] worst case m=7")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels-last", action="store_true")
+    args = ap.parse_args()
+
+    from baseboostdepth_amd import distributed as bdist
+    rank, local, world = bdist.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path in the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+
+    torch.manual_seed(42)
+    opt = make_options(args.batch, local, args.config)
+    trainer = Trainer(opt)
+    if args.channels_last:
+        for m in trainer.models.values():
+            m.to(memory_format=torch.channels_last)
+    trainer.set_train()
+    bdist.attach(trainer)
+    ms = [1] * args.batch if args.config == "md2" else [7] * args.batch
+    inputs = synthetic_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
+    if args.config != "md2":
+        inputs["cutt"] = torch.tensor(1.35)      # epoch >= 10 regime: incremental + partial pose modes
+    backend = ops.default_backend()
+
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(inputs)
+    timer = ops.KernelTimer()
+    backend.timer = timer
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(inputs)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    backend.timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        S = len(opt.scales)
+        nbytes = algorithmic_bytes(trainer.plan, S)
+        kernels = {}
+        for name, (count, mean_ms) in timer.summary().items():
+            if name in nbytes:
+                gbps = nbytes[name] / (mean_ms * 1e-3) / 1e9
+                kernels[name] = {"launches": count, "mean_ms": round(mean_ms, 4),
+                                 "alg_MB_per_launch": round(nbytes[name] / 1e6, 2),
+                                 "achieved_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4)}
+        dom = max(kernels, key=lambda k: kernels[k]["mean_ms"])
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
+                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None}
+        global_batch = args.batch * world
+        line = {
+            "metric": "training images/sec at 640x192, MD2 ResNet18",
+            "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MD2 ResNet-18 encoder+DepthDecoder+PoseNet training step, 640x192, "
+                                   "per-GPU batch %d, frames [0,-1,1], %d scales, HIP fused warp+SSIM+min"
+                                   % (args.batch, S) if args.config == "md2" else
+                                   "BaseBoostDepth boosted step (trimin+decomp+incremental+partial, m=7, 18 "
+                                   "candidates/px), ResNet-18, 640x192, per-GPU batch %d, 1 scale" % args.batch,
+                       "global_batch": global_batch, "parallelism": "dp%d" % world},
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

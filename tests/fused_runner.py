@@ -29,6 +29,7 @@ def bare_trainer(opt, backend, device):
     tr.backend = backend
     tr.models = {}
     tr.grad_sync = None
+    tr.flat_grads = None
     tr.maxing_valid_frames = False
     from baseboostdepth_amd.layers import SSIM
     tr.ssim = SSIM()

@@ -54,9 +54,9 @@ class Case:
     def poses_error(self, pose_error=5.5):
         out = {}
         for f, T in self.poses.items():
-            Te = T.clone().detach()
+            Te = T.clone().detach().cpu()             # CPU division, as the reference does it
             Te[:, :3, 3:] /= pose_error
-            out[f] = Te
+            out[f] = Te.to(T.device)
         return out
 
     def expected(self, key):

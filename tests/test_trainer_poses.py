@@ -1,0 +1,118 @@
+"""CPU tier: Trainer.predict_poses (three pose modes), the network heads, and the whole
+process_batch-style chain against golden vectors from the reference (host-port backend)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fake_nets import FakePoseEncoder, fill_deterministic
+from fused_runner import bare_trainer, make_opt, compare_with_golden
+from golden_io import Case, POSE_CASES, GOLDEN_DIR
+from host_port import HostPortBackend
+from baseboostdepth_amd import networks
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return HostPortBackend()
+
+
+def _fkey(f):
+    return "s" if f == "s" else str(int(f))
+
+
+@pytest.mark.parametrize("name", POSE_CASES)
+def test_predict_poses_and_step(name, backend):
+    case = Case(name)
+    opt = make_opt(case, materialize_warps=False)
+    tr = bare_trainer(opt, backend, "cpu")
+    penc = fill_deterministic(FakePoseEncoder(), 0.1)
+    pdec = fill_deterministic(networks.PoseDecoder(penc.num_ch_enc, 1, 2), 0.2)
+    tr.models = {"pose_encoder": penc, "pose": pdec}
+    inputs = dict(case.inputs)
+    inputs["noise"] = case.noise
+    tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+    tr.valid_frames_trimin(inputs)
+    outputs = tr.predict_poses(inputs)
+    # every pose tensor the reference produced, same key set, same values
+    want = {k for k in case.z.files if k.startswith("out/cam_T_cam")}
+    got = {"out/%s/%s/%s" % (k[0], _fkey(k[1]), _fkey(k[2])) for k in outputs}
+    assert got == want
+    for k in outputs:
+        e = case.expected("out/%s/%s/%s" % (k[0], _fkey(k[1]), _fkey(k[2])))
+        assert outputs[k].shape == e.shape, k
+        assert torch.allclose(outputs[k].detach(), e, atol=2e-6, rtol=1e-5), (k, float((outputs[k] - e).abs().max()))
+    for s in case.scales:
+        outputs[("disp", s)] = case.disp[s]
+    outputs.update(tr.generate_images_pred(inputs, outputs))
+    losses = tr.compute_losses(inputs, outputs)
+    # poses differ from the reference's by fp32 round-off of a different op graph, so use the
+    # tolerance protocol (loss 1e-5, arg-min equal off ties)
+    compare_with_golden(case, tr, outputs, losses, map_tol=1e-4, tie_margin=2e-4, check_warps=False)
+    losses["loss"].backward()
+    params = {"pose_encoder/" + k: p for k, p in penc.named_parameters()}
+    params.update({"pose/" + k: p for k, p in pdec.named_parameters()})
+    for k, p in params.items():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        if case.has("grad/w/" + k):
+            e = case.expected("grad/w/" + k)
+            scale = float(e.abs().max()) + 1e-12
+            assert float((g - e).abs().max()) / scale < 5e-3, k
+        else:
+            e = case.expected("gradsum/w/" + k)
+            assert abs(g.double().sum().item() - float(e[0])) <= 5e-3 * float(e[1]) + 1e-9, k
+    for s in case.scales:
+        ge = case.expected("grad/disp/%d" % s)
+        rel = (case.disp[s].grad - ge).abs() / float(ge.abs().max())
+        assert float(rel.max()) < 5e-3, (s, float(rel.max()))
+
+
+def test_decoders_match_reference_and_state_dict_keys():
+    z = np.load(os.path.join(GOLDEN_DIR, "layers.npz"))
+    num_ch_enc = np.array([64, 64, 128, 256, 512])
+    dec = fill_deterministic(networks.DepthDecoder(num_ch_enc, [0, 1, 2, 3]), 0.3)
+    assert sorted(dec.state_dict().keys()) == list(z["dec/keys"])
+    feats = [torch.from_numpy(z["dec/feat/%d" % i]) for i in range(5)]
+    out = dec(feats)
+    for s in range(4):
+        d = float((out[("disp", s)] - torch.from_numpy(z["dec/disp/%d" % s])).abs().max())
+        assert d < 2e-5, (s, d)
+    pose = fill_deterministic(networks.PoseDecoder(num_ch_enc, 1, 2), 0.4)
+    assert sorted(pose.state_dict().keys()) == list(z["pose/keys"])
+    aa, t = pose([feats])
+    assert torch.allclose(aa, torch.from_numpy(z["pose/aa"]), atol=1e-7)
+    assert torch.allclose(t, torch.from_numpy(z["pose/t"]), atol=1e-7)
+    assert sum(p.numel() for p in dec.parameters()) == 3152724
+    assert sum(p.numel() for p in pose.parameters()) == 1314572
+
+
+def test_resnet_encoder_layout():
+    """torchvision-identical keys / parameter count (the reference's encoder.pth must load)."""
+    enc = networks.ResnetEncoder(18, False)
+    sd = enc.state_dict()
+    assert sum(p.numel() for p in enc.parameters()) == 11689512
+    for k in ("encoder.conv1.weight", "encoder.bn1.running_mean", "encoder.layer1.0.conv1.weight",
+              "encoder.layer2.0.downsample.0.weight", "encoder.layer2.0.downsample.1.num_batches_tracked",
+              "encoder.layer4.1.bn2.bias", "encoder.fc.weight", "encoder.fc.bias"):
+        assert k in sd, k
+    assert sd["encoder.conv1.weight"].shape == (64, 3, 7, 7)
+    feats = enc(torch.rand(1, 3, 64, 96))
+    assert [f.shape[1] for f in feats] == [64, 64, 128, 256, 512]
+    assert [f.shape[2] for f in feats] == [32, 16, 8, 4, 2]
+    pe = networks.ResnetEncoder(18, False, num_input_images=2)
+    assert pe.state_dict()["encoder.conv1.weight"].shape == (64, 6, 7, 7)
+    e50 = networks.ResnetEncoder(50, False)
+    assert list(e50.num_ch_enc) == [64, 256, 512, 1024, 2048]
+    with pytest.raises(RuntimeError):
+        networks.ResnetEncoder(18, True)
+
+
+def test_transformation_from_parameters_matches_golden():
+    from baseboostdepth_amd.layers import transformation_from_parameters as tfp, disp_to_depth
+    z = np.load(os.path.join(GOLDEN_DIR, "layers.npz"))
+    aa, t = torch.from_numpy(z["tfp/aa"]), torch.from_numpy(z["tfp/t"])
+    assert torch.equal(tfp(aa, t), torch.from_numpy(z["tfp/M"]))
+    assert torch.equal(tfp(aa, t, invert=True), torch.from_numpy(z["tfp/Minv"]))
+    sd, dp = disp_to_depth(torch.from_numpy(z["d2d/disp"]), 0.1, 100.0)
+    assert torch.equal(dp, torch.from_numpy(z["d2d/depth"]))
