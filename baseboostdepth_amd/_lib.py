@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be imported first: it owns the process's libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbbd_hip.so")
+# BBD_HIP_LIB lets the tuning scripts load an alternative build of the SAME sources (tools/variants.sh)
+LIB_PATH = os.environ.get("BBD_HIP_LIB", os.path.join(_HERE, "csrc", "libbbd_hip.so"))
 
 MAX_FRAME_SLOTS = 16
 MAX_CAND = 20
@@ -36,6 +37,7 @@ SIGNATURES = {
     "bbd_backproject_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_project3d_fwd": [_p, _p, _p, _p, _i, _i, _i, _d, _p],
     "bbd_ssim_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
 }
 
 

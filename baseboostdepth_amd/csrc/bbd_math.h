@@ -46,6 +46,70 @@ BBD_HD int bbd_reflect(int i, int n) {
   return i > n - 1 ? n - 1 : i;
 }
 
+/* ---------------------------------------------------------------- IEEE division, cheaper
+ * PyTorch's CPU ops divide with correctly rounded IEEE division, so the kernels must too.  hipcc's
+ * expansion of `a / b` is v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas, v_div_fixup; the scale /
+ * fixup instructions only matter for extreme exponents.  For operands of moderate exponent the
+ * same Newton step + two residual corrections give the identical correctly rounded quotient, and
+ * quotients that share a denominator share the refined reciprocal.  Lanes outside the safe
+ * exponent window (or non-finite) take the compiler's full sequence.  On the host: plain `/`.
+ * Checked against `/` on 2^28 random operand pairs by tests/test_gpu_parity.py. */
+#if defined(__HIP_DEVICE_COMPILE__)
+BBD_HD int bbd_exp_ok(float x) {           /* 2^-57 <= |x| < 2^58: any quotient of two such values,
+                                              and every intermediate, stays a normal number */
+  const unsigned e = (__float_as_uint(x) >> 23) & 0xffu;
+  return e >= 70u && e <= 184u;
+}
+BBD_HD float bbd_rcp_refined(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+BBD_HD float bbd_div_with(float n, float d, float r) {
+  float q = n * r;
+  q = fmaf(fmaf(-d, q, n), r, q);
+  return fmaf(fmaf(-d, q, n), r, q);
+}
+BBD_HD float bbd_div(float n, float d) {
+  if (bbd_exp_ok(d) && (bbd_exp_ok(n) || n == 0.0f)) return bbd_div_with(n, d, bbd_rcp_refined(d));
+  return n / d;
+}
+BBD_HD void bbd_div2(float n0, float n1, float d, float* q0, float* q1) {
+  if (bbd_exp_ok(d) && (bbd_exp_ok(n0) || n0 == 0.0f) && (bbd_exp_ok(n1) || n1 == 0.0f)) {
+    const float r = bbd_rcp_refined(d);
+    *q0 = bbd_div_with(n0, d, r);
+    *q1 = bbd_div_with(n1, d, r);
+  } else {
+    *q0 = n0 / d;
+    *q1 = n1 / d;
+  }
+}
+/* division by a launch constant d whose reciprocal rd = RN(1/d) was computed on the host */
+BBD_HD float bbd_div_const(float n, float d, float rd) {
+  if (bbd_exp_ok(n) || n == 0.0f) return bbd_div_with(n, d, rd);
+  return n / d;
+}
+BBD_HD float bbd_rcp_approx(float d) { return bbd_rcp_refined(d); }   /* <= 1 ulp; backward only */
+#else
+BBD_HD float bbd_div(float n, float d) { return n / d; }
+BBD_HD void bbd_div2(float n0, float n1, float d, float* q0, float* q1) { *q0 = n0 / d; *q1 = n1 / d; }
+BBD_HD float bbd_div_const(float n, float d, float rd) { (void)rd; return n / d; }
+BBD_HD float bbd_rcp_approx(float d) { return 1.0f / d; }
+#endif
+
+/* image size and the constants derived from it on the host */
+struct BbdDims {
+  int H, W;
+  float hm1, wm1;    /* (float)(H-1), (float)(W-1) */
+  float rh, rw;      /* RN(1/hm1), RN(1/wm1) */
+};
+BBD_HD BbdDims bbd_dims(int H, int W) {
+  BbdDims d;
+  d.H = H; d.W = W;
+  d.hm1 = (float)(H - 1); d.wm1 = (float)(W - 1);
+  d.rh = 1.0f / d.hm1; d.rw = 1.0f / d.wm1;
+  return d;
+}
+
 /* ---------------------------------------------------------------- projection (A2, A3, A4) */
 struct BbdSample {
   float ix, iy;      /* clamped source coordinates in pixels */
@@ -85,7 +149,7 @@ BBD_HD float bbd_dot4_hom(const float* a, float x, float y, float z) {   /* a . 
 }
 
 /* proj = 21 floats: P (3x4 row-major), inv_K[:3,:3] (row-major). */
-BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, int H, int W, BbdSample* o) {
+BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const BbdDims& dm, BbdSample* o) {
   const float* P = proj;
   const float* iK = proj + 12;
   const float fx = (float)xx, fy = (float)yy;
@@ -101,12 +165,11 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, int H, i
   const float qy = bbd_dot4_hom(P + 4, o->X, o->Y, o->Z);
   const float qz = bbd_dot4_hom(P + 8, o->X, o->Y, o->Z);
   o->zi = qz + BBD_EPS;                       /* layers.py:188 */
-  o->u = qx / o->zi;
-  o->v = qy / o->zi;
+  bbd_div2(qx, qy, o->zi, &o->u, &o->v);
   /* layers.py:191-193 normalise, then ATen grid_sampler unnormalise (align_corners=True) */
-  const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-  const float gx = (o->u / wm1 - 0.5f) * 2.0f;
-  const float gy = (o->v / hm1 - 0.5f) * 2.0f;
+  const float wm1 = dm.wm1, hm1 = dm.hm1;
+  const float gx = (bbd_div_const(o->u, wm1, dm.rw) - 0.5f) * 2.0f;
+  const float gy = (bbd_div_const(o->v, hm1, dm.rh) - 0.5f) * 2.0f;
   float ix = ((gx + 1.0f) / 2.0f) * wm1;
   float iy = ((gy + 1.0f) / 2.0f) * hm1;
   /* border padding: clip_coordinates; gradient is zeroed when the clamp is active */
@@ -119,34 +182,35 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, int H, i
 }
 
 struct BbdTaps {
-  int x0, y0;        /* north-west texel */
+  int i0, i1;        /* element offsets (inside one channel plane) of the north and south texel pairs */
   float w, e, n, s;  /* distances: w = ix-x0, e = 1-w, n = iy-y0, s = 1-n */
 };
 
-BBD_HD void bbd_taps(float ix, float iy, BbdTaps* t) {
+/* Tap geometry for clamped coordinates 0 <= ix <= W-1, 0 <= iy <= H-1.  The east / south taps fall
+ * outside the image only when ix == W-1 / iy == H-1 exactly, where their weight is 0 and ATen masks
+ * them to 0.  Instead of masking values: at ix == W-1 the pair is taken one texel to the left with
+ * w = 1 (so nw = s*0, ne = s*1 multiplies the same texel by the same weight), and at iy == H-1
+ * the south row index is clamped (weights n*e = n*w = 0).  Adding 0*finite terms in the FMA chain
+ * leaves the result bit-identical to the masked form. */
+BBD_HD void bbd_taps(float ix, float iy, const BbdDims& dm, BbdTaps* t) {
   const float x0f = floorf(ix), y0f = floorf(iy);
-  t->x0 = (int)x0f;
-  t->y0 = (int)y0f;
+  int x0 = (int)x0f;
+  const int y0 = (int)y0f;
   t->w = ix - x0f;
+  if (x0 > dm.W - 2) { x0 = dm.W - 2; t->w = 1.0f; }
   t->e = 1.0f - t->w;
   t->n = iy - y0f;
   t->s = 1.0f - t->n;
+  const int y1 = y0 + 1 < dm.H ? y0 + 1 : dm.H - 1;
+  t->i0 = y0 * dm.W + x0;
+  t->i1 = y1 * dm.W + x0;
 }
 
-/* The four texel values of one channel plane; out-of-range east/south taps read as 0
- * (their weight is 0 there).  Texel pairs are fetched as one 8-byte access. */
-BBD_HD void bbd_fetch4(const float* plane, int H, int W, const BbdTaps* t, float v[4]) {
-  const int xl = t->x0 < W - 1 ? t->x0 : W - 2;    /* x0 == W-1 only when ix == W-1 */
-  const int y1 = t->y0 + 1 < H ? t->y0 + 1 : H - 1;
-  const float* r0 = plane + (size_t)t->y0 * W + xl;
-  const float* r1 = plane + (size_t)y1 * W + xl;
-  const float a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1];
-  const int edge = (t->x0 != xl);
-  const int south = (t->y0 + 1 < H);
-  v[0] = edge ? a1 : a0;                       /* nw */
-  v[1] = edge ? 0.0f : a1;                     /* ne */
-  v[2] = south ? (edge ? b1 : b0) : 0.0f;      /* sw */
-  v[3] = south ? (edge ? 0.0f : b1) : 0.0f;    /* se */
+/* The four texel values (nw, ne, sw, se) of one channel plane. */
+BBD_HD void bbd_fetch4(const float* plane, const BbdTaps* t, float v[4]) {
+  const float* r0 = plane + t->i0;
+  const float* r1 = plane + t->i1;
+  v[0] = r0[0]; v[1] = r0[1]; v[2] = r1[0]; v[3] = r1[1];
 }
 
 /* ATen grid_sampler_2d (CPU, bilinear): nw*a + ne*b + sw*c + se*d evaluated as an FMA chain in
@@ -169,7 +233,7 @@ BBD_HD float bbd_ssim(float sx, float sxx, float sxy, float mu_y, float sig_y) {
   const float sig_xy = bbd_div9(sxy) - mu_x * mu_y;
   const float n = (2.0f * mu_x * mu_y + BBD_C1) * (2.0f * sig_xy + BBD_C2);
   const float d = (mu_x * mu_x + mu_y * mu_y + BBD_C1) * (sig_x + sig_y + BBD_C2);
-  const float v = (1.0f - n / d) / 2.0f;
+  const float v = (1.0f - bbd_div(n, d)) / 2.0f;
   return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);   /* NaN stays NaN like torch.clamp */
 }
 
@@ -198,13 +262,14 @@ BBD_HD void bbd_ssim_grad(float sx, float sxx, float sxy, float mu_y, float sig_
   const float n1 = 2.0f * mu_x * mu_y + BBD_C1, n2 = 2.0f * sig_xy + BBD_C2;
   const float d1 = mu_x * mu_x + mu_y * mu_y + BBD_C1, d2 = sig_x + sig_y + BBD_C2;
   const float n = n1 * n2, d = d1 * d2;
-  const float v = (1.0f - n / d) / 2.0f;
+  const float v = (1.0f - bbd_div(n, d)) / 2.0f;
   if (!(v >= 0.0f && v <= 1.0f)) {   /* clamp passes gradient on [0,1] only */
     *A = 0.0f; *B = 0.0f; *C = 0.0f;
     return;
   }
-  const float dvdn = -0.5f / d;
-  const float dvdd = 0.5f * n / (d * d);
+  const float rd = bbd_rcp_approx(d);
+  const float dvdn = -0.5f * rd;
+  const float dvdd = 0.5f * n * rd * rd;
   *A = dvdn * (2.0f * mu_y * (n2 - n1)) + dvdd * (2.0f * mu_x * (d2 - d1));
   *B = 2.0f * (dvdd * d1);
   *C = dvdn * (2.0f * n1);
@@ -232,7 +297,7 @@ BBD_HD void bbd_project_grad(const float* proj, const BbdSample* sm, float gix, 
   const float* P = proj;
   const float du = sm->clipx ? 0.0f : gix;
   const float dv = sm->clipy ? 0.0f : giy;
-  const float rz = 1.0f / sm->zi;
+  const float rz = bbd_rcp_approx(sm->zi);
   const float gq0 = du * rz, gq1 = dv * rz;
   const float gq2 = -(du * sm->u + dv * sm->v) * rz;
   const float gX = gq0 * P[0] + gq1 * P[4] + gq2 * P[8];

@@ -101,6 +101,7 @@ def main():
                     help="md2 = BASELINE configs[1]/[3] (the headline); boosted = configs[2] worst case m=7")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     args = ap.parse_args()
 
     from baseboostdepth_amd import distributed as bdist
@@ -115,6 +116,8 @@ def main():
     from baseboostdepth_amd.synthetic import synthetic_batch
 
     torch.manual_seed(42)
+    if args.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
     opt = make_options(args.batch, local, args.config)
     trainer = Trainer(opt)
     if args.channels_last:

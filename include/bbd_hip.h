@@ -130,6 +130,11 @@ int bbd_project3d_fwd(const float* points, const float* K, const float* T, float
                       int n, int H, int W, double eps, void* stream);
 int bbd_ssim_fwd(const float* x, const float* y, float* out, int n, int H, int W, void* stream);
 
+/* Device self-test: the kernels replace hipcc's IEEE division sequence by a cheaper one that is
+ * exact for moderate exponents (bbd_math.h).  Runs blocks*256*iters random operand tuples through
+ * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */
+int bbd_selftest_div(int blocks, int iters, unsigned seed, int32_t* mismatches, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,15 +43,16 @@ float photometric(const float* px, const float* py, int y, int x, int H, int W, 
 void warp_image(const float* src, const float* depth, const float* pose_row, int H, int W, float* out) {
   float proj[21];
   bbd_make_proj(pose_row, proj);
+  const BbdDims dm = bbd_dims(H, W);
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) {
       BbdSample sm;
-      bbd_project(proj, x, y, depth[(size_t)y * W + x], H, W, &sm);
+      bbd_project(proj, x, y, depth[(size_t)y * W + x], dm, &sm);
       BbdTaps t;
-      bbd_taps(sm.ix, sm.iy, &t);
+      bbd_taps(sm.ix, sm.iy, dm, &t);
       for (int ch = 0; ch < 3; ++ch) {
         float v[4];
-        bbd_fetch4(src + (size_t)ch * H * W, H, W, &t, v);
+        bbd_fetch4(src + (size_t)ch * H * W, &t, v);
         out[((size_t)ch * H + y) * W + x] = bbd_bilerp(v, &t);
       }
     }
@@ -168,13 +169,14 @@ int hp_warp_ssim_min_bwd(const void* const* frames, const float* target, const f
         for (int y = 0; y < H; ++y)
           for (int x = 0; x < W; ++x) {
             BbdSample sm;
-            bbd_project(pj, x, y, dep[(size_t)y * W + x], H, W, &sm);
+            const BbdDims dm = bbd_dims(H, W);
+            bbd_project(pj, x, y, dep[(size_t)y * W + x], dm, &sm);
             BbdTaps t;
-            bbd_taps(sm.ix, sm.iy, &t);
+            bbd_taps(sm.ix, sm.iy, dm, &t);
             float gix = 0, giy = 0;
             for (int ch = 0; ch < 3; ++ch) {
               float v[4];
-              bbd_fetch4(src + (size_t)ch * hw, H, W, &t, v);
+              bbd_fetch4(src + (size_t)ch * hw, &t, v);
               bbd_bilerp_grad(v, &t, gx[((size_t)ch * H + y) * W + x], &gix, &giy);
             }
             float gd, gp[12];

@@ -35,6 +35,16 @@ def test_native_library_is_loaded_and_single_hip_runtime(backend):
     assert len(runtimes) == 1, runtimes      # our .so must share torch's HIP runtime
 
 
+def test_cheap_division_is_ieee_exact(backend):
+    """2^28 random operand tuples: shared-reciprocal / constant-divisor divisions == hipcc's `/`."""
+    from baseboostdepth_amd._lib import ptr
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for seed in (1, 2):
+        backend.run("bbd_selftest_div", bad, 2048, 256, seed, ptr(bad))
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+
+
 @pytest.mark.parametrize("name", DIRECT_CASES)
 def test_fused_path_matches_reference_bit_for_bit(name, backend):
     case = Case(name, device=DEV)

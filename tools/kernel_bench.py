@@ -104,10 +104,21 @@ def main():
 
     res = {"config": args.config, "batch": B, "scales": scales, "NP": plan.NP, "NI": plan.NI,
            "cands_per_sample": [len(n) for n in plan.cand_names]}
-    for name, fn, nbytes in (("identity", k_ident, ib), ("fwd", k_fwd, fb), ("bwd(+reduce)", k_bwd, bb)):
+    # HIP events directly around each C-ABI launch (python overhead excluded)
+    timer = ops.KernelTimer()
+    for name, fn, nbytes, key in (("identity", k_ident, ib, "bbd_identity_loss_fwd"),
+                                  ("fwd", k_fwd, fb, "bbd_warp_ssim_min_fwd"),
+                                  ("bwd", k_bwd, bb, "bbd_warp_ssim_min_bwd")):
         for _ in range(args.warmup):
             fn()
-        ms_ = time_it(fn, args.iters)
+        torch.cuda.synchronize()
+        timer.reset()
+        be.timer = timer
+        for _ in range(args.iters):
+            fn()
+        torch.cuda.synchronize()
+        be.timer = None
+        ms_ = timer.summary()[key][1]
         res[name] = {"ms": round(ms_, 4), "alg_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / ms_ / 1e6, 1),
                      "frac_of_8TBps": round(nbytes / ms_ / 1e6 / 8000, 4)}
     for _ in range(args.warmup):
