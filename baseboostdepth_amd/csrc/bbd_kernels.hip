@@ -156,34 +156,59 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
                                               float* __restrict__ warped_out) {
   float pj[21];
   bbd_make_proj(pose_row, pj);
-  BbdTaps t[CellsT::N];
+#if defined(BBD_ABLATE_WARP)          // timing experiment only: no projection, no gathers
 #pragma unroll
   for (int k = 0; k < CellsT::N; ++k) {
-    BbdSample sm;
-    bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
-    bbd_taps(sm.ix, sm.iy, dm, &t[k]);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) s[ch][cl.lds[k]] = d[k] + pj[ch];
   }
-#pragma unroll
-  for (int k = 0; k < CellsT::N; ++k) {
-    float val[3];
-#if defined(BBD_ABLATE_GATHER)        // timing experiment only: coalesced loads instead of gathers
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) val[ch] = src[ch * hw + cl.pix[k]] + t[k].w;
-#else
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float v[4];
-      bbd_fetch4(src + ch * hw, &t[k], v);
-      val[ch] = bbd_bilerp(v, &t[k]);
-    }
+  return;
 #endif
+  // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
+  // its gathers are in flight together (6 x 8-byte loads per cell), then the blends.  The batch
+  // size trades loads in flight against VGPRs (occupancy); BBD_WARP_BATCH is a tuning knob.
+#ifndef BBD_WARP_BATCH
+#define BBD_WARP_BATCH 3
+#endif
+  constexpr int BATCH = BBD_WARP_BATCH;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) s[ch][cl.lds[k]] = val[ch];
-    if (warped_out != nullptr && cl.own[k]) {
-      float* o = warped_out + cl.pix[k];
-      o[0] = val[0];
-      o[hw] = val[1];
-      o[2 * hw] = val[2];
+  for (int k0 = 0; k0 < CellsT::N; k0 += BATCH) {
+    BbdTaps t[BATCH];
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk) {
+      const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
+      BbdSample sm;
+      bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+      bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
+    }
+    float v[BATCH][3][4];
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+#if defined(BBD_ABLATE_GATHER)        // timing experiment only: coalesced loads instead of gathers
+        const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
+        v[kk][ch][0] = v[kk][ch][1] = v[kk][ch][2] = v[kk][ch][3] = src[ch * hw + cl.pix[k]];
+#else
+        bbd_fetch4(src + ch * hw, &t[kk], v[kk][ch]);
+#endif
+      }
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk) {
+      if (k0 + kk >= CellsT::N) break;
+      const int k = k0 + kk;
+      float val[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        val[ch] = bbd_bilerp(v[kk][ch], &t[kk]);
+        s[ch][cl.lds[k]] = val[ch];
+      }
+      if (warped_out != nullptr && cl.own[k]) {
+        float* o = warped_out + cl.pix[k];
+        o[0] = val[0];
+        o[hw] = val[1];
+        o[2 * hw] = val[2];
+      }
     }
   }
 }
@@ -331,7 +356,12 @@ struct FwdArgs {
 #ifndef BBD_FWD_WAVES
 #define BBD_FWD_WAVES 1
 #endif
-__global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(FwdArgs a) {
+#ifdef BBD_FWD_VGPR
+#define BBD_FWD_ATTR __attribute__((amdgpu_num_vgpr(BBD_FWD_VGPR)))
+#else
+#define BBD_FWD_ATTR
+#endif
+__global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdArgs a) {
   // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
   // still read candidate c, so one barrier per warp candidate is enough
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
@@ -439,7 +469,15 @@ struct BwdArgs {
   int S, B, NP, ntiles, no_ssim;
 };
 
-__global__ __launch_bounds__(NT) void warp_ssim_min_bwd_kernel(BwdArgs a) {
+#ifndef BBD_BWD_WAVES
+#define BBD_BWD_WAVES 1
+#endif
+#ifdef BBD_BWD_VGPR
+#define BBD_BWD_ATTR __attribute__((amdgpu_num_vgpr(BBD_BWD_VGPR)))
+#else
+#define BBD_BWD_ATTR
+#endif
+__global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float s_ybuf[3 * BPLANE + 8];
   __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE + 8];
   __shared__ __attribute__((aligned(16))) float s_cf[9][CPLANE];  // [channel*3 + {A,B,C}], sparse
@@ -551,7 +589,11 @@ __global__ __launch_bounds__(NT) void warp_ssim_min_bwd_kernel(BwdArgs a) {
     __syncthreads();
 
     // ---- phase C: SSIM partials A,B,C (d loss / d{mu_x, E[x^2], E[xy]}) of the loss pixels won by c
+#if defined(BBD_ABLATE_BWD_COEF)
+    const int nwin = 0;
+#else
     const int nwin = a.no_ssim ? 0 : s_count;
+#endif
     for (int idx = threadIdx.x; idx < nwin; idx += NT) {
       const int cell = s_list[idx];
       const int pr = cell / CS, pc = cell - pr * CS;
@@ -578,7 +620,11 @@ __global__ __launch_bounds__(NT) void warp_ssim_min_bwd_kernel(BwdArgs a) {
 
     // ---- phase G: adjoint of reflect-pad + 3x3 mean at this thread's 4 texels
     float gx[3][PPT];
+#ifdef BBD_BWD_ROLL_CH
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int ch = 0; ch < 3; ++ch) {
       float xw[8], yw[8];
       {

@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--no-fused-adam", action="store_true")
     args = ap.parse_args()
 
     from baseboostdepth_amd import distributed as bdist
@@ -119,6 +120,7 @@ def main():
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
     opt = make_options(args.batch, local, args.config)
+    opt.fused_adam = not args.no_fused_adam
     trainer = Trainer(opt)
     if args.channels_last:
         for m in trainer.models.values():

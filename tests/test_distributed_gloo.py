@@ -55,15 +55,16 @@ def _worker_flat(rank, world, port, q):
     tr.grad_sync = None
     flat = bdist.attach(tr)
     assert tr.grad_sync is not None
-    assert all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in net.parameters())
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 6, generator=g)
     y = torch.randn(8, 1, generator=g)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     flat.zero()
+    assert all(p.grad is None for p in net.parameters())
     ((net(xs) - ys) ** 2).mean().backward()
-    assert flat.flat.abs().sum() > 0          # backward accumulated INTO the flat buffer
-    tr.grad_sync()
+    tr.grad_sync()                             # pack into the flat buffer + one all-reduce
+    lo, hi = flat.flat.data_ptr(), flat.flat.data_ptr() + flat.nbytes
+    assert all(lo <= p.grad.data_ptr() < hi for p in net.parameters())   # grads are views of it
     got = flat.flat.clone()
     # single-process reference on the concatenated batch, same (rank-0) weights
     ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
