@@ -34,6 +34,9 @@ SIGNATURES = {
     "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],
     "bbd_disp_to_depth_fwd": [_p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
     "bbd_disp_to_depth_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
+    "bbd_smooth_chunks": [],
+    "bbd_smooth_loss_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "bbd_smooth_loss_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "bbd_backproject_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_project3d_fwd": [_p, _p, _p, _p, _i, _i, _i, _d, _p],
     "bbd_ssim_fwd": [_p, _p, _p, _i, _i, _i, _p],
@@ -61,6 +64,7 @@ class HipLibrary:
             fn.restype = _i
         if self._dll.bbd_abi_version() != ABI_VERSION:
             raise BbdError("libbbd_hip.so ABI version mismatch")
+        self.smooth_chunks = self._dll.bbd_smooth_chunks()
         self.tile_w = self._dll.bbd_tile_w()
         self.tile_h = self._dll.bbd_tile_h()
 

@@ -754,7 +754,6 @@ __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __re
                                                                float* __restrict__ gdisp, int B, int h, int w,
                                                                int H, int W, float lo, float span) {
   const size_t n = (size_t)B * h * w;
-  const int fy = (H + h - 1) / h, fx = (W + w - 1) / w;
   for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
     const int x = (int)(i % w);
     const int y = (int)((i / w) % h);
@@ -766,8 +765,13 @@ __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __re
       const float sc = lo + span * d[(size_t)y * w + x];
       acc = g[(size_t)y * W + x] * (-span / (sc * sc));
     } else {
-      const int oy_lo = max(0, (y - 1) * fy), oy_hi = min(H - 1, (y + 2) * fy);
-      const int ox_lo = max(0, (x - 1) * fx), ox_hi = min(W - 1, (x + 2) * fx);
+      // output rows/cols whose source index lies in [y-1, y+1): (o+0.5)*h/H - 0.5 in that range,
+      // widened by one on each side (the exact membership test is repeated inside the loop)
+      const float sy_ = (float)H / (float)h, sx_ = (float)W / (float)w;
+      const int oy_lo = max(0, (int)floorf(((float)y - 0.5f) * sy_ - 0.5f) - 1);
+      const int oy_hi = min(H - 1, (int)ceilf(((float)y + 1.5f) * sy_ - 0.5f) + 1);
+      const int ox_lo = max(0, (int)floorf(((float)x - 0.5f) * sx_ - 0.5f) - 1);
+      const int ox_hi = min(W - 1, (int)ceilf(((float)x + 1.5f) * sx_ - 0.5f) + 1);
       for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         int y0, y1;
         float ly0, ly1;
@@ -889,6 +893,113 @@ __global__ __launch_bounds__(NT) void ssim_map_kernel(const float* __restrict__ 
         out[(size_t)item * img + ch * hw + (size_t)yy * W + xx + j] = bbd_ssim(sx, sxx, sxy, mu_y[ch][j], sg_y[ch][j]);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Edge-aware smoothness of the mean-normalised disparity (layers.py:203-216, trainer.py:560-564).
+// Deterministic: per-(sample, row-chunk) partial sums, fixed reduction order.
+// ------------------------------------------------------------------------------------------
+constexpr int SM_CHUNKS = 16;
+
+__device__ __forceinline__ float block_sum_all(float v, float* s_red4) {   // every thread gets the total
+  const float w = wave_sum63(v);
+  if ((threadIdx.x & 63) == 63) s_red4[threadIdx.x >> 6] = w;
+  __syncthreads();
+  const float t = ((s_red4[0] + s_red4[1]) + s_red4[2]) + s_red4[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(NT) void smooth_mean_kernel(const float* __restrict__ disp, float* __restrict__ mean,
+                                                         int hw) {
+  __shared__ float s_red4[4];
+  const float* d = disp + (size_t)blockIdx.x * hw;
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < hw; i += NT) acc += d[i];
+  const float tot = block_sum_all(acc, s_red4);
+  if (threadIdx.x == 0) mean[blockIdx.x] = tot / (float)hw;
+}
+
+__device__ __forceinline__ float edge_weight(const float* img, int hw, int i0, int i1) {
+  const float g = fabsf(img[i0] - img[i1]) + fabsf(img[i0 + hw] - img[i1 + hw]) +
+                  fabsf(img[i0 + 2 * hw] - img[i1 + 2 * hw]);
+  return __expf(-g * (1.0f / 3.0f));
+}
+
+__global__ __launch_bounds__(NT) void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                        const float* __restrict__ mean, float* __restrict__ sums,
+                                                        int h, int w) {
+  __shared__ float s_red4[4];
+  const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
+  const int hw = h * w;
+  const float* d = disp + (size_t)b * hw;
+  const float* im = img + (size_t)b * 3 * hw;
+  const float inv = 1.0f / (mean[b] + 1e-7f);
+  const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
+  const int y0 = chunk * rows, y1 = min(h, y0 + rows);
+  float ax = 0.0f, ay = 0.0f;
+  for (int i = y0 * w + threadIdx.x; i < y1 * w; i += NT) {
+    const int y = i / w, x = i - y * w;
+    const float n0 = d[i] * inv;
+    if (x < w - 1) ax += fabsf(n0 - d[i + 1] * inv) * edge_weight(im, hw, i, i + 1);
+    if (y < h - 1) ay += fabsf(n0 - d[i + w] * inv) * edge_weight(im, hw, i, i + w);
+  }
+  const float tx = block_sum_all(ax, s_red4);
+  const float ty = block_sum_all(ay, s_red4);
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x * 2 + 0] = tx;
+    sums[blockIdx.x * 2 + 1] = ty;
+  }
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// pass 1: gn = d loss / d norm (stored into grad), and per-chunk partial of sum(gn * disp)
+__global__ __launch_bounds__(NT) void smooth_bwd1_kernel(const float* __restrict__ disp, const float* __restrict__ img,
+                                                         const float* __restrict__ mean, const float* __restrict__ gscale,
+                                                         float* __restrict__ grad, float* __restrict__ dots, int B,
+                                                         int h, int w) {
+  __shared__ float s_red4[4];
+  const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
+  const int hw = h * w;
+  const float* d = disp + (size_t)b * hw;
+  const float* im = img + (size_t)b * 3 * hw;
+  float* gout = grad + (size_t)b * hw;
+  const float inv = 1.0f / (mean[b] + 1e-7f);
+  const float g = gscale[0];
+  const float gxs = g / ((float)B * (float)h * (float)(w - 1));
+  const float gys = g / ((float)B * (float)(h - 1) * (float)w);
+  const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
+  const int y0 = chunk * rows, y1 = min(h, y0 + rows);
+  float dot = 0.0f;
+  for (int i = y0 * w + threadIdx.x; i < y1 * w; i += NT) {
+    const int y = i / w, x = i - y * w;
+    const float n0 = d[i] * inv;
+    float gn = 0.0f;
+    if (x < w - 1) gn += gxs * sgn(n0 - d[i + 1] * inv) * edge_weight(im, hw, i, i + 1);
+    if (x > 0) gn -= gxs * sgn(d[i - 1] * inv - n0) * edge_weight(im, hw, i - 1, i);
+    if (y < h - 1) gn += gys * sgn(n0 - d[i + w] * inv) * edge_weight(im, hw, i, i + w);
+    if (y > 0) gn -= gys * sgn(d[i - w] * inv - n0) * edge_weight(im, hw, i - w, i);
+    gout[i] = gn;
+    dot += gn * d[i];
+  }
+  const float t = block_sum_all(dot, s_red4);
+  if (threadIdx.x == 0) dots[blockIdx.x] = t;
+}
+
+// pass 2: grad_disp = gn / (m+eps) - sum(gn*disp) / (N (m+eps)^2)
+__global__ __launch_bounds__(NT) void smooth_bwd2_kernel(const float* __restrict__ mean, const float* __restrict__ dots,
+                                                         float* __restrict__ grad, int h, int w) {
+  const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
+  const int hw = h * w;
+  float dot = 0.0f;
+  for (int k = 0; k < SM_CHUNKS; ++k) dot += dots[b * SM_CHUNKS + k];
+  const float inv = 1.0f / (mean[b] + 1e-7f);
+  const float sub = dot * inv * inv / (float)hw;
+  float* gout = grad + (size_t)b * hw;
+  const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
+  const int y0 = chunk * rows, y1 = min(h, y0 + rows);
+  for (int i = y0 * w + threadIdx.x; i < y1 * w; i += NT) gout[i] = gout[i] * inv - sub;
 }
 
 // Self-test of the cheap exact divisions (bbd_math.h) against hipcc's IEEE `/`.
@@ -1037,6 +1148,29 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* gra
   const unsigned grid = (unsigned)((n + NT - 1) / NT < 4096 ? (n + NT - 1) / NT : 4096);
   hipLaunchKernelGGL(disp_to_depth_bwd_kernel, dim3(grid), dim3(NT), 0, static_cast<hipStream_t>(stream), disp,
                      grad_depth, grad_disp, B, h, w, H, W, lo, span);
+  return launch_status();
+}
+
+int bbd_smooth_chunks(void) { return SM_CHUNKS; }
+
+int bbd_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, float* sums, int B, int h, int w,
+                        void* stream) {
+  if (!disp || !img || !mean_disp || !sums || B <= 0 || h < 2 || w < 2) return BBD_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(smooth_mean_kernel, dim3((unsigned)B), dim3(NT), 0, st, disp, mean_disp, h * w);
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, img, mean_disp, sums,
+                     h, w);
+  return launch_status();
+}
+
+int bbd_smooth_loss_bwd(const float* disp, const float* img, const float* mean_disp, const float* gscale,
+                        float* grad_disp, float* dots, int B, int h, int w, void* stream) {
+  if (!disp || !img || !mean_disp || !gscale || !grad_disp || !dots || B <= 0 || h < 2 || w < 2) return BBD_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(smooth_bwd1_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, img, mean_disp,
+                     gscale, grad_disp, dots, B, h, w);
+  hipLaunchKernelGGL(smooth_bwd2_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, mean_disp, dots, grad_disp,
+                     h, w);
   return launch_status();
 }
 

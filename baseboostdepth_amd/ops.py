@@ -57,6 +57,9 @@ class HipBackend:
     def num_tiles(self, H, W):
         return self.lib.num_tiles(H, W)
 
+    def smooth_chunks(self):
+        return self.lib.smooth_chunks
+
     @staticmethod
     def _check(*tensors):
         for t in tensors:
@@ -155,6 +158,42 @@ class _DispPyramidToDepth(torch.autograd.Function):
 def disp_pyramid_to_depth(disps, H, W, min_depth, max_depth, backend=None):
     """[("disp", s)] list -> depth [S,B,H,W]; depth[i] is the reference's outputs[("depth",0,s_i)]."""
     return _DispPyramidToDepth.apply(H, W, min_depth, max_depth, backend or default_backend(), *disps)
+
+
+# ---------------------------------------------------------------------------- smoothness
+class _SmoothLoss(torch.autograd.Function):
+    """get_smooth_loss(disp / (mean(disp)+1e-7), img) as two launches forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, disp, img, backend):
+        B, _, h, w = disp.shape
+        disp, img = disp.contiguous(), img.contiguous()
+        backend._check(disp, img)
+        chunks = backend.smooth_chunks()
+        mean = torch.empty(B, device=disp.device, dtype=torch.float32)
+        sums = torch.empty(B, chunks, 2, device=disp.device, dtype=torch.float32)
+        backend.run("bbd_smooth_loss_fwd", disp, ptr(disp), ptr(img), ptr(mean), ptr(sums), B, h, w)
+        ctx.save_for_backward(disp, img, mean)
+        ctx.meta = (backend, chunks)
+        tot = sums.sum(dim=(0, 1))
+        return tot[0] / (B * h * (w - 1)) + tot[1] / (B * (h - 1) * w)
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img, mean = ctx.saved_tensors
+        backend, chunks = ctx.meta
+        B, _, h, w = disp.shape
+        gscale = g.reshape(1).contiguous().to(torch.float32)
+        grad = torch.empty_like(disp)
+        dots = torch.empty(B, chunks, device=disp.device, dtype=torch.float32)
+        backend.run("bbd_smooth_loss_bwd", disp, ptr(disp), ptr(img), ptr(mean), ptr(gscale), ptr(grad), ptr(dots),
+                    B, h, w)
+        return grad, None, None
+
+
+def normalised_smooth_loss(disp, img, backend=None):
+    """layers.get_smooth_loss(disp / (disp.mean(2,True).mean(3,True) + 1e-7), img)  (trainer.py:560-563)."""
+    return _SmoothLoss.apply(disp, img, backend or default_backend())
 
 
 # ---------------------------------------------------------------------------- identity pre-pass

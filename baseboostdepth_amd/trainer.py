@@ -271,8 +271,8 @@ class Trainer:
         for i, s in enumerate(opt.scales):
             loss = outputs[("bbd", "loss_sum")][i] / n_px                     # to_optimise.mean(), :557
             disp, color = outputs[("disp", s)], inputs[("color", 0, s)]
-            norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
-            loss = loss + opt.disparity_smoothness * get_smooth_loss(norm_disp, color) / (2 ** s)
+            smooth = ops.normalised_smooth_loss(disp, color, self._backend())         # :560-563, layers.py:203-216
+            loss = loss + opt.disparity_smoothness * smooth / (2 ** s)
             total = total + loss
             losses["loss/{}".format(s)] = loss
         losses["loss"] = total / self.num_scales

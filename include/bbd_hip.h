@@ -117,6 +117,20 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* gra
                           int B, int h, int w, int H, int W,
                           double min_depth, double max_depth, void* stream);
 
+/* Edge-aware smoothness of the mean-normalised disparity: layers.get_smooth_loss
+ * (layers.py:203-216) applied to disp / (mean_{H,W}(disp) + 1e-7) as in trainer.py:560-563.
+ *   disp [B,h,w], img [B,3,h,w]
+ *   fwd : mean_disp out [B]; sums out [B, bbd_smooth_chunks(), 2] partial sums of the x- and
+ *         y-terms; smooth = sum(x-terms)/(B*h*(w-1)) + sum(y-terms)/(B*(h-1)*w)
+ *   bwd : gscale [1] device scalar dL/d(smooth); dots scratch [B, bbd_smooth_chunks()];
+ *         grad_disp out [B,h,w] (overwritten).  Deterministic (fixed reduction order).        */
+int bbd_smooth_chunks(void);
+int bbd_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, float* sums,
+                        int B, int h, int w, void* stream);
+int bbd_smooth_loss_bwd(const float* disp, const float* img, const float* mean_disp,
+                        const float* gscale, float* grad_disp, float* dots,
+                        int B, int h, int w, void* stream);
+
 /* Stand-alone forward kernels behind the reference's layer classes (API surface only; the
  * training step uses the fused entry points above and never materialises these tensors).
  *   bbd_backproject_fwd : layers.BackprojectDepth.forward (layers.py:160-167)

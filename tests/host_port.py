@@ -32,6 +32,9 @@ class HostPortBackend:
     def num_tiles(self, H, W):
         return 1
 
+    def smooth_chunks(self):
+        return 1
+
     @staticmethod
     def _check(*tensors):
         for t in tensors:

@@ -240,6 +240,64 @@ int hp_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad
   return 0;
 }
 
+// smoothness (plain loops; single "chunk" layout: sums [B,1,2], dots [B,1])
+static float hp_edge(const float* im, int hw, int i0, int i1) {
+  const float g = fabsf(im[i0] - im[i1]) + fabsf(im[i0 + hw] - im[i1 + hw]) + fabsf(im[i0 + 2 * hw] - im[i1 + 2 * hw]);
+  return expf(-g * (1.0f / 3.0f));
+}
+static float hp_sgn(float v) { return v > 0 ? 1.0f : (v < 0 ? -1.0f : 0.0f); }
+
+int hp_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, float* sums, int B, int h, int w) {
+  const int hw = h * w;
+  for (int b = 0; b < B; ++b) {
+    const float* d = disp + (size_t)b * hw;
+    const float* im = img + (size_t)b * 3 * hw;
+    double m = 0;
+    for (int i = 0; i < hw; ++i) m += d[i];
+    mean_disp[b] = (float)(m / hw);
+    const float inv = 1.0f / (mean_disp[b] + 1e-7f);
+    double ax = 0, ay = 0;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const int i = y * w + x;
+        if (x < w - 1) ax += fabsf(d[i] * inv - d[i + 1] * inv) * hp_edge(im, hw, i, i + 1);
+        if (y < h - 1) ay += fabsf(d[i] * inv - d[i + w] * inv) * hp_edge(im, hw, i, i + w);
+      }
+    sums[b * 2 + 0] = (float)ax;
+    sums[b * 2 + 1] = (float)ay;
+  }
+  return 0;
+}
+
+int hp_smooth_loss_bwd(const float* disp, const float* img, const float* mean_disp, const float* gscale,
+                       float* grad, float* dots, int B, int h, int w) {
+  const int hw = h * w;
+  const float gxs = gscale[0] / ((float)B * h * (w - 1)), gys = gscale[0] / ((float)B * (h - 1) * w);
+  for (int b = 0; b < B; ++b) {
+    const float* d = disp + (size_t)b * hw;
+    const float* im = img + (size_t)b * 3 * hw;
+    float* go = grad + (size_t)b * hw;
+    const float inv = 1.0f / (mean_disp[b] + 1e-7f);
+    double dot = 0;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const int i = y * w + x;
+        const float n0 = d[i] * inv;
+        float gn = 0;
+        if (x < w - 1) gn += gxs * hp_sgn(n0 - d[i + 1] * inv) * hp_edge(im, hw, i, i + 1);
+        if (x > 0) gn -= gxs * hp_sgn(d[i - 1] * inv - n0) * hp_edge(im, hw, i - 1, i);
+        if (y < h - 1) gn += gys * hp_sgn(n0 - d[i + w] * inv) * hp_edge(im, hw, i, i + w);
+        if (y > 0) gn -= gys * hp_sgn(d[i - w] * inv - n0) * hp_edge(im, hw, i - w, i);
+        go[i] = gn;
+        dot += (double)gn * d[i];
+      }
+    dots[b] = (float)dot;
+    const float sub = (float)dot * inv * inv / (float)hw;
+    for (int i = 0; i < hw; ++i) go[i] = go[i] * inv - sub;
+  }
+  return 0;
+}
+
 // exhaustive-ish check helpers for the constant divisions
 int hp_check_div(uint32_t start, uint32_t count, uint32_t stride) {
   int bad = 0;

@@ -262,3 +262,23 @@ def test_full_size_properties(backend):
             assert bool((res1[("bbd", "to_optimise")][0, b] <= cand).all())
     # (5) arg-min ids stay inside the candidate list
     assert int(res1[("bbd", "argmin")].max()) < 4
+
+
+def test_smoothness_kernel_against_oracle(backend):
+    """layers.get_smooth_loss on the mean-normalised disparity, forward and backward, BASELINE sizes."""
+    from baseboostdepth_amd import ops
+    from oracle import hotpath_ref as O
+    gen = torch.Generator().manual_seed(9)
+    for s in (0, 2):
+        h, w = 192 >> s, 640 >> s
+        disp = torch.rand(3, 1, h, w, generator=gen) * 0.8 + 0.01
+        img = torch.round(torch.rand(3, 3, h, w, generator=gen) * 255) / 255
+        dc = disp.clone().requires_grad_(True)
+        ref = O.smooth_loss(dc / (dc.mean(2, True).mean(3, True) + 1e-7), img)
+        ref.backward()
+        dg = disp.clone().to(DEV).requires_grad_(True)
+        got = ops.normalised_smooth_loss(dg, img.to(DEV), backend)
+        got.backward()
+        assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref))), (float(got), float(ref))
+        err = float((dg.grad.cpu() - dc.grad).abs().max()) / float(dc.grad.abs().max())
+        assert err < 1e-3, (s, err)
