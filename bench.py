@@ -121,7 +121,10 @@ def main():
         torch.backends.cudnn.benchmark = True
     opt = make_options(args.batch, local, args.config)
     opt.fused_adam = not args.no_fused_adam
-    trainer = Trainer(opt)
+    run_scales = list(opt.scales)
+    opt.scales = list(SCALES)      # networks + num_scales are built for 4 scales (trainer.py:44); the epoch>=10
+    trainer = Trainer(opt)         # curriculum then trains on scale 0 only (run_epoch, trainer.py:209-212)
+    trainer.opt.scales = run_scales
     if args.channels_last:
         for m in trainer.models.values():
             m.to(memory_format=torch.channels_last)

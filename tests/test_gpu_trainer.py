@@ -1,0 +1,114 @@
+"""GPU tier: Trainer.process_batch / train_step end to end with the real ResNet-18 networks, and the
+hot-path part of it re-checked against the live oracle on the networks' own outputs."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_opt(H, W, B, scales, boosted):
+    return types.SimpleNamespace(
+        height=H, width=W, batch_size=B, scales=list(scales), frame_ids=[0, -1, 1], min_depth=0.1, max_depth=100.0,
+        disparity_smoothness=1e-3, no_ssim=False, trimin=boosted, decomp=boosted, pose_error=5.5,
+        incremental_skip=boosted, partial_skip=boosted, materialize_warps=False, num_layers=18,
+        weights_init="scratch", learning_rate=1e-4, no_cuda=False, cuda=0, load_weights_folder="None",
+        log_dir="/tmp", model_name="t")
+
+
+def oracle_on_outputs(tr, inputs, outputs, opt, ms):
+    """Run the CPU oracle on the disparities / poses the GPU networks produced."""
+    from oracle import hotpath_ref as O
+    plan = tr.plan
+    cin = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    disp = {s: outputs[("disp", s)].detach().cpu().requires_grad_(True) for s in opt.scales}
+    poses, perr = {}, {}
+    job_poses = tr._job_poses(inputs, outputs)
+    for (kind, f), T in job_poses.items():
+        if f == "s":
+            continue
+        (poses if kind == "T" else perr)[f] = T.detach().cpu()
+    return O.hot_path(cin, disp, poses, ms, opt.scales, opt.trimin, opt.decomp, cin["noise"].cpu(), opt.height,
+                      opt.width, poses_error=perr), disp
+
+
+@pytest.mark.parametrize("boosted,ms,scales,cutt", [
+    (False, [1, 1, 1], [0, 1, 2, 3], 0.3),
+    (True, [3, 1, 2, 5], [0], 1.35),
+    (True, [2, 1, 0, 2], [0, 1, 2, 3], 0.3),
+])
+def test_process_batch_end_to_end(boosted, ms, scales, cutt):
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, B = 96, 160, len(ms)
+    torch.manual_seed(0)
+    # like the reference: built with the default four scales (num_scales frozen at 4, trainer.py:44),
+    # the curriculum then narrows opt.scales per epoch (run_epoch, trainer.py:209-212)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], boosted)
+    tr = Trainer(opt)
+    tr.opt.scales = list(scales)
+    tr.set_train()
+    inputs = synthetic_batch(ms, H, W, scales, device=DEV, seed=3)
+    inputs["cutt"] = torch.tensor(cutt)
+    tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+    outputs, losses = tr.process_batch(inputs)
+    assert torch.isfinite(losses["loss"])
+    for s in scales:
+        assert outputs[("disp", s)].shape == (B, 1, H >> s, W >> s)
+        assert outputs[("depth", 0, s)].shape == (B, 1, H, W)
+    ref, ref_disp = oracle_on_outputs(tr, inputs, outputs, opt, ms)
+    assert abs(float(losses["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
+    for i, s in enumerate(scales):
+        got = outputs[("bbd", "to_optimise")][i].cpu()
+        assert float((got - ref["min/%d" % s]).abs().max()) < 1e-4
+        mism = outputs[("bbd", "argmin")][i].cpu() != ref["argmin/%d" % s]
+        assert int((mism & (ref["margin/%d" % s] > 2e-4)).sum()) == 0
+    # gradients reach all four networks (the unused torchvision fc layers stay without gradient)
+    losses["loss"].backward()
+    for name, model in tr.models.items():
+        got = [p.grad is not None and float(p.grad.abs().sum()) > 0 for n, p in model.named_parameters()
+               if ".fc." not in n]
+        assert sum(got) >= 0.75 * len(got), name     # unused-scale dispconvs get none when scales=[0]
+
+
+def test_train_step_updates_weights_and_is_deterministic():
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, ms = 96, 160, [1, 1]
+    losses = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        tr = Trainer(make_opt(H, W, 2, [0, 1, 2, 3], False))
+        tr.set_train()
+        inputs = synthetic_batch(ms, H, W, [0, 1, 2, 3], device=DEV, seed=3)
+        before = [p.detach().clone() for p in tr.models["depth"].parameters()]
+        seq = []
+        for _ in range(3):
+            _, l = tr.train_step(dict(inputs))
+            seq.append(float(l["loss"].detach()))
+        after = list(tr.models["depth"].parameters())
+        assert any(float((a - b).abs().max()) > 0 for a, b in zip(after, before))
+        losses.append(seq)
+    assert abs(losses[0][0] - losses[1][0]) < 1e-6          # same seed, same first loss
+    assert all(l == l for l in losses[0])                    # finite
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from baseboostdepth_amd.trainer import Trainer
+    opt = make_opt(96, 160, 2, [0, 1, 2, 3], False)
+    opt.log_dir = str(tmp_path)
+    torch.manual_seed(1)
+    a = Trainer(opt)
+    folder = a.save_model("unit")
+    sd = torch.load(folder + "/encoder.pth")
+    assert sd["height"] == 96 and sd["width"] == 160          # consumers read the resolution from here
+    opt2 = make_opt(96, 160, 2, [0, 1, 2, 3], False)
+    opt2.load_weights_folder = folder
+    opt2.models_to_load = ["encoder", "depth", "pose_encoder", "pose"]
+    torch.manual_seed(2)
+    b = Trainer(opt2)
+    for name in a.models:
+        for (k, v), (_, w) in zip(a.models[name].state_dict().items(), b.models[name].state_dict().items()):
+            assert torch.equal(v, w), (name, k)
