@@ -2,8 +2,8 @@
 
 Same names, constructor arguments and return shapes as the reference so that `trainer.py`- and
 `evaluate_depth.py`-style callers are drop-in.  The geometry / photometric classes run as HIP
-kernels through the C ABI (include/bbd_hip.h); small host-side helpers that never touch a
-full-resolution tensor (pose matrices) stay as a handful of torch ops.
+kernels through the C ABI (include/bbd_hip.h), including the pose-matrix composition
+(`transformation_from_parameters`, one launch each way on GPU tensors).
 """
 import numpy as np
 import torch
@@ -49,7 +49,17 @@ def get_translation_matrix(translation_vector):
 
 
 def transformation_from_parameters(axisangle, translation, invert=False):
-    """(axisangle, translation) -> 4x4; inverted form is R^T @ T(-t)  (layers.py:25-42)."""
+    """(axisangle, translation) [n,1,3] -> [n,4,4]; inverted form is R^T @ T(-t)  (layers.py:25-42).
+
+    GPU tensors go through the fused pose-matrix kernel (one launch forward, one backward, instead
+    of ~35 element-wise launches each way); host tensors - fixtures, synthetic-pose helpers - use the
+    op-for-op torch form below, which is what the golden vectors pin."""
+    if axisangle.is_cuda:
+        return ops.pose_matrix(axisangle, translation, invert)
+    return _transformation_from_parameters_torch(axisangle, translation, invert)
+
+
+def _transformation_from_parameters_torch(axisangle, translation, invert=False):
     R = rot_from_axisangle(axisangle)
     t = translation.clone()
     if invert:

@@ -160,6 +160,35 @@ def disp_pyramid_to_depth(disps, H, W, min_depth, max_depth, backend=None):
     return _DispPyramidToDepth.apply(H, W, min_depth, max_depth, backend or default_backend(), *disps)
 
 
+# ---------------------------------------------------------------------------- pose matrix
+class _PoseMatrix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert, backend):
+        aa = axisangle.reshape(-1, 3).contiguous()
+        tr = translation.reshape(-1, 3).contiguous()
+        backend._check(aa, tr)
+        n = aa.shape[0]
+        M = torch.empty(n, 4, 4, device=aa.device, dtype=torch.float32)
+        backend.run("bbd_pose_matrix_fwd", aa, ptr(aa), ptr(tr), ptr(M), n, int(invert))
+        ctx.save_for_backward(aa, tr)
+        ctx.meta = (bool(invert), backend, axisangle.shape, translation.shape)
+        return M
+
+    @staticmethod
+    def backward(ctx, gM):
+        aa, tr = ctx.saved_tensors
+        invert, backend, shp_a, shp_t = ctx.meta
+        gM = gM.contiguous()
+        ga, gt = torch.empty_like(aa), torch.empty_like(tr)
+        backend.run("bbd_pose_matrix_bwd", aa, ptr(aa), ptr(tr), ptr(gM), ptr(ga), ptr(gt), aa.shape[0], int(invert))
+        return ga.view(shp_a), gt.view(shp_t), None, None
+
+
+def pose_matrix(axisangle, translation, invert=False, backend=None):
+    """layers.transformation_from_parameters as one kernel (forward) + one (backward)."""
+    return _PoseMatrix.apply(axisangle, translation, invert, backend or default_backend())
+
+
 # ---------------------------------------------------------------------------- smoothness
 class _SmoothLoss(torch.autograd.Function):
     """get_smooth_loss(disp / (mean(disp)+1e-7), img) as two launches forward, two backward."""

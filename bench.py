@@ -71,19 +71,38 @@ def cpu_baseline(batch=4, budget_s=25.0):
     opt = torch.optim.Adam(params, 1e-4)
     inputs = synthetic_batch(ms, H, W, SCALES, device="cpu", seed=42)
     noise = inputs.pop("noise")
-    cores = torch.get_num_threads()
-    md2_step(models, opt, inputs, ms, SCALES, H, W, noise)          # warm-up (allocator, MKL-DNN primitives)
-    times, t_all = [], time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_all) < budget_s * 0.6:
+    # pick the thread count: PyTorch defaults to every hardware thread it can see, which can be far
+    # more than this process is allowed to run on (measured here: 128 threads 0.64 images/s vs 16
+    # threads 9.3 images/s) - try the scheduler-affinity count and smaller powers of two, keep the best
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else torch.get_num_threads()
+    cands = sorted({c for c in (8, 16, 32, 64, avail) if c <= max(avail, 8)})
+    md2_step(models, opt, inputs, ms, SCALES, H, W, noise)          # warm-up (allocator, oneDNN primitives)
+    t_all, best, probe = time.perf_counter(), None, {}
+    for c in cands:
+        torch.set_num_threads(c)
+        md2_step(models, opt, inputs, ms, SCALES, H, W, noise)
+        t0 = time.perf_counter()
+        md2_step(models, opt, inputs, ms, SCALES, H, W, noise)
+        probe[c] = time.perf_counter() - t0
+        if best is None or probe[c] < probe[best]:
+            best = c
+        elif probe[c] > 1.5 * probe[best] or (time.perf_counter() - t_all) > budget_s * 0.5:
+            break
+    cores = best
+    torch.set_num_threads(cores)
+    times = []
+    while len(times) < 5 and (time.perf_counter() - t_all) < budget_s * 0.8:
         t0 = time.perf_counter()
         md2_step(models, opt, inputs, ms, SCALES, H, W, noise)
         times.append(time.perf_counter() - t0)
+    times = times or [probe[best]]
     med = sorted(times)[len(times) // 2]
     out = {"value": round(batch / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-           "sample": "%d full MD2 steps (ResNet-18 nets + oracle hot path + Adam), batch %d, 640x192, "
-                     "4 scales, median step %.3f s" % (len(times), batch, med)}
-    if (time.perf_counter() - t_all) < budget_s * 0.5:
-        torch.set_num_threads(1)
+           "sample": "%d full MD2 steps (ResNet-18 nets + oracle hot path + Adam), batch %d, 640x192, 4 scales, "
+                     "median step %.3f s; threads probed %s of %d schedulable" % (
+                         len(times), batch, med, {k: round(v, 2) for k, v in probe.items()}, avail)}
+    if (time.perf_counter() - t_all) < budget_s:
+        torch.set_num_threads(1)                                     # the reference's own setting (train.py:23)
         t0 = time.perf_counter()
         md2_step(models, opt, inputs, ms, SCALES, H, W, noise)
         out["one_thread_images_per_sec"] = round(batch / (time.perf_counter() - t0), 3)
@@ -109,6 +128,8 @@ def main():
     rank, local, world = bdist.init_from_env()
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path in the product)"
+    if os.environ.get("BBD_SHARE_GPU0"):       # test hook: all ranks on GPU 0 (with BBD_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -137,6 +158,7 @@ def main():
     backend = ops.default_backend()
 
     def sync_all():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()

@@ -117,6 +117,14 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* gra
                           int B, int h, int w, int H, int W,
                           double min_depth, double max_depth, void* stream);
 
+/* Pose matrix from the pose head's output: layers.transformation_from_parameters
+ * (layers.py:25-100: rot_from_axisangle, get_translation_matrix, T@R or R^T@T(-t)).
+ *   axisangle, translation [n,3] -> M [n,4,4];  bwd: grad_M [n,4,4] -> grads [n,3] each.      */
+int bbd_pose_matrix_fwd(const float* axisangle, const float* translation, float* M, int n, int invert,
+                        void* stream);
+int bbd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* grad_M,
+                        float* grad_axisangle, float* grad_translation, int n, int invert, void* stream);
+
 /* Edge-aware smoothness of the mean-normalised disparity: layers.get_smooth_loss
  * (layers.py:203-216) applied to disp / (mean_{H,W}(disp) + 1e-7) as in trainer.py:560-563.
  *   disp [B,h,w], img [B,3,h,w]

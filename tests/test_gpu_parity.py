@@ -282,3 +282,25 @@ def test_smoothness_kernel_against_oracle(backend):
         assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref))), (float(got), float(ref))
         err = float((dg.grad.cpu() - dc.grad).abs().max()) / float(dc.grad.abs().max())
         assert err < 1e-3, (s, err)
+
+
+def test_pose_matrix_kernel(backend):
+    """Fused transformation_from_parameters vs the op-for-op torch form (values and gradients)."""
+    from baseboostdepth_amd import layers as L
+    gen = torch.Generator().manual_seed(4)
+    for invert in (False, True):
+        aa = (0.3 * torch.randn(7, 1, 3, generator=gen))
+        tr = torch.randn(7, 1, 3, generator=gen)
+        w = torch.randn(7, 4, 4, generator=gen)
+        a1, t1 = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        ref = L._transformation_from_parameters_torch(a1, t1, invert)
+        (ref * w).sum().backward()
+        a2, t2 = aa.clone().to(DEV).requires_grad_(True), tr.clone().to(DEV).requires_grad_(True)
+        got = L.transformation_from_parameters(a2, t2, invert)
+        (got * w.to(DEV)).sum().backward()
+        assert torch.allclose(got.detach().cpu(), ref.detach(), atol=2e-6), float((got.cpu() - ref).abs().max())
+        assert torch.allclose(a2.grad.cpu(), a1.grad, atol=2e-5, rtol=1e-4), float((a2.grad.cpu() - a1.grad).abs().max())
+        assert torch.allclose(t2.grad.cpu(), t1.grad, atol=2e-5, rtol=1e-4)
+    eye = torch.matmul(L.transformation_from_parameters(a2.detach(), t2.detach(), False),
+                       L.transformation_from_parameters(a2.detach(), t2.detach(), True))     # KAT K4
+    assert torch.allclose(eye.cpu(), torch.eye(4).expand(7, 4, 4), atol=1e-5)
