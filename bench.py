@@ -190,8 +190,17 @@ def main():
                                  "alg_MB_per_launch": round(nbytes[name] / 1e6, 2),
                                  "achieved_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4)}
         dom = max(kernels, key=lambda k: kernels[k]["mean_ms"])
+        # HBM bytes per launch from rocprofv3 PMC passes of the same workload (committed under profiles/)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_md2.json")
+        if args.config == "md2" and args.batch == 12 and os.path.isfile(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom, {}).get("traffic_bytes")
+            for k in kernels:
+                if k in tj:
+                    kernels[k]["pmc_traffic_MB_per_launch"] = round(tj[k]["traffic_bytes"] / 1e6, 1)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
-                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": None}
+                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic}
         global_batch = args.batch * world
         line = {
             "metric": "training images/sec at 640x192, MD2 ResNet18",

@@ -304,3 +304,36 @@ def test_pose_matrix_kernel(backend):
     eye = torch.matmul(L.transformation_from_parameters(a2.detach(), t2.detach(), False),
                        L.transformation_from_parameters(a2.detach(), t2.detach(), True))     # KAT K4
     assert torch.allclose(eye.cpu(), torch.eye(4).expand(7, 4, 4), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["md2_b2_32x64", "tri_3105_32x64"])
+def test_no_ssim_option_on_gpu(name, backend):
+    """L1-only loss (--no_ssim): HIP vs the live oracle (tolerance protocol) incl. gradients."""
+    from oracle import hotpath_ref as O
+    from fused_runner import make_opt, bare_trainer
+    case, ref = Case(name, device=DEV), Case(name)
+    out = O.hot_path(ref.inputs, ref.disp, ref.poses, ref.ms, ref.scales, ref.trimin, ref.decomp, ref.noise,
+                     ref.H, ref.W, poses_error=ref.poses_error(), no_ssim=True)
+    out["loss"].backward()
+    opt = make_opt(case, materialize_warps=False, no_ssim=True)
+    tr = bare_trainer(opt, backend, DEV)
+    inputs = dict(case.inputs)
+    inputs["noise"] = case.noise
+    tr.valid_frames_trimin(inputs)
+    outputs = {("disp", s): case.disp[s] for s in case.scales}
+    perr = case.poses_error()
+    for f, T in case.poses.items():
+        outputs[("cam_T_cam", 0, f)] = T
+        outputs[("cam_T_cam_error", 0, f)] = perr[f]
+    outputs.update(tr.generate_images_pred(inputs, outputs))
+    losses = tr.compute_losses(inputs, outputs)
+    losses["loss"].backward()
+    for i, s in enumerate(case.scales):
+        got = outputs[("bbd", "to_optimise")][i].cpu()
+        assert float((got - out["min/%d" % s]).abs().max()) < 1e-4
+        mism = outputs[("bbd", "argmin")][i].cpu() != out["argmin/%d" % s]
+        assert int((mism & (out["margin/%d" % s] > 2e-4)).sum()) == 0
+        g, ge = case.disp[s].grad.cpu(), ref.disp[s].grad
+        rel = (g - ge).abs() / float(ge.abs().max())
+        assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum())
+    assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5

@@ -26,3 +26,33 @@ def test_fused_path_host_port(name, backend):
     report = compare_with_golden(case, tr, outputs, losses, exact=True)
     losses["loss"].backward()
     compare_grads(case, report)
+
+
+@pytest.mark.parametrize("name", ["md2_b2_32x64", "tri_2102_32x64"])
+def test_no_ssim_option_matches_oracle(name, backend):
+    """--no_ssim (L1-only photometric loss, trainer.py:481-482): product path vs oracle, forward + grads."""
+    from oracle import hotpath_ref as O
+    from fused_runner import make_opt, bare_trainer
+    case, ref = Case(name), Case(name)
+    out = O.hot_path(ref.inputs, ref.disp, ref.poses, ref.ms, ref.scales, ref.trimin, ref.decomp, ref.noise,
+                     ref.H, ref.W, poses_error=ref.poses_error(), no_ssim=True)
+    out["loss"].backward()
+    opt = make_opt(case, materialize_warps=False, no_ssim=True)
+    tr = bare_trainer(opt, backend, "cpu")
+    inputs = dict(case.inputs)
+    inputs["noise"] = case.noise
+    tr.valid_frames_trimin(inputs)
+    outputs = {("disp", s): case.disp[s] for s in case.scales}
+    perr = case.poses_error()
+    for f, T in case.poses.items():
+        outputs[("cam_T_cam", 0, f)] = T
+        outputs[("cam_T_cam_error", 0, f)] = perr[f]
+    outputs.update(tr.generate_images_pred(inputs, outputs))
+    losses = tr.compute_losses(inputs, outputs)
+    losses["loss"].backward()
+    for i, s in enumerate(case.scales):
+        assert torch.equal(outputs[("bbd", "to_optimise")][i], out["min/%d" % s])
+        assert torch.equal(outputs[("bbd", "argmin")][i], out["argmin/%d" % s])
+        g, ge = case.disp[s].grad, ref.disp[s].grad
+        assert float((g - ge).abs().max()) <= 2e-3 * float(ge.abs().max())
+    assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-6

@@ -18,3 +18,20 @@ for k, cs in vals.items():
     print("==", k)
     for c, v in sorted(cs.items()):
         print("   %-26s n=%3d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+
+# optional second argument: write the per-kernel HBM traffic (bytes per launch) as JSON for bench.py
+if len(sys.argv) > 2:
+    import json
+    names = {"warp_ssim_min_fwd": "bbd_warp_ssim_min_fwd", "warp_ssim_min_bwd": "bbd_warp_ssim_min_bwd",
+             "identity_loss": "bbd_identity_loss_fwd"}
+    out = {"_note": "rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE (tools/pmc_passes.sh); KB -> bytes "
+                    "x1024; FETCH_SIZE NOT doubled: these kernels issue 4/8-byte loads, and the dword-load "
+                    "disp_to_depth kernel calibrates FETCH_SIZE at 1.00x of its known bytes (the x2 correction of "
+                    "MI355X_MICROARCH.md applies to 16-byte-per-lane streams)",
+           "workload": "MD2 batch 12, 4 scales, 640x192 (tools/kernel_bench.py --config md2)"}
+    for k, cs in vals.items():
+        if k in names and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024
+            w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
+            out[names[k]] = {"fetch_bytes": round(f), "write_bytes": round(w), "traffic_bytes": round(f + w)}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
