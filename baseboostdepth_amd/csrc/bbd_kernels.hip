@@ -749,53 +749,58 @@ __global__ __launch_bounds__(NT) void disp_to_depth_fwd_kernel(const float* __re
   }
 }
 
+// Gather-form adjoint.  Q lanes (1, 4, 16 or 64 by up-sampling factor) share one low-resolution pixel:
+// each takes every Q-th of the candidate output pixels and the partial sums are combined with a
+// fixed xor-butterfly, so the result is deterministic and small scales still fill the chip.
+template <int Q>
 __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __restrict__ disp,
                                                                const float* __restrict__ gdepth,
                                                                float* __restrict__ gdisp, int B, int h, int w,
                                                                int H, int W, float lo, float span) {
   const size_t n = (size_t)B * h * w;
-  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
-    const int x = (int)(i % w);
-    const int y = (int)((i / w) % h);
-    const int b = (int)(i / ((size_t)w * h));
-    const float* d = disp + (size_t)b * h * w;
-    const float* g = gdepth + (size_t)b * H * W;
-    float acc = 0.0f;
-    if (h == H && w == W) {
-      const float sc = lo + span * d[(size_t)y * w + x];
-      acc = g[(size_t)y * W + x] * (-span / (sc * sc));
-    } else {
-      // output rows/cols whose source index lies in [y-1, y+1): (o+0.5)*h/H - 0.5 in that range,
-      // widened by one on each side (the exact membership test is repeated inside the loop)
-      const float sy_ = (float)H / (float)h, sx_ = (float)W / (float)w;
-      const int oy_lo = max(0, (int)floorf(((float)y - 0.5f) * sy_ - 0.5f) - 1);
-      const int oy_hi = min(H - 1, (int)ceilf(((float)y + 1.5f) * sy_ - 0.5f) + 1);
-      const int ox_lo = max(0, (int)floorf(((float)x - 0.5f) * sx_ - 0.5f) - 1);
-      const int ox_hi = min(W - 1, (int)ceilf(((float)x + 1.5f) * sx_ - 0.5f) + 1);
-      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-        int y0, y1;
-        float ly0, ly1;
-        bbd_up_src(oy, h, H, &y0, &y1, &ly0, &ly1);
-        const float wy = (y0 == y ? ly0 : 0.0f) + (y1 == y ? ly1 : 0.0f);
-        if (wy == 0.0f) continue;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-          int x0, x1;
-          float lx0, lx1;
-          bbd_up_src(ox, w, W, &x0, &x1, &lx0, &lx1);
-          const float wx = (x0 == x ? lx0 : 0.0f) + (x1 == x ? lx1 : 0.0f);
-          if (wx == 0.0f) continue;
-          // recompute the upsampled disparity at (oy, ox) for d depth / d disp_up
-          const float sc = lo + span * bbd_up_blend(d[(size_t)y0 * w + x0], d[(size_t)y0 * w + x1],
-                                                    d[(size_t)y1 * w + x0], d[(size_t)y1 * w + x1], ly0, ly1,
-                                                    lx0, lx1, (H + W) <= 128);
-          acc += g[(size_t)oy * W + ox] * (-span / (sc * sc)) * wy * wx;
-        }
-      }
+  const size_t gid = ((size_t)blockIdx.x * NT + threadIdx.x) / Q;
+  const int sub = threadIdx.x % Q;
+  const bool live = gid < n;
+  const size_t i = live ? gid : n - 1;
+  const int x = (int)(i % w);
+  const int y = (int)((i / w) % h);
+  const int b = (int)(i / ((size_t)w * h));
+  const float* d = disp + (size_t)b * h * w;
+  const float* g = gdepth + (size_t)b * H * W;
+  float acc = 0.0f;
+  if (h == H && w == W) {
+    const float sc = lo + span * d[(size_t)y * w + x];
+    acc = g[(size_t)y * W + x] * (-span / (sc * sc));
+  } else {
+    // output rows/cols whose source index lies in [y-1, y+1): (o+0.5)*h/H - 0.5 in that range,
+    // widened by one on each side (the exact membership test is repeated inside the loop)
+    const float sy_ = (float)H / (float)h, sx_ = (float)W / (float)w;
+    const int oy_lo = max(0, (int)floorf(((float)y - 0.5f) * sy_ - 0.5f) - 1);
+    const int oy_hi = min(H - 1, (int)ceilf(((float)y + 1.5f) * sy_ - 0.5f) + 1);
+    const int ox_lo = max(0, (int)floorf(((float)x - 0.5f) * sx_ - 0.5f) - 1);
+    const int ox_hi = min(W - 1, (int)ceilf(((float)x + 1.5f) * sx_ - 0.5f) + 1);
+    const int nx = ox_hi - ox_lo + 1, ncand = (oy_hi - oy_lo + 1) * nx;
+    const bool small = (H + W) <= 128;
+    for (int k = sub; k < ncand; k += Q) {
+      const int oy = oy_lo + k / nx, ox = ox_lo + k % nx;
+      int y0, y1, x0, x1;
+      float ly0, ly1, lx0, lx1;
+      bbd_up_src(oy, h, H, &y0, &y1, &ly0, &ly1);
+      bbd_up_src(ox, w, W, &x0, &x1, &lx0, &lx1);
+      const float wy = (y0 == y ? ly0 : 0.0f) + (y1 == y ? ly1 : 0.0f);
+      const float wx = (x0 == x ? lx0 : 0.0f) + (x1 == x ? lx1 : 0.0f);
+      if (wy == 0.0f || wx == 0.0f) continue;
+      // recompute the up-sampled disparity at (oy, ox) for d depth / d disp_up
+      const float sc = lo + span * bbd_up_blend(d[(size_t)y0 * w + x0], d[(size_t)y0 * w + x1],
+                                                d[(size_t)y1 * w + x0], d[(size_t)y1 * w + x1], ly0, ly1, lx0,
+                                                lx1, small);
+      acc += g[(size_t)oy * W + ox] * (-span / (sc * sc)) * wy * wx;
     }
-    gdisp[i] = acc;
   }
+#pragma unroll
+  for (int off = Q / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (live && sub == 0) gdisp[i] = acc;
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Stand-alone layer kernels (layers.BackprojectDepth / Project3D / SSIM API surface).
@@ -1021,14 +1026,24 @@ __device__ __forceinline__ float block_sum_all(float v, float* s_red4) {   // ev
   return t;
 }
 
-__global__ __launch_bounds__(NT) void smooth_mean_kernel(const float* __restrict__ disp, float* __restrict__ mean,
+// per-(sample, chunk) partial sums of disp; the mean is finished by sample_mean() in the consumers
+__global__ __launch_bounds__(NT) void smooth_mean_kernel(const float* __restrict__ disp, float* __restrict__ psum,
                                                          int hw) {
   __shared__ float s_red4[4];
-  const float* d = disp + (size_t)blockIdx.x * hw;
+  const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
+  const float* d = disp + (size_t)b * hw;
+  const int per = (hw + SM_CHUNKS - 1) / SM_CHUNKS;
+  const int i0 = chunk * per, i1 = min(hw, i0 + per);
   float acc = 0.0f;
-  for (int i = threadIdx.x; i < hw; i += NT) acc += d[i];
+  for (int i = i0 + threadIdx.x; i < i1; i += NT) acc += d[i];
   const float tot = block_sum_all(acc, s_red4);
-  if (threadIdx.x == 0) mean[blockIdx.x] = tot / (float)hw;
+  if (threadIdx.x == 0) psum[blockIdx.x] = tot;
+}
+
+__device__ __forceinline__ float sample_mean(const float* __restrict__ psum, int b, int hw) {
+  float t = 0.0f;
+  for (int k = 0; k < SM_CHUNKS; ++k) t += psum[b * SM_CHUNKS + k];
+  return t / (float)hw;
 }
 
 __device__ __forceinline__ float edge_weight(const float* img, int hw, int i0, int i1) {
@@ -1045,7 +1060,7 @@ __global__ __launch_bounds__(NT) void smooth_fwd_kernel(const float* __restrict_
   const int hw = h * w;
   const float* d = disp + (size_t)b * hw;
   const float* im = img + (size_t)b * 3 * hw;
-  const float inv = 1.0f / (mean[b] + 1e-7f);
+  const float inv = 1.0f / (sample_mean(mean, b, hw) + 1e-7f);
   const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
   const int y0 = chunk * rows, y1 = min(h, y0 + rows);
   float ax = 0.0f, ay = 0.0f;
@@ -1076,7 +1091,7 @@ __global__ __launch_bounds__(NT) void smooth_bwd1_kernel(const float* __restrict
   const float* d = disp + (size_t)b * hw;
   const float* im = img + (size_t)b * 3 * hw;
   float* gout = grad + (size_t)b * hw;
-  const float inv = 1.0f / (mean[b] + 1e-7f);
+  const float inv = 1.0f / (sample_mean(mean, b, hw) + 1e-7f);
   const float g = gscale[0];
   const float gxs = g / ((float)B * (float)h * (float)(w - 1));
   const float gys = g / ((float)B * (float)(h - 1) * (float)w);
@@ -1105,7 +1120,7 @@ __global__ __launch_bounds__(NT) void smooth_bwd2_kernel(const float* __restrict
   const int hw = h * w;
   float dot = 0.0f;
   for (int k = 0; k < SM_CHUNKS; ++k) dot += dots[b * SM_CHUNKS + k];
-  const float inv = 1.0f / (mean[b] + 1e-7f);
+  const float inv = 1.0f / (sample_mean(mean, b, hw) + 1e-7f);
   const float sub = dot * inv * inv / (float)hw;
   float* gout = grad + (size_t)b * hw;
   const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
@@ -1256,9 +1271,16 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* gra
   if (!disp || !grad_depth || !grad_disp || B <= 0 || h <= 0 || w <= 0 || H < h || W < w) return BBD_E_BADARG;
   const float lo = (float)(1.0 / max_depth), span = (float)(1.0 / min_depth - 1.0 / max_depth);
   const size_t n = (size_t)B * h * w;
-  const unsigned grid = (unsigned)((n + NT - 1) / NT < 4096 ? (n + NT - 1) / NT : 4096);
-  hipLaunchKernelGGL(disp_to_depth_bwd_kernel, dim3(grid), dim3(NT), 0, static_cast<hipStream_t>(stream), disp,
-                     grad_depth, grad_disp, B, h, w, H, W, lo, span);
+  const int f = (H + h - 1) / h;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define BBD_D2D_BWD(Q)                                                                                         \
+  hipLaunchKernelGGL(disp_to_depth_bwd_kernel<Q>, dim3((unsigned)((n * Q + NT - 1) / NT)), dim3(NT), 0, st, disp, \
+                     grad_depth, grad_disp, B, h, w, H, W, lo, span)
+  if (f <= 1) BBD_D2D_BWD(1);
+  else if (f <= 2) BBD_D2D_BWD(4);
+  else if (f <= 4) BBD_D2D_BWD(16);
+  else BBD_D2D_BWD(64);
+#undef BBD_D2D_BWD
   return launch_status();
 }
 
@@ -1286,7 +1308,7 @@ int bbd_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, f
                         void* stream) {
   if (!disp || !img || !mean_disp || !sums || B <= 0 || h < 2 || w < 2) return BBD_E_BADARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(smooth_mean_kernel, dim3((unsigned)B), dim3(NT), 0, st, disp, mean_disp, h * w);
+  hipLaunchKernelGGL(smooth_mean_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, mean_disp, h * w);
   hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, img, mean_disp, sums,
                      h, w);
   return launch_status();

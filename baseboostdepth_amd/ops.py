@@ -199,7 +199,7 @@ class _SmoothLoss(torch.autograd.Function):
         disp, img = disp.contiguous(), img.contiguous()
         backend._check(disp, img)
         chunks = backend.smooth_chunks()
-        mean = torch.empty(B, device=disp.device, dtype=torch.float32)
+        mean = torch.empty(B, chunks, device=disp.device, dtype=torch.float32)   # partial sums of disp
         sums = torch.empty(B, chunks, 2, device=disp.device, dtype=torch.float32)
         backend.run("bbd_smooth_loss_fwd", disp, ptr(disp), ptr(img), ptr(mean), ptr(sums), B, h, w)
         ctx.save_for_backward(disp, img, mean)

@@ -128,7 +128,8 @@ int bbd_pose_matrix_bwd(const float* axisangle, const float* translation, const 
 /* Edge-aware smoothness of the mean-normalised disparity: layers.get_smooth_loss
  * (layers.py:203-216) applied to disp / (mean_{H,W}(disp) + 1e-7) as in trainer.py:560-563.
  *   disp [B,h,w], img [B,3,h,w]
- *   fwd : mean_disp out [B]; sums out [B, bbd_smooth_chunks(), 2] partial sums of the x- and
+ *   fwd : mean_disp out [B, bbd_smooth_chunks()] partial sums of disp (mean = sum / (h*w));
+ *         sums out [B, bbd_smooth_chunks(), 2] partial sums of the x- and
  *         y-terms; smooth = sum(x-terms)/(B*h*(w-1)) + sum(y-terms)/(B*(h-1)*w)
  *   bwd : gscale [1] device scalar dL/d(smooth); dots scratch [B, bbd_smooth_chunks()];
  *         grad_disp out [B,h,w] (overwritten).  Deterministic (fixed reduction order).        */

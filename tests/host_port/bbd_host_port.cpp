@@ -254,8 +254,8 @@ int hp_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, fl
     const float* im = img + (size_t)b * 3 * hw;
     double m = 0;
     for (int i = 0; i < hw; ++i) m += d[i];
-    mean_disp[b] = (float)(m / hw);
-    const float inv = 1.0f / (mean_disp[b] + 1e-7f);
+    mean_disp[b] = (float)m;                       // partial-sum layout of the ABI (one chunk)
+    const float inv = 1.0f / (mean_disp[b] / (float)hw + 1e-7f);
     double ax = 0, ay = 0;
     for (int y = 0; y < h; ++y)
       for (int x = 0; x < w; ++x) {
@@ -277,7 +277,7 @@ int hp_smooth_loss_bwd(const float* disp, const float* img, const float* mean_di
     const float* d = disp + (size_t)b * hw;
     const float* im = img + (size_t)b * 3 * hw;
     float* go = grad + (size_t)b * hw;
-    const float inv = 1.0f / (mean_disp[b] + 1e-7f);
+    const float inv = 1.0f / (mean_disp[b] / (float)hw + 1e-7f);
     double dot = 0;
     for (int y = 0; y < h; ++y)
       for (int x = 0; x < w; ++x) {
