@@ -28,10 +28,11 @@ class FlatGradients:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.views, off = [], 0
+        self.views, self.offsets, off = [], [], 0
         for p in self.params:
             n = p.numel()
             self.views.append(self.flat[off:off + n].view_as(p))
+            self.offsets.append(off)
             off += n
 
     def zero(self):
@@ -57,22 +58,104 @@ class FlatGradients:
 
 
 class GradientAverager:
-    """Callable placed between backward() and optimizer.step() (Trainer.grad_sync)."""
+    """Callable placed between backward() and optimizer.step() (Trainer.grad_sync): pack + one all-reduce."""
 
     def __init__(self, flat, group=None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
 
+    def _reduce(self, tensor, async_op=False):
+        if self.backend == "nccl":          # RCCL: average in the collective
+            return dist.all_reduce(tensor, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
     def __call__(self):
         self.flat.pack()
         if self.world == 1:
             return
-        if self.backend == "nccl":          # RCCL: average in the collective
-            dist.all_reduce(self.flat.flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:                               # gloo (CPU tests) has no AVG
-            dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._reduce(self.flat.flat)
+        if self.backend != "nccl":          # gloo (CPU tests) has no AVG
             self.flat.flat.div_(self.world)
+
+
+class OverlappedGradientAverager(GradientAverager):
+    """Same result, but the exchange overlaps the backward pass.
+
+    The flat buffer is cut into buckets in REVERSE parameter order (the order gradients become
+    ready).  A post-accumulate hook per parameter counts its bucket down; a complete bucket is packed
+    (one multi-tensor copy) and its all-reduce is issued asynchronously - strictly in bucket order,
+    so every rank issues the same collective sequence even when their autograd graphs differ (boosted
+    batches have rank-specific pose-net call patterns).  `__call__` flushes what is left (parameters
+    that never get a gradient, e.g. the ResNet `fc` layers, contribute zeros) and waits.
+    xGMI is point-to-point, so a ring all-reduce is per-link bound: buckets are sized (32 MB) to be
+    well past the latency regime while leaving 3-4 of them to pipeline against the conv backward."""
+
+    def __init__(self, flat, group=None, bucket_bytes=32 << 20):
+        super().__init__(flat, group)
+        order = list(range(len(flat.params)))[::-1]
+        self.buckets, cur, cur_bytes = [], [], 0
+        for idx in order:
+            cur.append(idx)
+            cur_bytes += flat.params[idx].numel() * 4
+            if cur_bytes >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {}
+        self.slices = []
+        for b, idxs in enumerate(self.buckets):
+            lo = min(flat.offsets[i] for i in idxs)
+            hi = max(flat.offsets[i] + flat.params[i].numel() for i in idxs)
+            self.slices.append(flat.flat[lo:hi])          # reverse order keeps each bucket contiguous
+            for i in idxs:
+                self.bucket_of[i] = b
+        self._reset()
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _reset(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.launched = 0
+        self.works = []
+
+    def _make_hook(self, i):
+        def hook(param):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            self._launch_ready()
+        return hook
+
+    def _pack_bucket(self, b):
+        flat = self.flat
+        have_v, have_g = [], []
+        for i in self.buckets[b]:
+            p, v = flat.params[i], flat.views[i]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                have_v.append(v)
+                have_g.append(p.grad)
+        if have_v:
+            torch._foreach_copy_(have_v, have_g)
+        for i in self.buckets[b]:
+            flat.params[i].grad = flat.views[i]
+
+    def _launch_ready(self, force=False):
+        while self.launched < len(self.buckets) and (force or self.pending[self.launched] == 0):
+            b = self.launched
+            self._pack_bucket(b)
+            self.works.append(self._reduce(self.slices[b], async_op=True))
+            self.launched += 1
+
+    def __call__(self):
+        self._launch_ready(force=True)
+        for w in self.works:
+            w.wait()
+        if self.backend != "nccl":
+            self.flat.flat.div_(self.world)
+        self._reset()
 
 
 def init_from_env(backend=None):
@@ -110,5 +193,8 @@ def attach(trainer, group=None):
             for b in m.buffers():
                 if b.is_floating_point():
                     dist.broadcast(b.data, src=0, group=group)
-        trainer.grad_sync = GradientAverager(flat, group)
+        overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1"
+        bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
+        trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket) if overlap
+                             else GradientAverager(flat, group))
     return flat

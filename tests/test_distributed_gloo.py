@@ -42,7 +42,9 @@ class _Holder:
     pass
 
 
-def _worker_flat(rank, world, port, q):
+def _worker_flat(rank, world, port, q, overlap=True):
+    os.environ["BBD_NO_OVERLAP"] = "0" if overlap else "1"
+    os.environ["BBD_BUCKET_BYTES"] = "16"          # several buckets even for this tiny model
     bdist = _setup(rank, world, port)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
@@ -55,6 +57,9 @@ def _worker_flat(rank, world, port, q):
     tr.grad_sync = None
     flat = bdist.attach(tr)
     assert tr.grad_sync is not None
+    assert type(tr.grad_sync).__name__ == ("OverlappedGradientAverager" if overlap else "GradientAverager")
+    if overlap:
+        assert len(tr.grad_sync.buckets) >= 2
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 6, generator=g)
     y = torch.randn(8, 1, generator=g)
@@ -71,7 +76,51 @@ def _worker_flat(rank, world, port, q):
     ref.load_state_dict(net.state_dict())
     ((ref(x) - y) ** 2).mean().backward()
     want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
-    q.put((rank, float((got - want).abs().max())))
+    err = float((got - want).abs().max())
+    # second step through the same hooks (state must reset cleanly)
+    flat.zero()
+    ((net(xs) - ys) ** 2).mean().backward()
+    tr.grad_sync()
+    err = max(err, float((flat.flat - want).abs().max()))
+    q.put((rank, err))
+    dist.destroy_process_group()
+
+
+def _worker_flat_simple(rank, world, port, q):
+    _worker_flat(rank, world, port, q, overlap=False)
+
+
+def _worker_uneven_graphs(rank, world, port, q):
+    """Ranks whose autograd graphs differ (rank 1 never touches the last layer) must still issue the
+    same collective sequence: buckets launch strictly in order, leftovers are flushed with zeros."""
+    os.environ["BBD_NO_OVERLAP"] = "0"
+    os.environ["BBD_BUCKET_BYTES"] = "16"
+    bdist = _setup(rank, world, port)
+    torch.manual_seed(0)
+    l1, l2 = torch.nn.Linear(6, 5), torch.nn.Linear(5, 1)
+    tr = _Holder()
+    tr.parameters_to_train = list(l1.parameters()) + list(l2.parameters())
+    tr.models = {"l1": l1, "l2": l2}
+    tr.grad_sync = None
+    flat = bdist.attach(tr)
+    x = torch.ones(4, 6) * (rank + 1)
+    flat.zero()
+    h = torch.tanh(l1(x))
+    loss = (l2(h) ** 2).mean() if rank == 0 else (h ** 2).mean()
+    loss.backward()
+    tr.grad_sync()
+    # reference: average of the two ranks' gradients computed locally
+    grads = []
+    for r in range(world):
+        a1, a2 = torch.nn.Linear(6, 5), torch.nn.Linear(5, 1)
+        a1.load_state_dict(l1.state_dict()); a2.load_state_dict(l2.state_dict())
+        xr = torch.ones(4, 6) * (r + 1)
+        hr = torch.tanh(a1(xr))
+        ((a2(hr) ** 2).mean() if r == 0 else (hr ** 2).mean()).backward()
+        grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                for p in list(a1.parameters()) + list(a2.parameters())]))
+    want = sum(grads) / world
+    q.put((rank, float((flat.flat - want).abs().max())))
     dist.destroy_process_group()
 
 
@@ -114,7 +163,18 @@ def _run(worker, world=2):
     procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=180) for _ in range(world)]
+    import queue
+    out, waited = [], 0
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            waited += 2
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or waited > 180:
+                for p in procs:
+                    p.kill()
+                raise AssertionError("worker failed (exit codes %s)" % dead)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -122,7 +182,17 @@ def _run(worker, world=2):
 
 
 def test_flat_gradient_average_world2():
+    for rank, err in _run(_worker_flat_simple):
+        assert err < 1e-6, (rank, err)
+
+
+def test_overlapped_bucketed_average_world2():
     for rank, err in _run(_worker_flat):
+        assert err < 1e-6, (rank, err)
+
+
+def test_overlapped_average_with_rank_specific_graphs():
+    for rank, err in _run(_worker_uneven_graphs):
         assert err < 1e-6, (rank, err)
 
 
