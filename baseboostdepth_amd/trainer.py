@@ -116,6 +116,31 @@ class Trainer:
             losses = None
         return outputs, losses
 
+    # ------------------------------------------------------------------ collate (trainer.py:867-886)
+    def custom_collate(self, batch):
+        """Per-item dicts from the loader (mono_dataset.py:76-146) -> the batch dict `process_batch` takes.
+        Tensors of a key are stacked over the items that HAVE that key, so `("color", f, 0)` has one
+        row per sample whose own frame set reaches |f| (variable n_f)."""
+        out = {}
+        max_frames = [int(torch.max(item["frames"]).item()) for item in batch]
+        out["ordering"] = [[0, STEREO] if m == 0 else [0, m, -m] for m in max_frames]
+        top = max(max_frames)
+        if top == 0:
+            frame_ids = [0, STEREO]
+        else:
+            frame_ids = list(range(-top, top + 1))
+            if any(m in (0, 1, 2) for m in max_frames):
+                frame_ids.append(STEREO)
+        keys = [("color_aug", f, 0) for f in frame_ids if f != STEREO]
+        keys += [("color", f, s) if f == 0 else ("color", f, 0) for f in frame_ids for s in self.opt.scales]
+        keys += [("K", 0), ("inv_K", 0), "stereo_T"]
+        for key in keys:
+            out[key] = torch.stack([item[key] for item in batch if key in item], dim=0)
+        out["frames"] = frame_ids
+        out["cutt"] = batch[0]["cutt_off"]
+        out["to_use"] = batch[0]["to_use"]
+        return out
+
     # ------------------------------------------------------------------ index table (a11)
     def valid_frames_trimin(self, inputs):
         """Builds the candidate/index table for this batch's `ordering` (replaces the mask dicts of

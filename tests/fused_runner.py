@@ -128,3 +128,25 @@ def compare_grads(case, report=None, grad_rtol=2e-3):
         err = float((g - ge).abs().max()) / scale
         tol = grad_rtol if total_flips == 0 else 10 * grad_rtol
         assert err < tol, "grad T[%s]: rel-to-max err %.3e" % (f, err)
+
+
+def extreme_case(name="tri_2102_32x64", device="cpu"):
+    """A golden case with its poses/disparities replaced by edge-of-domain values: large rotations and
+    translations (most samples land outside the source -> border clamp, zero coordinate gradient),
+    points behind the camera (z <= 0), disparity at both ends of [0,1] (depth 100 and 0.1)."""
+    from golden_io import Case
+    case = Case(name, device=device)
+    gen = torch.Generator().manual_seed(123)
+    from baseboostdepth_amd.layers import _transformation_from_parameters_torch as tfp
+    for f, T in list(case.poses.items()):
+        n = T.shape[0]
+        aa = 0.6 * torch.randn(n, 1, 3, generator=gen)
+        tt = 1.5 * torch.randn(n, 1, 3, generator=gen)
+        tt[0, 0, 2] = -3.0 if f > 0 else 3.0           # drives z through zero for near points
+        case.poses[f] = tfp(aa, tt, invert=(f < 0)).to(device).requires_grad_(True)
+    for s in case.scales:
+        d = case.disp[s].detach().clone()
+        d[:, :, : d.shape[2] // 2, : d.shape[3] // 2] = 0.0      # depth = max_depth
+        d[:, :, d.shape[2] // 2:, d.shape[3] // 2:] = 1.0        # depth = min_depth
+        case.disp[s] = d.requires_grad_(True)
+    return case

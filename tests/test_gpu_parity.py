@@ -337,3 +337,26 @@ def test_no_ssim_option_on_gpu(name, backend):
         rel = (g - ge).abs() / float(ge.abs().max())
         assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum())
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
+
+
+def test_edge_of_domain_poses_and_depths_on_gpu(backend):
+    """Border clamps, z <= 0, extreme depths on the GPU vs the live oracle (tolerance protocol)."""
+    from oracle import hotpath_ref as O
+    from fused_runner import extreme_case
+    case, ref = extreme_case(device=DEV), extreme_case()
+    out = O.hot_path(ref.inputs, ref.disp, ref.poses, ref.ms, ref.scales, ref.trimin, ref.decomp, ref.noise,
+                     ref.H, ref.W, poses_error=ref.poses_error())
+    out["loss"].backward()
+    tr, inputs, outputs, losses = run_direct_case(case, backend, device=DEV, materialize=False)
+    losses["loss"].backward()
+    flips = 0
+    for i, s in enumerate(case.scales):
+        got, want = outputs[("bbd", "to_optimise")][i].cpu(), out["min/%d" % s]
+        assert float((got - want).abs().max()) < 1e-4
+        mism = outputs[("bbd", "argmin")][i].cpu() != out["argmin/%d" % s]
+        assert int((mism & (out["margin/%d" % s] > 2e-4)).sum()) == 0
+        flips += int(mism.sum())
+        g, ge = case.disp[s].grad.cpu(), ref.disp[s].grad
+        rel = (g - ge).abs() / (float(ge.abs().max()) + 1e-12)
+        assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum()) + 4      # +4: clamp decisions at |ix - border| ~ ulp
+    assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5

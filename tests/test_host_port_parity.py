@@ -56,3 +56,28 @@ def test_no_ssim_option_matches_oracle(name, backend):
         g, ge = case.disp[s].grad, ref.disp[s].grad
         assert float((g - ge).abs().max()) <= 2e-3 * float(ge.abs().max())
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-6
+
+
+def test_edge_of_domain_poses_and_depths(backend):
+    """Border clamps, z <= 0, extreme depths: still bit-identical to the reference op sequence here."""
+    from oracle import hotpath_ref as O
+    from fused_runner import extreme_case, run_direct_case
+    case, ref = extreme_case(), extreme_case()
+    out = O.hot_path(ref.inputs, ref.disp, ref.poses, ref.ms, ref.scales, ref.trimin, ref.decomp, ref.noise,
+                     ref.H, ref.W, poses_error=ref.poses_error())
+    out["loss"].backward()
+    tr, inputs, outputs, losses = run_direct_case(case, backend, materialize=False)
+    losses["loss"].backward()
+    for i, s in enumerate(case.scales):
+        got, want = outputs[("bbd", "to_optimise")][i], out["min/%d" % s]
+        nan = torch.isnan(want)
+        assert torch.equal(torch.isnan(got), nan)
+        assert torch.equal(got[~nan], want[~nan]), float((got[~nan] - want[~nan]).abs().max())
+        assert torch.equal(outputs[("bbd", "argmin")][i], out["argmin/%d" % s])
+        g, ge = case.disp[s].grad, ref.disp[s].grad
+        assert float((g - ge).abs().max()) <= 2e-3 * float(ge.abs().max()) + 1e-12
+    for f, T in case.poses.items():
+        ge = ref.poses[f].grad
+        if ge is None:
+            continue
+        assert float((T.grad - ge).abs().max()) <= 5e-3 * float(ge.abs().max()) + 1e-12, f

@@ -116,3 +116,27 @@ def test_transformation_from_parameters_matches_golden():
     assert torch.equal(tfp(aa, t, invert=True), torch.from_numpy(z["tfp/Minv"]))
     sd, dp = disp_to_depth(torch.from_numpy(z["d2d/disp"]), 0.1, 100.0)
     assert torch.equal(dp, torch.from_numpy(z["d2d/depth"]))
+
+
+def test_custom_collate_matches_reference():
+    """Same keys, shapes and values as the reference's Trainer.custom_collate on ragged items."""
+    import refshim
+    if not refshim.reference_available():
+        pytest.skip("reference tree not present on this machine")
+    import types
+    from make_golden import make_item, make_ref_trainer, make_opt as ref_opt
+    from baseboostdepth_amd.trainer import Trainer
+    rt, rl, rn = refshim.import_reference()
+    for ms in ([3, 1, 0, 5], [0, 0], [7, 2], [1, 1, 1]):
+        gen = torch.Generator().manual_seed(1)
+        items = [make_item(gen, m, 32, 64, [0, 1, 2, 3], max(max(ms), 1), 0.3) for m in ms]
+        ref = make_ref_trainer(rt, rl, ref_opt(32, 64, len(ms), [0, 1, 2, 3], True, True)).custom_collate(items)
+        mine = Trainer.__new__(Trainer)
+        mine.opt = types.SimpleNamespace(scales=[0, 1, 2, 3])
+        got = mine.custom_collate(items)
+        assert set(got.keys()) == set(ref.keys())
+        for k in ref:
+            if torch.is_tensor(ref[k]):
+                assert torch.equal(got[k], ref[k]), k
+            else:
+                assert got[k] == ref[k], k
