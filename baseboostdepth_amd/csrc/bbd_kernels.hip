@@ -336,7 +336,20 @@ __global__ __launch_bounds__(NT) void identity_loss_kernel(FramePtrs frames, con
 // ------------------------------------------------------------------------------------------
 // Fused forward: warp + SSIM/L1 + min/arg-min over the candidate list.
 // ------------------------------------------------------------------------------------------
+// Diagnostic build only (-DBBD_STAMPS): wave 0 of every workgroup records s_memtime at phase
+// boundaries into a buffer registered with bbd_debug_set_stamps(); never part of the shipped library.
+#ifdef BBD_STAMPS
+static unsigned long long* g_stamps_host_ptr = nullptr;
+#define BBD_STAMP(k)                                                                         \
+  do {                                                                                       \
+    if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); \
+  } while (0)
+#else
+#define BBD_STAMP(k) do { } while (0)
+#endif
+
 struct FwdArgs {
+  unsigned long long* stamps;
   FramePtrs frames;
   const float* target;
   const float* depth;
@@ -379,12 +392,15 @@ __global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdA
   const size_t img = (size_t)3 * hw;
   const size_t sb = (size_t)s * a.B + b;
 
+  BBD_STAMP(0);
   Cells<LH, LW, LS, 1> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
   stage_image(a.target + (size_t)b * img, hw, cl, s_y);
   float dcell[Cells<LH, LW, LS, 1>::N];
   load_depth(a.depth + sb * hw, cl, dcell);
+  BBD_STAMP(1);
   __syncthreads();
+  BBD_STAMP(2);
   int ly, lx0;
   strip_of_thread(&ly, &lx0);
   const int yy = tc.ty0 + ly, xx = tc.tx0 + lx0;
@@ -402,6 +418,7 @@ __global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdA
   int arg[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) { best[j] = INFINITY; arg[j] = 0; }
+  BBD_STAMP(3);
 
   const int nc = a.ncand[b];
   for (int c = 0; c < nc; ++c) {
@@ -410,9 +427,13 @@ __global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdA
     if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
       float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
+      BBD_STAMP(4 + 4 * (c & 3));
       warp_into_lds(src, dcell, a.pose + (size_t)cd.pose * BBD_POSE_STRIDE, dm, hw, cl, s_xx[buf], wout);
+      BBD_STAMP(5 + 4 * (c & 3));
       __syncthreads();
+      BBD_STAMP(6 + 4 * (c & 3));
       strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+      BBD_STAMP(7 + 4 * (c & 3));
       buf ^= 1;
     } else {
 #pragma unroll
@@ -449,12 +470,14 @@ __global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdA
   if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
   __syncthreads();
   if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+  BBD_STAMP(20);
 }
 
 // ------------------------------------------------------------------------------------------
 // Fused backward.
 // ------------------------------------------------------------------------------------------
 struct BwdArgs {
+  unsigned long long* stamps;
   FramePtrs frames;
   const float* target;
   const float* depth;
@@ -502,6 +525,7 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
   const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
   const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
 
+  BBD_STAMP(0);
   if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
   // the coefficient planes are sparse (only loss pixels won by the current candidate are non-zero):
   // cleared once here, and each candidate's entries are cleared again by the thread that owns them
@@ -555,7 +579,9 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
     }
   }
   float gdepth[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
+  BBD_STAMP(1);
   __syncthreads();
+  BBD_STAMP(2);
   const unsigned present = s_present;
 
   const int nc = a.ncand[b];
@@ -585,8 +611,11 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
       }
     }
     prev = c;
+    BBD_STAMP(4 + 8 * (c & 1));
     warp_into_lds(src, dcell, pose_row, dm, hw, cl, s_x, nullptr);
+    BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
+    BBD_STAMP(6 + 8 * (c & 1));
 
     // ---- phase C: SSIM partials A,B,C (d loss / d{mu_x, E[x^2], E[xy]}) of the loss pixels won by c
 #if defined(BBD_ABLATE_BWD_COEF)
@@ -615,7 +644,9 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
         s_cf[ch * 3 + 2][cell] = Cc * w_ssim;
       }
     }
+    BBD_STAMP(7 + 8 * (c & 1));
     __syncthreads();
+    BBD_STAMP(8 + 8 * (c & 1));
     if (threadIdx.x == 0) s_count = 0;   // everyone has read it; next written after the barrier below
 
     // ---- phase G: adjoint of reflect-pad + 3x3 mean at this thread's 4 texels
@@ -668,6 +699,7 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
       }
     }
 
+    BBD_STAMP(9 + 8 * (c & 1));
     // texel gradient -> sampling coordinates -> depth and P
     float gP[12];
 #pragma unroll
@@ -712,7 +744,9 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
         if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6][k] = ws;
       }
     }
+    BBD_STAMP(10 + 8 * (c & 1));
     __syncthreads();   // s_red complete; every thread is done with s_x / s_cf of this candidate
+    BBD_STAMP(11 + 8 * (c & 1));
     if (!(cd.kind & FLAG_NO_POSE_GRAD) && threadIdx.x < 12)
       gp_out[threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) +
                             s_red[3][threadIdx.x];
@@ -720,6 +754,7 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
 
   if (q_row_ok)
     store_strip(a.grad_depth + sb * hw + qy * W + qx0, qx0, W, (qx0 + PPT <= W) && ((W & 3) == 0), gdepth);
+  BBD_STAMP(20);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1227,6 +1262,11 @@ int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const 
   if (!target || !depth || !cand || !ncand || !min_loss || !argmin || !partial) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   FwdArgs a;
+#ifdef BBD_STAMPS
+  a.stamps = g_stamps_host_ptr;
+#else
+  a.stamps = nullptr;
+#endif
   if (fill_frames(frames, &a.frames)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.ident = ident; a.noise = noise;
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
@@ -1244,6 +1284,11 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
   if (!target || !depth || !cand || !ncand || !argmin || !gscale || !grad_depth || !grad_proj) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   BwdArgs a;
+#ifdef BBD_STAMPS
+  a.stamps = g_stamps_host_ptr;
+#else
+  a.stamps = nullptr;
+#endif
   if (fill_frames(frames, &a.frames)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.cand = cand; a.ncand = ncand; a.argmin = argmin;
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
@@ -1324,6 +1369,10 @@ int bbd_smooth_loss_bwd(const float* disp, const float* img, const float* mean_d
                      h, w);
   return launch_status();
 }
+
+#ifdef BBD_STAMPS
+int bbd_debug_set_stamps(void* buf) { g_stamps_host_ptr = static_cast<unsigned long long*>(buf); return 0; }
+#endif
 
 int bbd_selftest_div(int blocks, int iters, unsigned seed, int32_t* mismatches, void* stream) {
   if (!mismatches || blocks <= 0 || iters <= 0) return BBD_E_BADARG;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Phase timeline of the fused forward kernel from in-kernel s_memtime stamps (diagnostic build
+-DBBD_STAMPS, loaded through BBD_HIP_LIB).  Prints mean cycles per phase for wave 0 of each workgroup."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = "/tmp/bbdvar/libbbd_stamps.so"
+os.makedirs("/tmp/bbdvar", exist_ok=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17",
+                "-fPIC", "-shared", "-DBBD_STAMPS", "-o", out, os.path.join(ROOT, "baseboostdepth_amd/csrc/bbd_kernels.hip")], check=True)
+os.environ["BBD_HIP_LIB"] = out
+import types, torch
+from baseboostdepth_amd import ops, _lib
+from baseboostdepth_amd.synthetic import synthetic_batch, synthetic_disp, synthetic_poses
+from baseboostdepth_amd.trainer import Trainer
+dev, H, W, B, scales = "cuda:0", 192, 640, 12, [0, 1, 2, 3]
+inputs = synthetic_batch([1] * B, H, W, scales, device=dev, seed=42)
+opt = types.SimpleNamespace(height=H, width=W, batch_size=B, scales=scales, frame_ids=[0], min_depth=0.1, max_depth=100.0,
+                            disparity_smoothness=1e-3, no_ssim=False, trimin=False, decomp=False, pose_error=5.5,
+                            incremental_skip=False, partial_skip=False, materialize_warps=False)
+tr = Trainer.__new__(Trainer)
+tr.opt, tr.device, tr.num_scales, tr.backend, tr.maxing_valid_frames = opt, torch.device(dev), 4, None, False
+be = tr._backend()
+plan = tr.valid_frames_trimin(inputs)
+disp = synthetic_disp(B, H, W, scales, device=dev, seed=1)
+outputs = {("disp", s): disp[s] for s in scales}
+outputs.update(synthetic_poses(plan, device=dev, seed=2))
+nblocks = 4 * B * be.num_tiles(H, W)
+stamps = torch.zeros(nblocks * 32, dtype=torch.int64, device=dev)
+dll = be.lib._dll
+dll.bbd_debug_set_stamps.argtypes = [ctypes.c_void_p]
+for _ in range(3):
+    tr.generate_images_pred(inputs, dict(outputs))
+dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+tr.generate_images_pred(inputs, dict(outputs))
+torch.cuda.synchronize()
+st = stamps.view(nblocks, 32).cpu().double()
+names = {(0, 1): "cells+stage target+depth issue", (1, 2): "wait loads + barrier", (2, 3): "ystats",
+         (4, 5): "cand0 project+gather+blend", (5, 6): "cand0 barrier wait", (6, 7): "cand0 SSIM",
+         (8, 9): "cand1 project+gather+blend", (9, 10): "cand1 barrier wait", (10, 11): "cand1 SSIM",
+         (11, 20): "identity cands + stores + reduce", (0, 20): "TOTAL workgroup"}
+print("== forward")
+for (a, b), n in names.items():
+    d = st[:, b] - st[:, a]
+    print("%-36s mean %8.0f  median %8.0f  p90 %8.0f ticks" % (n, d.mean(), d.median(), d.quantile(0.9)))
+
+# ---- backward (MD2: candidates 0 and 1 are the two warps)
+stamps.zero_()
+o = tr.generate_images_pred(inputs, {k: (v.clone().requires_grad_(True) if k[0] == "disp" else v) for k, v in outputs.items()})
+dll.bbd_debug_set_stamps(ctypes.c_void_p(0))
+ls = o[("bbd", "loss_sum")]
+dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+ls.sum().backward()
+torch.cuda.synchronize()
+st = stamps.view(nblocks, 32).cpu().double()
+bn = {(0, 1): "setup: clear planes, arg ids, cells, stage", (1, 2): "barrier", (4, 5): "cand0 W: list + warp recompute",
+      (5, 6): "cand0 barrier", (6, 7): "cand0 C: winners' SSIM partials", (7, 8): "cand0 barrier",
+      (8, 9): "cand0 G: adjoint gather", (9, 10): "cand0 sample-grad + dP reduce", (10, 11): "cand0 barrier",
+      (12, 13): "cand1 W", (14, 15): "cand1 C", (16, 17): "cand1 G", (17, 18): "cand1 sample-grad + reduce",
+      (0, 20): "TOTAL workgroup"}
+print("== backward")
+for (a, b), n in bn.items():
+    d = st[:, b] - st[:, a]
+    print("%-44s mean %8.0f  median %8.0f  p90 %8.0f ticks" % (n, d.mean(), d.median(), d.quantile(0.9)))
