@@ -374,11 +374,15 @@ struct FwdArgs {
 #else
 #define BBD_FWD_ATTR
 #endif
-__global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(FwdArgs a) {
   // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
   // still read candidate c, so one barrier per warp candidate is enough
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
+#ifdef BBD_FWD_SINGLE_BUF
+  __shared__ __attribute__((aligned(16))) float s_xx[1][3][FPLANE];
+#else
   __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE];
+#endif
   __shared__ float s_red[4];
   int buf = 0;
   const BbdDims dm = a.dm;
@@ -434,7 +438,11 @@ __global__ __launch_bounds__(NT) BBD_FWD_ATTR void warp_ssim_min_fwd_kernel(FwdA
       BBD_STAMP(6 + 4 * (c & 3));
       strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
       BBD_STAMP(7 + 4 * (c & 3));
+#ifdef BBD_FWD_SINGLE_BUF
+      __syncthreads();
+#else
       buf ^= 1;
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < PPT; ++j) loss[j] = 0.0f;
@@ -500,10 +508,10 @@ struct BwdArgs {
 #else
 #define BBD_BWD_ATTR
 #endif
-__global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdArgs a) {
+__global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float s_ybuf[3 * BPLANE + 8];
   __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE + 8];
-  __shared__ __attribute__((aligned(16))) float s_cf[9][CPLANE];  // [channel*3 + {A,B,C}], sparse
+  __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE];  // {A,B,C} of the channel in flight, sparse
   __shared__ uint16_t s_list[CH * CW];                            // coefficient cells won by the candidate
   __shared__ float s_red[4][12];
   __shared__ unsigned s_present;
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
   if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
   // the coefficient planes are sparse (only loss pixels won by the current candidate are non-zero):
   // cleared once here, and each candidate's entries are cleared again by the thread that owns them
-  for (int i = threadIdx.x; i < 9 * CPLANE / 4; i += NT)
+  for (int i = threadIdx.x; i < 3 * CPLANE / 4; i += NT)
     reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
       for (int k = 0; k < NP_CELLS; ++k) {
         if ((int)parg[k] == prev) {
 #pragma unroll
-          for (int pl = 0; pl < 9; ++pl) s_cf[pl][pcell[k]] = 0.0f;
+          for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
         }
         if (parg[k] == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
       }
@@ -617,17 +625,20 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
 
-    // ---- phase C: SSIM partials A,B,C (d loss / d{mu_x, E[x^2], E[xy]}) of the loss pixels won by c
+    // ---- phases C/G, one colour channel at a time (three coefficient planes in LDS instead of nine:
+    //      LDS, not registers, is what caps this kernel's occupancy)
 #if defined(BBD_ABLATE_BWD_COEF)
     const int nwin = 0;
 #else
     const int nwin = a.no_ssim ? 0 : s_count;
 #endif
-    for (int idx = threadIdx.x; idx < nwin; idx += NT) {
-      const int cell = s_list[idx];
-      const int pr = cell / CS, pc = cell - pr * CS;
+    float gx[3][PPT];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
+    for (int ch = 0; ch < 3; ++ch) {
+      // C: SSIM partials A,B,C (d loss / d{mu_x, E[x^2], E[xy]}) of the loss pixels won by c
+      for (int idx = threadIdx.x; idx < nwin; idx += NT) {
+        const int cell = s_list[idx];
+        const int pr = cell / CS, pc = cell - pr * CS;
         float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr)
@@ -639,24 +650,16 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
         float mu_y, sg_y, A, Bc, Cc;
         bbd_ystats(sy_, syy, &mu_y, &sg_y);
         bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
-        s_cf[ch * 3 + 0][cell] = A * w_ssim;
-        s_cf[ch * 3 + 1][cell] = Bc * w_ssim;
-        s_cf[ch * 3 + 2][cell] = Cc * w_ssim;
+        s_cf[0][cell] = A * w_ssim;
+        s_cf[1][cell] = Bc * w_ssim;
+        s_cf[2][cell] = Cc * w_ssim;
       }
-    }
-    BBD_STAMP(7 + 8 * (c & 1));
-    __syncthreads();
-    BBD_STAMP(8 + 8 * (c & 1));
-    if (threadIdx.x == 0) s_count = 0;   // everyone has read it; next written after the barrier below
+      if (ch == 0) BBD_STAMP(7 + 8 * (c & 1));
+      __syncthreads();
+      if (ch == 0) BBD_STAMP(8 + 8 * (c & 1));
+      if (ch == 0 && threadIdx.x == 0) s_count = 0;   // everyone has read it; rewritten after the next barrier
 
-    // ---- phase G: adjoint of reflect-pad + 3x3 mean at this thread's 4 texels
-    float gx[3][PPT];
-#ifdef BBD_BWD_ROLL_CH
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
-    for (int ch = 0; ch < 3; ++ch) {
+      // G: adjoint of reflect-pad + 3x3 mean at this thread's 4 texels
       float xw[8], yw[8];
       {
         const float4* px4 = reinterpret_cast<const float4*>(s_x[ch]) + ((ly + 2) * (BS / 4) + (lx0 >> 2));
@@ -668,9 +671,9 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
       float SA[PPT] = {0.f, 0.f, 0.f, 0.f}, SB[PPT] = {0.f, 0.f, 0.f, 0.f}, SC[PPT] = {0.f, 0.f, 0.f, 0.f};
       if (!a.no_ssim) {
         float cA[3][8], cB[3][8], cC[3][8];
-        load_window<CS>(s_cf[ch * 3 + 0], ly, lx0, cA);
-        load_window<CS>(s_cf[ch * 3 + 1], ly, lx0, cB);
-        load_window<CS>(s_cf[ch * 3 + 2], ly, lx0, cC);
+        load_window<CS>(s_cf[0], ly, lx0, cA);
+        load_window<CS>(s_cf[1], ly, lx0, cB);
+        load_window<CS>(s_cf[2], ly, lx0, cC);
 #pragma unroll
         for (int j = 0; j < PPT; ++j)
 #pragma unroll
@@ -697,6 +700,7 @@ __global__ __launch_bounds__(NT) BBD_BWD_ATTR void warp_ssim_min_bwd_kernel(BwdA
         }
         gx[ch][j] = (q_row_ok && qx0 + j < W) ? acc : 0.0f;
       }
+      if (ch < 2 && !a.no_ssim) __syncthreads();    // the planes are rewritten for the next channel
     }
 
     BBD_STAMP(9 + 8 * (c & 1));
