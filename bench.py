@@ -199,6 +199,12 @@ def main():
             for k in kernels:
                 if k in tj:
                     kernels[k]["pmc_traffic_MB_per_launch"] = round(tj[k]["traffic_bytes"] / 1e6, 1)
+                    if "valu_wave_instructions" in tj[k]:
+                        # the kernels are VALU-bound: 1024 SIMDs, 1.25 ns per wave-instruction
+                        # per SIMD measured by tools/microbench/valu_rate.hip at >= 4 waves/SIMD
+                        floor_ms = tj[k]["valu_wave_instructions"] / 1024 * 1.25e-6
+                        kernels[k]["valu_floor_ms"] = round(floor_ms, 4)
+                        kernels[k]["frac_of_valu_floor"] = round(floor_ms / kernels[k]["mean_ms"], 3)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic}
         global_batch = args.batch * world

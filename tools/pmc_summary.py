@@ -34,4 +34,7 @@ if len(sys.argv) > 2:
             f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024
             w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
             out[names[k]] = {"fetch_bytes": round(f), "write_bytes": round(w), "traffic_bytes": round(f + w)}
+            if "SQ_INSTS_VALU" in cs:
+                out[names[k]]["valu_wave_instructions"] = round(sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"]))
+                out[names[k]]["waves"] = round(sum(cs["SQ_WAVES"]) / len(cs["SQ_WAVES"]))
     json.dump(out, open(sys.argv[2], "w"), indent=1)
