@@ -360,3 +360,54 @@ def test_edge_of_domain_poses_and_depths_on_gpu(backend):
         rel = (g - ge).abs() / (float(ge.abs().max()) + 1e-12)
         assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum()) + 4      # +4: clamp decisions at |ix - border| ~ ulp
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
+
+
+def test_backward_properties_full_size(backend):
+    """Size-independent properties of the fused backward at BASELINE size (B=12, 4 scales, 192x640):
+    bitwise determinism, exact linearity in the upstream scalar (power of two), pose rows that are
+    constants (stereo / error-induced) receive exactly zero, and d loss/d depth is zero wherever an
+    identity candidate won the whole 3x3 neighbourhood."""
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.synthetic import synthetic_batch, synthetic_disp, synthetic_poses
+    from baseboostdepth_amd.plan import get_plan
+    H, W, B, scales = 192, 640, 12, [0, 1, 2, 3]
+    ms = [2, 1, 0, 2, 1, 2, 1, 1, 2, 0, 1, 2]
+    inputs = synthetic_batch(ms, H, W, scales, device=DEV, seed=8)
+    plan = get_plan(inputs["ordering"], True, True)
+    poses = synthetic_poses(plan, device=DEV, seed=3)
+    job = {}
+    for kind, f in plan.pose_jobs:
+        if f == "s":
+            job[(kind, f)] = inputs["stereo_T"][plan.jobs[f]]
+        else:
+            job[(kind, f)] = poses[("cam_T_cam" if kind == "T" else "cam_T_cam_error", 0, f)]
+    table = ops.pose_table(plan, inputs[("K", 0)], inputs[("inv_K", 0)], job)
+    disp = synthetic_disp(B, H, W, scales, device=DEV, seed=4)
+    depth = ops.disp_pyramid_to_depth([disp[s] for s in scales], H, W, 0.1, 100.0, backend)
+    frames = {f: inputs[("color", f, 0)] for f in plan.frames}
+    target = inputs[("color", 0, 0)]
+    ident = ops.identity_losses(plan, frames, target, False, backend)
+
+    def grads(scale):
+        d = depth.detach().clone().requires_grad_(True)
+        t = table.detach().clone().requires_grad_(True)
+        ls, mn, am, _ = ops.fused_reprojection_min(d, t, target, ident, inputs["noise"], plan, frames, False,
+                                                   False, backend)
+        (ls.sum() * scale).backward()
+        return d.grad, t.grad, am
+
+    g1, t1, am = grads(1.0 / 1024)
+    g2, t2, _ = grads(1.0 / 1024)
+    assert torch.equal(g1, g2) and torch.equal(t1, t2)                       # deterministic
+    g4, t4, _ = grads(4.0 / 1024)
+    assert torch.equal(g4, g1 * 4) and torch.allclose(t4, t1 * 4, rtol=1e-6)  # linear in the upstream scalar
+    assert float(t1[:, :12].abs().max()) == 0 and float(t1[:, 28:].abs().max()) == 0   # only T gets gradient
+    for (kind, f), off in plan.pose_offset.items():
+        if kind == "E" or f == "s":
+            assert float(t1[off:off + len(plan.jobs[f])].abs().max()) == 0, (kind, f)
+    # pixels whose 3x3 neighbourhood was won entirely by identity candidates get no depth gradient
+    n_warp = torch.tensor([sum(1 for k, _ in names if k != "I") for names in plan.cand_names], device=DEV)
+    is_ident = (am >= n_warp.view(1, B, 1, 1)).float()
+    all_ident = torch.nn.functional.avg_pool2d(is_ident, 3, 1, 1, count_include_pad=False) == 1.0
+    assert float(g1[all_ident].abs().max()) == 0.0
+    assert float(g1.abs().max()) > 0
