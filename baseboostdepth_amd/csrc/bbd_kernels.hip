@@ -574,18 +574,9 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   unsigned qarg[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) qarg[j] = (q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u;
-  // adjoint multiplicities of reflect-pad + 3x3 mean (0 where the loss pixel is outside the image)
-  float wy[3], wx[PPT][3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const int py = qy + d - 1;
-    wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int px = qx0 + j + d - 1;
-      wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
-    }
-  }
+  // Tiles at least two pixels away from every image border see neither reflection multiplicities nor
+  // missing loss pixels: their 3x3 adjoint is a plain 9-term sum (block-uniform fast path).
+  const bool interior = tc.tx0 >= 2 && tc.tx0 + TW + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
   float gdepth[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
   BBD_STAMP(1);
   __syncthreads();
@@ -668,28 +659,55 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
         xw[0] = a0.x; xw[1] = a0.y; xw[2] = a0.z; xw[3] = a0.w; xw[4] = a1.x; xw[5] = a1.y; xw[6] = a1.z; xw[7] = a1.w;
         yw[0] = b0.x; yw[1] = b0.y; yw[2] = b0.z; yw[3] = b0.w; yw[4] = b1.x; yw[5] = b1.y; yw[6] = b1.z; yw[7] = b1.w;
       }
-      float SA[PPT] = {0.f, 0.f, 0.f, 0.f}, SB[PPT] = {0.f, 0.f, 0.f, 0.f}, SC[PPT] = {0.f, 0.f, 0.f, 0.f};
+      // weighted 3x3 gathers of the three coefficient planes, one plane at a time (register pressure)
+      float S3[3][PPT];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) S3[pl][j] = 0.0f;
       if (!a.no_ssim) {
-        float cA[3][8], cB[3][8], cC[3][8];
-        load_window<CS>(s_cf[0], ly, lx0, cA);
-        load_window<CS>(s_cf[1], ly, lx0, cB);
-        load_window<CS>(s_cf[2], ly, lx0, cC);
+        if (interior) {
 #pragma unroll
-        for (int j = 0; j < PPT; ++j)
+          for (int pl = 0; pl < 3; ++pl) {
+            float cw[3][8];
+            load_window<CS>(s_cf[pl], ly, lx0, cw);
 #pragma unroll
-          for (int dr = 0; dr < 3; ++dr) {
-            float ra = 0.0f, rb = 0.0f, rc = 0.0f;
+            for (int j = 0; j < PPT; ++j)
 #pragma unroll
-            for (int dc = 0; dc < 3; ++dc) {
-              ra = fmaf(wx[j][dc], cA[dr][j + dc], ra);
-              rb = fmaf(wx[j][dc], cB[dr][j + dc], rb);
-              rc = fmaf(wx[j][dc], cC[dr][j + dc], rc);
-            }
-            SA[j] = fmaf(wy[dr], ra, SA[j]);
-            SB[j] = fmaf(wy[dr], rb, SB[j]);
-            SC[j] = fmaf(wy[dr], rc, SC[j]);
+              for (int dr = 0; dr < 3; ++dr) S3[pl][j] += (cw[dr][j] + cw[dr][j + 1]) + cw[dr][j + 2];
           }
+        } else {
+          // adjoint multiplicities of reflect-pad + 3x3 mean (0 where the loss pixel is outside the image)
+          float wy[3], wx[PPT][3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int py = qy + d - 1;
+            wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+              const int px = qx0 + j + d - 1;
+              wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
+            }
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            float cw[3][8];
+            load_window<CS>(s_cf[pl], ly, lx0, cw);
+#pragma unroll
+            for (int j = 0; j < PPT; ++j)
+#pragma unroll
+              for (int dr = 0; dr < 3; ++dr) {
+                float r = 0.0f;
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc) r = fmaf(wx[j][dc], cw[dr][j + dc], r);
+                S3[pl][j] = fmaf(wy[dr], r, S3[pl][j]);
+              }
+          }
+        }
       }
+      const float (&SA)[PPT] = S3[0];
+      const float (&SB)[PPT] = S3[1];
+      const float (&SC)[PPT] = S3[2];
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         const float xq = xw[j + 2], yq = yw[j + 2];
@@ -737,6 +755,9 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
         gdepth[j] += gd;
 #pragma unroll
         for (int k = 0; k < 12; ++k) gP[k] += gp1[k];
+        // keep the four pixels' projections from being interleaved: this phase is the kernel's
+        // register peak, and 168 VGPRs is the line between 2 and 3 waves per SIMD
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (cd.kind & FLAG_NO_POSE_GRAD) {
