@@ -367,7 +367,7 @@ struct FwdArgs {
 };
 
 #ifndef BBD_FWD_WAVES
-#define BBD_FWD_WAVES 1
+#define BBD_FWD_WAVES 3   // 168 VGPRs: the kernel sits right at this line; 2 waves/SIMD is 15 % slower
 #endif
 #ifdef BBD_FWD_VGPR
 #define BBD_FWD_ATTR __attribute__((amdgpu_num_vgpr(BBD_FWD_VGPR)))

@@ -69,12 +69,20 @@ BBD_HD float bbd_div_with(float n, float d, float r) {
   q = fmaf(fmaf(-d, q, n), r, q);
   return fmaf(fmaf(-d, q, n), r, q);
 }
+/* all three magnitudes inside the window with two 3-input integer min/max (a zero numerator simply
+ * takes the exact fallback) */
+BBD_HD int bbd_exp_ok3(float a, float b, float c) {
+  const unsigned ia = __float_as_uint(a) & 0x7fffffffu, ib = __float_as_uint(b) & 0x7fffffffu,
+                 ic = __float_as_uint(c) & 0x7fffffffu;
+  const unsigned mx = max(max(ia, ib), ic), mn = min(min(ia, ib), ic);
+  return mn >= (70u << 23) && mx < (185u << 23);
+}
 BBD_HD float bbd_div(float n, float d) {
-  if (bbd_exp_ok(d) && (bbd_exp_ok(n) || n == 0.0f)) return bbd_div_with(n, d, bbd_rcp_refined(d));
+  if (bbd_exp_ok3(n, d, d)) return bbd_div_with(n, d, bbd_rcp_refined(d));
   return n / d;
 }
 BBD_HD void bbd_div2(float n0, float n1, float d, float* q0, float* q1) {
-  if (bbd_exp_ok(d) && (bbd_exp_ok(n0) || n0 == 0.0f) && (bbd_exp_ok(n1) || n1 == 0.0f)) {
+  if (bbd_exp_ok3(n0, n1, d)) {
     const float r = bbd_rcp_refined(d);
     *q0 = bbd_div_with(n0, d, r);
     *q1 = bbd_div_with(n1, d, r);
