@@ -1,7 +1,6 @@
-"""networks.* API of the reference (networks/__init__.py): same class names, constructor
-arguments, forward signatures and state-dict keys, as PyTorch-ROCm modules (MIOpen convs)."""
-from .resnet_encoder import ResnetEncoder
-from .depth_decoder import DepthDecoder
-from .pose_decoder import PoseDecoder
+"""networks.* API of the reference (same class names, constructor arguments, forward signatures and
+state-dict keys), as PyTorch-ROCm modules: the conv stacks run on MIOpen."""
+from .decoders import DepthDecoder, PoseDecoder
+from .encoder import ResnetEncoder
 
 __all__ = ["ResnetEncoder", "DepthDecoder", "PoseDecoder"]

@@ -38,7 +38,7 @@ def install_stubs():
     try:
         import torchvision  # noqa: F401
     except Exception:
-        class _ResNet:  # placeholder base class for networks.resnet_encoder
+        class _ResNet:  # placeholder base class for the reference encoder module
             pass
 
         tv = _stub("torchvision")
