@@ -16,6 +16,8 @@ over ranks of the wall time.  Rank 0 prints ONE JSON line carrying, besides the 
   kernels       the same for each of the three hot-path kernels
   cpu_baseline  the oracle (PyTorch-CPU restatement of the reference step, BASELINE.json
                 configs[0]: batch 4) timed on this box's host cores, bounded to a few steps
+  hot_path_ab   BASELINE configs[1] A/B on this GPU: the hot path alone as fused HIP kernels vs the
+                same arithmetic as eager PyTorch-ROCm ops (grid_sample / avg_pool2d / cat / min)
 """
 import argparse
 import json
@@ -110,6 +112,45 @@ def cpu_baseline(batch=4, budget_s=25.0):
     return out
 
 
+def eager_hot_path_ab(trainer, inputs, opt, iters=10):
+    """BASELINE configs[1] A/B: the hot path only (generate_images_pred + compute_losses + backward
+    w.r.t. disp and poses) as (a) the fused HIP kernels and (b) the oracle's eager PyTorch-ROCm op
+    sequence (F.grid_sample / avg_pool2d / cat / min - what the reference would launch on this GPU),
+    on identical device-resident inputs.  Measurement only; the product never runs (b)."""
+    from oracle import hotpath_ref as O
+    plan = trainer.plan
+    dev = inputs[("color", 0, 0)].device
+    gen = torch.Generator(device=dev).manual_seed(7)
+    disp = {s: torch.rand(plan.B, 1, H >> s, W >> s, generator=gen, device=dev).requires_grad_(True)
+            for s in opt.scales}
+    from baseboostdepth_amd.synthetic import synthetic_poses
+    pp = synthetic_poses(plan, device=dev, seed=2)
+    poses = {f: pp[("cam_T_cam", 0, f)].clone().requires_grad_(True) for f in plan.frames if f != "s"}
+
+    def fused():
+        out = {("disp", s): disp[s] for s in opt.scales}
+        out.update({("cam_T_cam", 0, f): T for f, T in poses.items()})
+        out.update(trainer.generate_images_pred(inputs, out))
+        trainer.compute_losses(inputs, out)["loss"].backward()
+
+    def eager():
+        O.hot_path(inputs, disp, poses, plan.ms, opt.scales, False, False, inputs["noise"], H, W)["loss"].backward()
+
+    res = {}
+    for name, fn in (("fused_hip_ms", fused), ("eager_rocm_ms", eager)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        res[name] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+    res["speedup"] = round(res["eager_rocm_ms"] / res["fused_hip_ms"], 2)
+    res["what"] = "hot path only: warp+SSIM+min over 4 scales + smoothness, forward+backward, batch %d" % plan.B
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +163,8 @@ def main():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--no-fused-adam", action="store_true")
+    ap.add_argument("--no-eager-ab", action="store_true",
+                    help="skip timing the hot path as eager PyTorch-ROCm ops (oracle) vs the fused kernels")
     args = ap.parse_args()
 
     from baseboostdepth_amd import distributed as bdist
@@ -222,6 +265,8 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
             "roofline": roofline, "kernels": kernels,
         }
+        if world == 1 and not args.no_eager_ab and args.config == "md2":
+            line["hot_path_ab"] = eager_hot_path_ab(trainer, inputs, opt)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

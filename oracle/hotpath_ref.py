@@ -225,9 +225,10 @@ def hot_path(inputs, disp, poses, ms, scales, trimin, decomp, noise, H, W,
                 reproj_e[f] = photometric_loss(we, tgt, no_ssim)
                 if keep:
                     out[("color_D", f, s)] = we
-        mins = torch.zeros(B, H, W)
-        args = torch.zeros(B, H, W, dtype=torch.uint8)
-        margin = torch.zeros(B, H, W)      # runner-up minus winner: how decisive the arg-min is
+        dev = target.device
+        mins = torch.zeros(B, H, W, device=dev)
+        args = torch.zeros(B, H, W, dtype=torch.uint8, device=dev)
+        margin = torch.zeros(B, H, W, device=dev)      # runner-up minus winner: how decisive the arg-min is
         parts = []
         for m in sorted(set(ms)):                      # one min per group, as x_min_opt does
             rows = [b for b in range(B) if ms[b] == m]
