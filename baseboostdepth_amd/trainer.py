@@ -16,7 +16,7 @@ import torch
 import torch.optim as optim
 
 from . import networks, ops
-from .layers import (SSIM, BackprojectDepth, Project3D, disp_to_depth, get_smooth_loss,
+from .layers import (SSIM, BackprojectDepth, Project3D, compute_depth_errors, disp_to_depth, get_smooth_loss,
                      transformation_from_parameters)
 from .plan import STEREO, get_plan
 
@@ -301,6 +301,32 @@ class Trainer:
             total = total + loss
             losses["loss/{}".format(s)] = loss
         losses["loss"] = total / self.num_scales
+        return losses
+
+    # ------------------------------------------------------------------ validation metrics (trainer.py:572-617)
+    def compute_depth_losses(self, outputs, losses, gt_depth, accumulate=False):
+        """KITTI depth metrics of `outputs[("depth",0,0)]` (batch 1) against a ground-truth depth map,
+        entirely on the device: bilinear resize to the GT size, clamp to [1e-3, 80], Garg crop,
+        median scaling, the seven metrics of `layers.compute_depth_errors`.  `gt_depth` is the
+        [h,w] array/tensor the reference keeps in `self.gt_depths[idx]`."""
+        import torch.nn.functional as F
+        min_depth, max_depth = 1e-3, 80
+        gt = torch.as_tensor(gt_depth, dtype=torch.float32, device=self.device)
+        gh, gw = gt.shape[:2]
+        pred = torch.clamp(F.interpolate(outputs["depth", 0, 0], [gh, gw], mode="bilinear", align_corners=False),
+                           1e-3, 80).detach().squeeze()
+        mask = (gt > min_depth) & (gt < max_depth)
+        import numpy as np
+        crop = np.array([0.40810811 * gh, 0.99189189 * gh, 0.03594771 * gw, 0.96405229 * gw]).astype(np.int32)
+        crop_mask = torch.zeros_like(mask)
+        crop_mask[crop[0]:crop[1], crop[2]:crop[3]] = True
+        mask = mask & crop_mask
+        pred = pred * (torch.median(gt[mask]) / torch.median(pred[mask]))
+        pred = torch.clamp(pred, min=min_depth, max=max_depth)
+        errors = compute_depth_errors(gt[mask], pred[mask])
+        for name, val in zip(self.depth_metric_names, errors):
+            v = float(val)
+            losses[name] = losses.get(name, 0.0) + v if accumulate else v
         return losses
 
     def argmin_masks(self, outputs, scale_index=0):

@@ -140,3 +140,27 @@ def test_custom_collate_matches_reference():
                 assert torch.equal(got[k], ref[k]), k
             else:
                 assert got[k] == ref[k], k
+
+
+def test_compute_depth_losses_matches_reference():
+    """Validation metrics (resize, Garg crop, median scaling, 7 errors) vs the live reference."""
+    import refshim
+    if not refshim.reference_available():
+        pytest.skip("reference tree not present on this machine")
+    import types
+    from baseboostdepth_amd.trainer import Trainer
+    rt, rl, rn = refshim.import_reference()
+    gen = torch.Generator().manual_seed(2)
+    gt = (torch.rand(375, 1242, generator=gen) * 90).numpy()
+    gt[gt < 20] = 0                                              # sparse LiDAR-like ground truth
+    depth = 0.5 + 60 * torch.rand(1, 1, 192, 640, generator=gen)
+    names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+    ref = rt.Trainer.__new__(rt.Trainer)
+    ref.device, ref.depth_metric_names, ref.gt_depths = torch.device("cpu"), names, [gt]
+    want = {}
+    ref.compute_depth_losses({("depth", 0, 0): depth.clone()}, want, 0)
+    mine = Trainer.__new__(Trainer)
+    mine.device, mine.depth_metric_names = torch.device("cpu"), names
+    got = mine.compute_depth_losses({("depth", 0, 0): depth.clone()}, {}, gt)
+    for k in names:
+        assert abs(got[k] - float(want[k])) < 1e-5 * max(1.0, abs(float(want[k]))), (k, got[k], want[k])
