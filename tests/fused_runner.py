@@ -150,3 +150,41 @@ def extreme_case(name="tri_2102_32x64", device="cpu"):
         d[:, :, d.shape[2] // 2:, d.shape[3] // 2:] = 1.0        # depth = min_depth
         case.disp[s] = d.requires_grad_(True)
     return case
+
+
+def odd_size_case(H=37, W=70, ms=(2, 1, 0), trimin=True, decomp=True, device="cpu", seed=31):
+    """Synthetic batch whose size is not a multiple of the 64x16 tile nor of 4: partial tiles, scalar
+    (unaligned) loads/stores, image borders inside a tile.  Returns an object shaped like golden_io.Case."""
+    import types
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    from baseboostdepth_amd.plan import get_plan
+    from baseboostdepth_amd.layers import _transformation_from_parameters_torch as tfp
+    ms = list(ms)
+    inputs = synthetic_batch(ms, H, W, [0], device="cpu", seed=seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    plan = get_plan(inputs["ordering"], trimin, decomp)
+    poses = {}
+    for f in plan.frames:
+        if f == "s":
+            continue
+        n = len(plan.jobs[f])
+        poses[f] = tfp(0.02 * torch.randn(n, 1, 3, generator=gen), 0.05 * torch.randn(n, 1, 3, generator=gen),
+                       invert=(f < 0)).to(device).requires_grad_(True)
+    case = types.SimpleNamespace()
+    case.inputs = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inputs.items()}
+    case.noise = case.inputs.pop("noise")
+    case.ms, case.scales, case.trimin, case.decomp = ms, [0], trimin, decomp
+    case.incremental = case.partial = False
+    case.B, case.H, case.W = len(ms), H, W
+    case.disp = {0: (0.02 + 0.5 * torch.rand(len(ms), 1, H, W, generator=gen)).to(device).requires_grad_(True)}
+    case.poses = poses
+
+    def poses_error(pose_error=5.5):
+        out = {}
+        for f, T in case.poses.items():
+            Te = T.clone().detach().cpu()
+            Te[:, :3, 3:] /= pose_error
+            out[f] = Te.to(T.device)
+        return out
+    case.poses_error = poses_error
+    return case

@@ -411,3 +411,24 @@ def test_backward_properties_full_size(backend):
     all_ident = torch.nn.functional.avg_pool2d(is_ident, 3, 1, 1, count_include_pad=False) == 1.0
     assert float(g1[all_ident].abs().max()) == 0.0
     assert float(g1.abs().max()) > 0
+
+
+@pytest.mark.parametrize("H,W", [(37, 70), (16, 64), (19, 130), (200, 646)])
+def test_sizes_off_the_tile_grid_on_gpu(H, W, backend):
+    """Partial tiles, widths not multiple of 4 (scalar load/store paths), borders inside tiles."""
+    from oracle import hotpath_ref as O
+    from fused_runner import odd_size_case
+    case, ref = odd_size_case(H, W, device=DEV), odd_size_case(H, W)
+    out = O.hot_path(ref.inputs, ref.disp, ref.poses, ref.ms, ref.scales, ref.trimin, ref.decomp, ref.noise,
+                     H, W, poses_error=ref.poses_error())
+    out["loss"].backward()
+    tr, inputs, outputs, losses = run_direct_case(case, backend, device=DEV, materialize=True)
+    losses["loss"].backward()
+    got = outputs[("bbd", "to_optimise")][0].cpu()
+    assert float((got - out["min/0"]).abs().max()) < 1e-4
+    mism = outputs[("bbd", "argmin")][0].cpu() != out["argmin/0"]
+    assert int((mism & (out["margin/0"] > 2e-4)).sum()) == 0
+    g, ge = case.disp[0].grad.cpu(), ref.disp[0].grad
+    rel = (g - ge).abs() / float(ge.abs().max())
+    assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum()) + 4
+    assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5

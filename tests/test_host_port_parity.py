@@ -81,3 +81,20 @@ def test_edge_of_domain_poses_and_depths(backend):
         if ge is None:
             continue
         assert float((T.grad - ge).abs().max()) <= 5e-3 * float(ge.abs().max()) + 1e-12, f
+
+
+@pytest.mark.parametrize("H,W", [(37, 70), (16, 64), (19, 130)])
+def test_sizes_off_the_tile_grid(H, W, backend):
+    """Partial tiles / widths that are not multiples of 4: product plumbing + kernel math == oracle."""
+    from oracle import hotpath_ref as O
+    from fused_runner import odd_size_case, run_direct_case
+    case, ref = odd_size_case(H, W), odd_size_case(H, W)
+    out = O.hot_path(ref.inputs, ref.disp, ref.poses, ref.ms, ref.scales, ref.trimin, ref.decomp, ref.noise,
+                     H, W, poses_error=ref.poses_error())
+    out["loss"].backward()
+    tr, inputs, outputs, losses = run_direct_case(case, backend, materialize=False)
+    losses["loss"].backward()
+    assert torch.equal(outputs[("bbd", "to_optimise")][0], out["min/0"])
+    assert torch.equal(outputs[("bbd", "argmin")][0], out["argmin/0"])
+    g, ge = case.disp[0].grad, ref.disp[0].grad
+    assert float((g - ge).abs().max()) <= 2e-3 * float(ge.abs().max())
