@@ -103,6 +103,19 @@ def cpu_baseline(batch=4, budget_s=25.0):
            "sample": "%d full MD2 steps (ResNet-18 nets + oracle hot path + Adam), batch %d, 640x192, 4 scales, "
                      "median step %.3f s; threads probed %s of %d schedulable" % (
                          len(times), batch, med, {k: round(v, 2) for k, v in probe.items()}, avail)}
+    # hot-path-only split: generate_images_pred + compute_losses + backward on fixed disp/poses
+    try:
+        from oracle import hotpath_ref as O
+        g = torch.Generator().manual_seed(3)
+        hd = {s: torch.rand(batch, 1, H >> s, W >> s, generator=g).requires_grad_(True) for s in SCALES}
+        hp = {f: O.pose_matrix(0.01 * torch.randn(batch, 1, 3, generator=g), 0.05 * torch.randn(batch, 1, 3, generator=g),
+                               invert=(f < 0)).requires_grad_(True) for f in (1, -1)}
+        O.hot_path(inputs, hd, hp, ms, SCALES, False, False, noise, H, W)["loss"].backward()
+        t0 = time.perf_counter()
+        O.hot_path(inputs, hd, hp, ms, SCALES, False, False, noise, H, W)["loss"].backward()
+        out["hot_path_only_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    except Exception as e:      # the baseline is informational; never fail the benchmark on it
+        out["hot_path_only_ms"] = "n/a (%s)" % type(e).__name__
     if (time.perf_counter() - t_all) < budget_s:
         torch.set_num_threads(1)                                     # the reference's own setting (train.py:23)
         t0 = time.perf_counter()
