@@ -92,6 +92,18 @@ def compare_with_golden(case, tr, outputs, losses, loss_tol=1e-5, map_tol=2e-5, 
                 assert torch.equal(d, de), "depth scale %d not bit-exact" % s
             assert torch.allclose(d, de, rtol=2e-6, atol=1e-7), float((d - de).abs().max())
     assert abs(float(losses["loss"].detach()) - float(case.expected("out/loss"))) < loss_tol
+    # identity photometric losses (un-warped source vs target), one map per (sample, frame)
+    ident = outputs[("bbd", "identity")].detach().cpu()
+    for k in case.z.files:
+        if k.startswith("out/ident/"):
+            f = k.split("/")[2]
+            f = STEREO if f == "s" else int(f)
+            want = case.expected(k)[:, 0]
+            rows = [tr.plan.ident_index[(b, f)] for b in tr.plan.jobs[f]]
+            got_i = ident[rows]
+            if exact:
+                assert torch.equal(got_i, want), "identity loss of frame %s not bit-exact" % (f,)
+            assert float((got_i - want).abs().max()) < map_tol + 1e-6
     if check_warps:
         for k in case.z.files:
             if k.startswith("out/color"):

@@ -290,6 +290,13 @@ def run_case(rt, rl, rn, spec):
         for key, val in outputs.items():
             if key[0] in ("color", "color_D"):
                 rec["out/%s/%s/%d" % (key[0], fkey(key[1]), key[2])] = val.detach().numpy()
+    # identity photometric losses per warp job, exactly as compute_losses forms them (trainer.py:501-508)
+    if spec.get("store_identity", H * W <= 64 * 64):
+        mv = tr.valid_tri_mask if opt.trimin else tr.valid_mask
+        for f in tr.valid_frames:
+            tgt = inputs[("color", 0, 0)][mask_dict[f if f == "s" else abs(f)]]
+            src = inputs[("color", f, 0)] if f == "s" else inputs[("color", f, 0)][mv[abs(f)]]
+            rec["out/ident/%s" % fkey(f)] = tr.compute_reprojection_loss(src, tgt).detach().numpy()
     os.makedirs(OUT_DIR, exist_ok=True)
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **rec)
