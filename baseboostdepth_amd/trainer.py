@@ -152,8 +152,18 @@ class Trainer:
     def _rows(self, tensor, rows):
         if len(rows) == tensor.shape[0] and list(rows) == list(range(tensor.shape[0])):
             return tensor
-        idx = torch.as_tensor(rows, dtype=torch.long, device=tensor.device)
-        return tensor.index_select(0, idx)
+        return tensor.index_select(0, self._index(rows, tensor.device))
+
+    def _index(self, rows, device, dtype=torch.long):
+        """Row-index tensors are cached per (rows, device): the boosted pose modes select sub-batches
+        ~60 times per step and each fresh `torch.as_tensor(list)` is a synchronous host-to-device copy."""
+        key = (tuple(rows), str(device), dtype)
+        cache = self.__dict__.setdefault("_index_cache", {})
+        if key not in cache:
+            if len(cache) > 8192:
+                cache.clear()
+            cache[key] = torch.as_tensor(list(rows), dtype=dtype, device=device)
+        return cache[key]
 
     # ------------------------------------------------------------------ poses (trainer.py:310-419)
     def _pose_pair(self, first, second, invert):
@@ -228,8 +238,8 @@ class Trainer:
                 chained = outputs[("cam_T_cam", 0, f)]
                 replaced = torch.cat([chained[:, :, :3], direct[:, :, 3:]], dim=2)
                 # the reference indexes its all-sample list by ROW number of the n_f-row tensor
-                keep = torch.tensor([abs(f) == nonstereo[r] - 2 for r in range(chained.shape[0])],
-                                    device=self.device).view(-1, 1, 1)
+                keep = self._index([abs(f) == nonstereo[r] - 2 for r in range(chained.shape[0])], self.device,
+                                   torch.bool).view(-1, 1, 1)
                 outputs[("cam_T_cam", 0, f)] = torch.where(keep, chained, replaced)
         return outputs
 
