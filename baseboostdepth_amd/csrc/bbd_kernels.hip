@@ -814,6 +814,7 @@ __global__ __launch_bounds__(NT) void disp_to_depth_fwd_kernel(const float* __re
 // fixed xor-butterfly, so the result is deterministic and small scales still fill the chip.
 template <int Q>
 __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __restrict__ disp,
+                                                               const float* __restrict__ depth,
                                                                const float* __restrict__ gdepth,
                                                                float* __restrict__ gdisp, int B, int h, int w,
                                                                int H, int W, float lo, float span) {
@@ -827,6 +828,7 @@ __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __re
   const int b = (int)(i / ((size_t)w * h));
   const float* d = disp + (size_t)b * h * w;
   const float* g = gdepth + (size_t)b * H * W;
+  const float* dep = depth ? depth + (size_t)b * H * W : nullptr;
   float acc = 0.0f;
   if (h == H && w == W) {
     const float sc = lo + span * d[(size_t)y * w + x];
@@ -850,11 +852,16 @@ __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __re
       const float wy = (y0 == y ? ly0 : 0.0f) + (y1 == y ? ly1 : 0.0f);
       const float wx = (x0 == x ? lx0 : 0.0f) + (x1 == x ? lx1 : 0.0f);
       if (wy == 0.0f || wx == 0.0f) continue;
-      // recompute the up-sampled disparity at (oy, ox) for d depth / d disp_up
-      const float sc = lo + span * bbd_up_blend(d[(size_t)y0 * w + x0], d[(size_t)y0 * w + x1],
-                                                d[(size_t)y1 * w + x0], d[(size_t)y1 * w + x1], ly0, ly1, lx0,
-                                                lx1, small);
-      acc += g[(size_t)oy * W + ox] * (-span / (sc * sc)) * wy * wx;
+      if (dep != nullptr) {
+        // d depth / d disp_up = -span / scaled^2 = -span * depth^2 with the forward's saved depth
+        const float dp = dep[(size_t)oy * W + ox];
+        acc += g[(size_t)oy * W + ox] * (-span * dp * dp) * wy * wx;
+      } else {
+        const float sc = lo + span * bbd_up_blend(d[(size_t)y0 * w + x0], d[(size_t)y0 * w + x1],
+                                                  d[(size_t)y1 * w + x0], d[(size_t)y1 * w + x1], ly0, ly1, lx0,
+                                                  lx1, small);
+        acc += g[(size_t)oy * W + ox] * (-span / (sc * sc)) * wy * wx;
+      }
     }
   }
 #pragma unroll
@@ -1075,7 +1082,7 @@ __global__ __launch_bounds__(NT) void pose_matrix_bwd_kernel(const float* __rest
 // Edge-aware smoothness of the mean-normalised disparity (layers.py:203-216, trainer.py:560-564).
 // Deterministic: per-(sample, row-chunk) partial sums, fixed reduction order.
 // ------------------------------------------------------------------------------------------
-constexpr int SM_CHUNKS = 16;
+constexpr int SM_CHUNKS = 64;   // B x 64 workgroups per launch: enough to cover 256 CUs at B = 12
 
 __device__ __forceinline__ float block_sum_all(float v, float* s_red4) {   // every thread gets the total
   const float w = wave_sum63(v);
@@ -1336,8 +1343,8 @@ int bbd_disp_to_depth_fwd(const float* disp, float* depth, int B, int h, int w, 
   return launch_status();
 }
 
-int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp, int B, int h, int w, int H,
-                          int W, double min_depth, double max_depth, void* stream) {
+int bbd_disp_to_depth_bwd(const float* disp, const float* depth, const float* grad_depth, float* grad_disp, int B,
+                          int h, int w, int H, int W, double min_depth, double max_depth, void* stream) {
   if (!disp || !grad_depth || !grad_disp || B <= 0 || h <= 0 || w <= 0 || H < h || W < w) return BBD_E_BADARG;
   const float lo = (float)(1.0 / max_depth), span = (float)(1.0 / min_depth - 1.0 / max_depth);
   const size_t n = (size_t)B * h * w;
@@ -1345,7 +1352,7 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* gra
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define BBD_D2D_BWD(Q)                                                                                         \
   hipLaunchKernelGGL(disp_to_depth_bwd_kernel<Q>, dim3((unsigned)((n * Q + NT - 1) / NT)), dim3(NT), 0, st, disp, \
-                     grad_depth, grad_disp, B, h, w, H, W, lo, span)
+                     depth, grad_depth, grad_disp, B, h, w, H, W, lo, span)
   if (f <= 1) BBD_D2D_BWD(1);
   else if (f <= 2) BBD_D2D_BWD(4);
   else if (f <= 4) BBD_D2D_BWD(16);

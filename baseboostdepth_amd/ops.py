@@ -104,19 +104,19 @@ class _DispToDepth(torch.autograd.Function):
         backend._check(disp)
         backend.run("bbd_disp_to_depth_fwd", disp, ptr(disp), ptr(depth), B, h, w, H, W,
                     float(min_depth), float(max_depth))
-        ctx.save_for_backward(disp)
+        ctx.save_for_backward(disp, depth)
         ctx.meta = (H, W, float(min_depth), float(max_depth), backend)
         return depth
 
     @staticmethod
     def backward(ctx, grad_depth):
-        (disp,) = ctx.saved_tensors
+        disp, depth = ctx.saved_tensors
         H, W, lo, hi, backend = ctx.meta
         B, _, h, w = disp.shape
         grad_depth = grad_depth.contiguous()
         grad_disp = torch.empty_like(disp)
-        backend.run("bbd_disp_to_depth_bwd", disp, ptr(disp), ptr(grad_depth), ptr(grad_disp), B, h, w, H, W,
-                    lo, hi)
+        backend.run("bbd_disp_to_depth_bwd", disp, ptr(disp), ptr(depth), ptr(grad_depth), ptr(grad_disp), B, h, w,
+                    H, W, lo, hi)
         return grad_disp, None, None, None, None, None
 
 
@@ -137,20 +137,20 @@ class _DispPyramidToDepth(torch.autograd.Function):
         for i, d in enumerate(disps):
             backend.run("bbd_disp_to_depth_fwd", d, ptr(d), ptr(depth[i]), B, d.shape[2], d.shape[3], H, W,
                         float(min_depth), float(max_depth))
-        ctx.save_for_backward(*disps)
+        ctx.save_for_backward(depth, *disps)
         ctx.meta = (H, W, float(min_depth), float(max_depth), backend)
         return depth
 
     @staticmethod
     def backward(ctx, grad_depth):
-        disps = ctx.saved_tensors
+        depth, disps = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         H, W, lo, hi, backend = ctx.meta
         grad_depth = grad_depth.contiguous()
         grads = []
         for i, d in enumerate(disps):
             g = torch.empty_like(d)
-            backend.run("bbd_disp_to_depth_bwd", d, ptr(d), ptr(grad_depth[i]), ptr(g), d.shape[0], d.shape[2],
-                        d.shape[3], H, W, lo, hi)
+            backend.run("bbd_disp_to_depth_bwd", d, ptr(d), ptr(depth[i]), ptr(grad_depth[i]), ptr(g), d.shape[0],
+                        d.shape[2], d.shape[3], H, W, lo, hi)
             grads.append(g)
         return (None, None, None, None, None) + tuple(grads)
 

@@ -112,8 +112,9 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
  * layers.disp_to_depth (layers.py:13-22).  disp [B,h,w] -> depth [B,H,W].           */
 int bbd_disp_to_depth_fwd(const float* disp, float* depth, int B, int h, int w, int H, int W,
                           double min_depth, double max_depth, void* stream);
-/* grad_disp [B,h,w] is OVERWRITTEN with the adjoint (gather form, deterministic). */
-int bbd_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp,
+/* grad_disp [B,h,w] is OVERWRITTEN with the adjoint (gather form, deterministic).  `depth` is the
+ * forward's output [B,H,W] (d depth/d disp_up = -span*depth^2) or NULL to recompute it from disp. */
+int bbd_disp_to_depth_bwd(const float* disp, const float* depth, const float* grad_depth, float* grad_disp,
                           int B, int h, int w, int H, int W,
                           double min_depth, double max_depth, void* stream);
 

@@ -214,8 +214,8 @@ int hp_disp_to_depth_fwd(const float* disp, float* depth, int B, int h, int w, i
 }
 
 // scatter-form adjoint (the kernel uses a gather)
-int hp_disp_to_depth_bwd(const float* disp, const float* grad_depth, float* grad_disp, int B, int h, int w, int H,
-                         int W, double min_depth, double max_depth) {
+int hp_disp_to_depth_bwd(const float* disp, const float* /*depth*/, const float* grad_depth, float* grad_disp, int B,
+                         int h, int w, int H, int W, double min_depth, double max_depth) {
   const float lo = (float)(1.0 / max_depth), span = (float)(1.0 / min_depth - 1.0 / max_depth);
   memset(grad_disp, 0, sizeof(float) * B * h * w);
   for (int b = 0; b < B; ++b)
