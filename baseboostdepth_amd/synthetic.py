@@ -87,3 +87,21 @@ def synthetic_poses(plan, device="cpu", seed=2, pose_error=5.5):
             Te[:, :3, 3:] /= pose_error
             out[("cam_T_cam_error", 0, f)] = Te
     return out
+
+
+def synthetic_loader(batch_size, steps, H=192, W=640, scales=(0, 1, 2, 3), device="cpu", seed=42, trimin=False,
+                     epoch=0):
+    """Generator of `steps` synthetic batches shaped like the reference loader's output for `epoch`:
+    before epoch 10 the largest offset is 1 (2 with tri-minimisation, stereo for small baselines), from
+    epoch 10 it follows the epoch-15 offset distribution of SURVEY.md 8d (m in 1..7)."""
+    import random
+    rnd = random.Random(seed + 1000 * epoch)
+    for it in range(steps):
+        if epoch < 10:
+            ms = [rnd.choice([0, 1, 2]) if trimin else 1 for _ in range(batch_size)]
+        else:
+            ms = [rnd.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448])[0] for _ in range(batch_size)]
+        batch = synthetic_batch(ms, H, W, scales, device=device, seed=seed + it)
+        batch["cutt"] = torch.tensor(0.1 + 0.04 * epoch if epoch < 10 else 0.15 * epoch - 0.9)
+        batch.pop("noise")        # let the trainer draw its own identity noise, like the reference
+        yield batch

@@ -96,6 +96,27 @@ class Trainer:
         self.step += 1
         return outputs, losses
 
+    def run_epoch(self, loader):
+        """One epoch over an iterable of collated batches, with the reference's per-epoch curriculum
+        (trainer.py:196-232): LR schedule step, and - under --rand - all four scales before epoch 10,
+        scale 0 only afterwards.  The loader itself (frame-set selection by baseline, mono_dataset.py)
+        is the caller's: `synthetic.synthetic_loader` here, a KITTI loader in the reference."""
+        self.model_lr_scheduler.step()
+        self.set_train()
+        if getattr(self.opt, "rand", False):
+            self.opt.scales = [0, 1, 2, 3] if self.epoch < 10 else [0]
+        last = None
+        for self.batch_idx, inputs in enumerate(loader):
+            last = self.train_step(inputs)
+        return last
+
+    def train(self, loader_factory, num_epochs=None):
+        """`loader_factory(epoch)` -> iterable of batches; checkpoints every `save_frequency` epochs."""
+        for self.epoch in range(self.epoch, num_epochs or self.opt.num_epochs):
+            self.run_epoch(loader_factory(self.epoch))
+            if (self.epoch + 1) % getattr(self.opt, "save_frequency", 1) == 0 and getattr(self.opt, "save_models", False):
+                self.save_model()
+
     def process_batch(self, inputs, batch_idx=None, is_train=True):
         for key, ipt in inputs.items():
             if key not in ["frames", "ordering", "cutt"] and torch.is_tensor(ipt):
