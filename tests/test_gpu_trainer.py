@@ -112,3 +112,22 @@ def test_checkpoint_roundtrip(tmp_path):
     for name in a.models:
         for (k, v), (_, w) in zip(a.models[name].state_dict().items(), b.models[name].state_dict().items()):
             assert torch.equal(v, w), (name, k)
+
+
+def test_loss_goes_down_on_a_fixed_batch():
+    """End-to-end sanity of the gradients through depth + pose nets: 40 Adam steps on one batch."""
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, ms = 96, 160, [1, 1, 1, 1]
+    torch.manual_seed(0)
+    opt = make_opt(H, W, 4, [0, 1, 2, 3], False)
+    opt.learning_rate = 2e-4
+    tr = Trainer(opt)
+    tr.set_train()
+    inputs = synthetic_batch(ms, H, W, [0, 1, 2, 3], device=DEV, seed=5)
+    hist = []
+    for _ in range(40):
+        _, l = tr.train_step(dict(inputs))
+        hist.append(float(l["loss"].detach()))
+    assert all(h == h for h in hist)
+    assert sum(hist[-5:]) / 5 < sum(hist[:5]) / 5 - 1e-3, (hist[:5], hist[-5:])
