@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("BBD_HIP_LIB", os.path.join(_HERE, "csrc", "libbbd_hip
 MAX_FRAME_SLOTS = 16
 MAX_CAND = 20
 POSE_STRIDE = 40
+PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
 ABI_VERSION = 1
 
@@ -29,6 +30,7 @@ SIGNATURES = {
     "bbd_tile_w": [],
     "bbd_tile_h": [],
     "bbd_num_tiles": [_i, _i],
+    "bbd_pose_expand": [_p, _p, _i, _p],
     "bbd_identity_loss_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
     "bbd_warp_ssim_min_fwd": [_p] * 12 + [_i] * 6 + [_p],
     "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],

@@ -154,8 +154,11 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
                                               float* __restrict__ warped_out) {
+  // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
+  // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
-  bbd_make_proj(pose_row, pj);
+#pragma unroll
+  for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
 #if defined(BBD_ABLATE_WARP)          // timing experiment only: no projection, no gathers
 #pragma unroll
   for (int k = 0; k < CellsT::N; ++k) {
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
       float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
       BBD_STAMP(4 + 4 * (c & 3));
-      warp_into_lds(src, dcell, a.pose + (size_t)cd.pose * BBD_POSE_STRIDE, dm, hw, cl, s_xx[buf], wout);
+      warp_into_lds(src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
       BBD_STAMP(5 + 4 * (c & 3));
       __syncthreads();
       BBD_STAMP(6 + 4 * (c & 3));
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
       continue;
     }
     const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
-    const float* pose_row = a.pose + (size_t)cd.pose * BBD_POSE_STRIDE;
+    const float* pose_row = a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE;
 
     // ---- phase W: clear the previous candidate's coefficients, list this candidate's winners, and
     //      recompute the warped region.  Staging cell (r,c) holds the warped value AT the reflected
@@ -733,7 +736,8 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
     if (q_row_ok) {
 #endif
       float pj[21];
-      bbd_make_proj(pose_row, pj);
+#pragma unroll
+      for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         const int qx = qx0 + j;
@@ -965,6 +969,23 @@ __global__ __launch_bounds__(NT) void ssim_map_kernel(const float* __restrict__ 
         out[(size_t)item * img + ch * hw + (size_t)yy * W + xx + j] = bbd_ssim(sx, sxx, sxy, mu_y[ch][j], sg_y[ch][j]);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pose table [NP,40] (K[:3,:] | T | inv_K[:3,:3]) -> projection table [NP,24] (P = (K@T)[:3,:] | inv_K).
+// One thread per row; bbd_make_proj applies the reference CPU path's rounding order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void pose_expand_kernel(const float* __restrict__ pose, float* __restrict__ proj,
+                                                         int n) {
+  const int i = blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  float out[21];
+  bbd_make_proj(pose + (size_t)i * BBD_POSE_STRIDE, out);
+#pragma unroll
+  for (int k = 0; k < 21; ++k) proj[(size_t)i * BBD_PROJ_STRIDE + k] = out[k];
+  proj[(size_t)i * BBD_PROJ_STRIDE + 21] = 0.0f;
+  proj[(size_t)i * BBD_PROJ_STRIDE + 22] = 0.0f;
+  proj[(size_t)i * BBD_PROJ_STRIDE + 23] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1358,6 +1379,14 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* depth, const float* gr
   else if (f <= 4) BBD_D2D_BWD(16);
   else BBD_D2D_BWD(64);
 #undef BBD_D2D_BWD
+  return launch_status();
+}
+
+int bbd_pose_expand(const float* pose, float* proj, int NP, void* stream) {
+  if (!pose || !proj || NP < 0) return BBD_E_BADARG;
+  if (NP == 0) return 0;
+  hipLaunchKernelGGL(pose_expand_kernel, dim3((unsigned)((NP + NT - 1) / NT)), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), pose, proj, NP);
   return launch_status();
 }
 

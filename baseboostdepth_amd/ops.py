@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import POSE_STRIDE, MAX_FRAME_SLOTS, ptr
+from ._lib import POSE_STRIDE, PROJ_STRIDE, MAX_FRAME_SLOTS, ptr
 from .plan import frame_slot
 
 
@@ -274,10 +274,13 @@ class _FusedReprojectionMin(torch.autograd.Function):
         warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
         backend._check(depth, proj, target, ident, noise, *frame_tensors.values())
         frames = frame_pointer_array(frame_tensors)
-        backend.run("bbd_warp_ssim_min_fwd", depth, frames, ptr(target), ptr(depth), ptr(proj), ptr(ident),
+        # pose table (K | T | inv_K) -> projection table (P | inv_K), once per step
+        ptab = torch.empty(plan.NP, PROJ_STRIDE, device=dev, dtype=torch.float32)
+        backend.run("bbd_pose_expand", proj, ptr(proj), ptr(ptab), plan.NP)
+        backend.run("bbd_warp_ssim_min_fwd", depth, frames, ptr(target), ptr(depth), ptr(ptab), ptr(ident),
                     ptr(noise), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial),
                     ptr(warped), S, B, plan.NP, H, W, int(no_ssim))
-        ctx.save_for_backward(depth, proj, target, argmin)
+        ctx.save_for_backward(depth, proj, target, argmin, ptab)
         ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, ntiles)
         ctx.mark_non_differentiable(min_loss, argmin)
         outs = (partial.view(S, -1).sum(dim=1), min_loss, argmin)
@@ -288,7 +291,7 @@ class _FusedReprojectionMin(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_sum, *_unused):
-        depth, proj, target, argmin = ctx.saved_tensors
+        depth, proj, target, argmin, ptab = ctx.saved_tensors
         plan, frame_tensors, frames, no_ssim, backend, ntiles = ctx.meta
         S, B, H, W = depth.shape
         dev = depth.device
@@ -296,7 +299,7 @@ class _FusedReprojectionMin(torch.autograd.Function):
         gscale = g_sum.contiguous().to(torch.float32)
         grad_depth = torch.empty_like(depth)
         gp_partial = torch.empty(S, plan.NP, ntiles, 12, device=dev, dtype=torch.float32)
-        backend.run("bbd_warp_ssim_min_bwd", depth, frames, ptr(target), ptr(depth), ptr(proj), ptr(tb["cand"]),
+        backend.run("bbd_warp_ssim_min_bwd", depth, frames, ptr(target), ptr(depth), ptr(ptab), ptr(tb["cand"]),
                     ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_depth), ptr(gp_partial),
                     S, B, plan.NP, H, W, no_ssim)
         # dL/dT = K[:3,:]^T @ dL/dP  (P = (K@T)[:3,:]); K and inv_K columns get no gradient

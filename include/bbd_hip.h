@@ -52,16 +52,24 @@ typedef struct bbd_cand {
 } bbd_cand_t;
 
 /* Row of the pose table (40 floats) of one (warp job, sample):  K[:3,:] row-major (12),
- * T row-major (16), inv_K[:3,:3] row-major (9), 3 pad.  The kernels form P = (K@T)[:3,:]
- * themselves with the reference's CPU rounding order; replaces the per-warp matmul chain of
- * layers.py:163-165 and :182-185. */
+ * T row-major (16), inv_K[:3,:3] row-major (9), 3 pad.  bbd_pose_expand turns it into the
+ * projection table with the reference's CPU rounding order; replaces the per-warp matmul chain
+ * of layers.py:163-165 and :182-185. */
 #define BBD_POSE_STRIDE 40
+
+/* Row of the projection table (24 floats) the fused kernels read: P = (K@T)[:3,:] row-major (12),
+ * inv_K[:3,:3] row-major (9), 3 pad.  Produced from the pose table by bbd_pose_expand. */
+#define BBD_PROJ_STRIDE 24
 
 /* Geometry of the launch tiling, so callers can size scratch buffers. */
 int bbd_abi_version(void);
 int bbd_tile_w(void);
 int bbd_tile_h(void);
 int bbd_num_tiles(int H, int W);
+
+/* Pose table [NP,40] -> projection table [NP,24]: P = (K@T)[:3,:] formed with the rounding order of
+ * the reference's CPU torch.matmul (layers.py:182), inv_K[:3,:3] copied. */
+int bbd_pose_expand(const float* pose, float* proj, int NP, void* stream);
 
 /* Identity photometric loss  0.85*mean_c SSIM(src, tgt) + 0.15*mean_c |tgt - src|
  * for NI (target sample, source image) pairs.  Replaces trainer.py:501-508
@@ -79,7 +87,7 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target,
  * Replaces trainer.py:421-442 (warping_block), :477-486, :525-557 and x_min_opt :983-1100,
  * i.e. layers.BackprojectDepth/Project3D/SSIM + F.grid_sample + cat + torch.min.
  *   depth      [S,B,H,W]   full-resolution depth per scale (outputs[("depth",0,s)])
- *   pose       [NP,40]     pose table (see BBD_POSE_STRIDE)
+ *   proj       [NP,24]     projection table from bbd_pose_expand (see BBD_PROJ_STRIDE)
  *   ident      [NI,H,W]    identity losses from bbd_identity_loss_fwd
  *   noise      [B,H,W]     identity noise per sample (trainer.py:518-523), may be NULL
  *   cand/ncand [B][BBD_MAX_CAND] / [B]
@@ -88,7 +96,7 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target,
  *   partial    out [S,B,ntiles] per-tile sums of min_loss (deterministic 2-stage mean)
  *   warped     out [S,NP,3,H,W] or NULL: materialise outputs[("color"/"color_D",f,s)]      */
 int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const float* depth,
-                          const float* pose, const float* ident, const float* noise,
+                          const float* proj, const float* ident, const float* noise,
                           const bbd_cand_t* cand, const int32_t* ncand,
                           float* min_loss, uint8_t* argmin, float* partial, float* warped,
                           int S, int B, int NP, int H, int W, int no_ssim, void* stream);
@@ -102,7 +110,7 @@ int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const 
  *                               tiles and applies dL/dT = K[:3,:]^T dL/dP; rows never visited
  *                               are written as zeros)                                        */
 int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth,
-                          const float* pose, const bbd_cand_t* cand, const int32_t* ncand,
+                          const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
                           const uint8_t* argmin, const float* gscale,
                           float* grad_depth, float* grad_proj,
                           int S, int B, int NP, int H, int W, int no_ssim, void* stream);

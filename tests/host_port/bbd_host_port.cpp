@@ -40,9 +40,7 @@ float photometric(const float* px, const float* py, int y, int x, int H, int W, 
   return bbd_combine(ssim, l1, no_ssim);
 }
 
-void warp_image(const float* src, const float* depth, const float* pose_row, int H, int W, float* out) {
-  float proj[21];
-  bbd_make_proj(pose_row, proj);
+void warp_image(const float* src, const float* depth, const float* proj, int H, int W, float* out) {
   const BbdDims dm = bbd_dims(H, W);
   for (int y = 0; y < H; ++y)
     for (int x = 0; x < W; ++x) {
@@ -61,6 +59,16 @@ void warp_image(const float* src, const float* depth, const float* pose_row, int
 }  // namespace
 
 extern "C" {
+
+int hp_pose_expand(const float* pose, float* proj, int NP) {
+  for (int i = 0; i < NP; ++i) {
+    float out[21];
+    bbd_make_proj(pose + (size_t)i * BBD_POSE_STRIDE, out);
+    for (int k = 0; k < 21; ++k) proj[(size_t)i * BBD_PROJ_STRIDE + k] = out[k];
+    for (int k = 21; k < BBD_PROJ_STRIDE; ++k) proj[(size_t)i * BBD_PROJ_STRIDE + k] = 0.0f;
+  }
+  return 0;
+}
 
 int hp_identity_loss_fwd(const void* const* frames, const float* target, const int32_t* items, int NI,
                          float* ident, int H, int W, int no_ssim) {
@@ -91,7 +99,7 @@ int hp_warp_ssim_min_fwd(const void* const* frames, const float* target, const f
         const bbd_cand_t cd = cand[b * BBD_MAX_CAND + c];
         if ((cd.kind & 0xff) == BBD_KIND_WARP) {
           const float* src = static_cast<const float*>(frames[cd.slot]) + (size_t)cd.row * img;
-          warp_image(src, depth + sb * hw, proj + (size_t)cd.pose * BBD_POSE_STRIDE, H, W, wbuf.data());
+          warp_image(src, depth + sb * hw, proj + (size_t)cd.pose * BBD_PROJ_STRIDE, H, W, wbuf.data());
           if (warped) memcpy(warped + ((size_t)s * NP + cd.pose) * img, wbuf.data(), img * sizeof(float));
           for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
@@ -132,10 +140,8 @@ int hp_warp_ssim_min_bwd(const void* const* frames, const float* target, const f
         const bbd_cand_t cd = cand[b * BBD_MAX_CAND + c];
         if ((cd.kind & 0xff) != BBD_KIND_WARP) continue;
         const float* src = static_cast<const float*>(frames[cd.slot]) + (size_t)cd.row * img;
-        const float* pose_row = proj + (size_t)cd.pose * BBD_POSE_STRIDE;
-        float pj[21];
-        bbd_make_proj(pose_row, pj);
-        warp_image(src, dep, pose_row, H, W, wbuf.data());
+        const float* pj = proj + (size_t)cd.pose * BBD_PROJ_STRIDE;
+        warp_image(src, dep, pj, H, W, wbuf.data());
         std::fill(gx.begin(), gx.end(), 0.0f);
         // scatter d loss_p / d warped texels for every pixel p this candidate won
         for (int y = 0; y < H; ++y)
