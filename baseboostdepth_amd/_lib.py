@@ -44,8 +44,11 @@ SIGNATURES = {
     "bbd_backproject_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_project3d_fwd": [_p, _p, _p, _p, _i, _i, _i, _d, _p],
     "bbd_ssim_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_depth_metrics": [_p, _p, _p, _p, _i, _i, _i, _d, _d, _d, _d, _d, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
 }
+EVAL_DESC, EVAL_OUT = 8, 12
+EVAL_PRED_IS_DISP, EVAL_MEDIAN_MIDPOINT, EVAL_NO_MEDIAN_SCALING = 1, 2, 4
 
 
 class BbdError(RuntimeError):

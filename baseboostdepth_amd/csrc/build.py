@@ -11,9 +11,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "bbd_kernels.hip")
+SRCS = [os.path.join(HERE, "bbd_kernels.hip"), os.path.join(HERE, "bbd_eval.hip")]
 OUT = os.path.join(HERE, "libbbd_hip.so")
-DEPS = [SRC, os.path.join(HERE, "bbd_math.h"), os.path.join(HERE, "..", "..", "include", "bbd_hip.h")]
+DEPS = SRCS + [os.path.join(HERE, "bbd_math.h"), os.path.join(HERE, "..", "..", "include", "bbd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17"]
 
 
@@ -21,7 +21,7 @@ def build(force=False, verbose=False):
     if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
+    cmd = [hipcc] + FLAGS + ["-o", OUT] + SRCS
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -1,0 +1,68 @@
+"""Validation metrics on the device.
+
+`GroundTruthSet` keeps a whole split's ground-truth depth maps (ragged sizes) resident in HBM as
+one buffer plus an int descriptor table, so scoring an image is one kernel launch with no host
+round trip - the reference re-uploads the map, builds the crop mask in numpy, gathers with it and
+sorts twice per image (trainer.py:594-617, evaluate_depth.py:244-297).
+
+`depth_metrics` is the single entry: one `bbd_depth_metrics` launch for a batch of predictions.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import (EVAL_DESC, EVAL_OUT, EVAL_PRED_IS_DISP, EVAL_MEDIAN_MIDPOINT, EVAL_NO_MEDIAN_SCALING, ptr)
+
+METRIC_NAMES = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]   # trainer.py:156
+GARG_CROP = (0.40810811, 0.99189189, 0.03594771, 0.96405229)     # trainer.py:603-604
+
+
+def garg_window(gh, gw):
+    """[r0,r1) x [c0,c1) exactly as the reference computes it (float64 products truncated to int32)."""
+    c = np.array([GARG_CROP[0] * gh, GARG_CROP[1] * gh, GARG_CROP[2] * gw, GARG_CROP[3] * gw]).astype(np.int32)
+    return int(c[0]), int(c[1]), int(c[2]), int(c[3])
+
+
+class GroundTruthSet:
+    """Ragged ground-truth depth maps of a split, packed once into device memory."""
+
+    def __init__(self, gt_depths, device, crop=True):
+        maps = [np.ascontiguousarray(np.asarray(g, dtype=np.float32)) for g in gt_depths]
+        assert all(m.ndim == 2 for m in maps)
+        desc = np.zeros((len(maps), EVAL_DESC), dtype=np.int32)
+        off = 0
+        for i, m in enumerate(maps):
+            gh, gw = m.shape
+            win = garg_window(gh, gw) if crop else (0, gh, 0, gw)
+            desc[i] = (off & 0xFFFFFFFF if off < 2 ** 31 else (off & 0xFFFFFFFF) - 2 ** 32, off >> 32, gh, gw) + win
+            off += m.size
+        flat = np.concatenate([m.ravel() for m in maps]) if maps else np.zeros(0, np.float32)
+        self.shapes = [m.shape for m in maps]
+        self.buffer = torch.from_numpy(flat).to(device)
+        self.desc = torch.from_numpy(desc).to(device)
+
+    def __len__(self):
+        return len(self.shapes)
+
+
+def depth_metrics(pred, gts, indices, min_depth=1e-3, max_depth=80.0, clamp=(1e-3, 80.0), pred_is_disp=False,
+                  median="torch", median_scaling=True, scale_factor=1.0, backend=None):
+    """Scores pred[i] ([n,1,h,w] or [n,h,w]) against gts[indices[i]]; returns a [n, 12] device tensor
+    (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, ratio, median_gt, median_pred, count, 0)."""
+    backend = backend or ops.default_backend()
+    pred = pred.detach()
+    if pred.dim() == 4:
+        assert pred.shape[1] == 1
+        pred = pred[:, 0]
+    pred = pred.contiguous().float()
+    backend._check(pred, gts.buffer)
+    n, h, w = pred.shape
+    idx = torch.as_tensor(indices, dtype=torch.long, device=gts.desc.device).view(-1)
+    assert idx.numel() == n
+    desc = gts.desc.index_select(0, idx).contiguous()
+    out = torch.empty(n, EVAL_OUT, device=pred.device, dtype=torch.float32)
+    flags = (EVAL_PRED_IS_DISP if pred_is_disp else 0) | (EVAL_MEDIAN_MIDPOINT if median == "numpy" else 0) | \
+            (0 if median_scaling else EVAL_NO_MEDIAN_SCALING)
+    backend.run("bbd_depth_metrics", pred, ptr(pred), ptr(gts.buffer), ptr(desc), ptr(out), n, h, w,
+                float(min_depth), float(max_depth), float(clamp[0]), float(clamp[1]), float(scale_factor), flags)
+    return out

@@ -335,30 +335,49 @@ class Trainer:
         return losses
 
     # ------------------------------------------------------------------ validation metrics (trainer.py:572-617)
-    def compute_depth_losses(self, outputs, losses, gt_depth, accumulate=False):
-        """KITTI depth metrics of `outputs[("depth",0,0)]` (batch 1) against a ground-truth depth map,
-        entirely on the device: bilinear resize to the GT size, clamp to [1e-3, 80], Garg crop,
-        median scaling, the seven metrics of `layers.compute_depth_errors`.  `gt_depth` is the
-        [h,w] array/tensor the reference keeps in `self.gt_depths[idx]`."""
-        import torch.nn.functional as F
-        min_depth, max_depth = 1e-3, 80
-        gt = torch.as_tensor(gt_depth, dtype=torch.float32, device=self.device)
-        gh, gw = gt.shape[:2]
-        pred = torch.clamp(F.interpolate(outputs["depth", 0, 0], [gh, gw], mode="bilinear", align_corners=False),
-                           1e-3, 80).detach().squeeze()
-        mask = (gt > min_depth) & (gt < max_depth)
-        import numpy as np
-        crop = np.array([0.40810811 * gh, 0.99189189 * gh, 0.03594771 * gw, 0.96405229 * gw]).astype(np.int32)
-        crop_mask = torch.zeros_like(mask)
-        crop_mask[crop[0]:crop[1], crop[2]:crop[3]] = True
-        mask = mask & crop_mask
-        pred = pred * (torch.median(gt[mask]) / torch.median(pred[mask]))
-        pred = torch.clamp(pred, min=min_depth, max=max_depth)
-        errors = compute_depth_errors(gt[mask], pred[mask])
-        for name, val in zip(self.depth_metric_names, errors):
-            v = float(val)
-            losses[name] = losses.get(name, 0.0) + v if accumulate else v
+    def set_ground_truth(self, gt_depths):
+        """Packs a split's ground-truth depth maps (the reference's `self.gt_depths`, loaded from
+        `splits/<split>/gt_depths.npz`, trainer.py:138-143) into device memory once."""
+        from .evaluation import GroundTruthSet
+        self.gt_depths = gt_depths if isinstance(gt_depths, GroundTruthSet) else GroundTruthSet(gt_depths, self.device)
+        return self.gt_depths
+
+    def compute_depth_losses(self, outputs, losses, idx, SYNS=False, accumulate=False):
+        """KITTI depth metrics of `outputs[("depth",0,0)]` against ground-truth map(s) `idx` of
+        `self.gt_depths` (trainer.py:572-617, KITTI branch), in ONE kernel launch on the device
+        (`bbd_depth_metrics`): bilinear resize to the GT size, clamp to [1e-3, 80], Garg crop, median
+        scaling, the seven metrics of `layers.compute_depth_errors`.  `idx` is an int (the reference's
+        batch-1 validation loop) or one index per row of a batched prediction; metrics of a batch are
+        summed, as `accumulate=True` does over the reference's loop.  Values stay on the device
+        (0-dim tensors) so the validation loop never synchronises per image."""
+        if SYNS:
+            raise NotImplementedError("SYNS edge metrics (cv2/scipy host code, trainer.py:577-593) are out of scope")
+        from .evaluation import depth_metrics, GroundTruthSet
+        if not isinstance(self.gt_depths, GroundTruthSet):
+            self.set_ground_truth(self.gt_depths)
+        indices = [int(idx)] if not hasattr(idx, "__len__") else [int(i) for i in idx]
+        rows = depth_metrics(outputs["depth", 0, 0], self.gt_depths, indices, backend=self._backend())
+        sums = rows[:, :7].sum(0)
+        for k, name in enumerate(self.depth_metric_names):
+            losses[name] = losses[name] + sums[k] if accumulate and name in losses else sums[k]
         return losses
+
+    def val(self, val_loader, is_init=None):
+        """Validation pass (trainer.py:623-665): mean of the seven metrics over the loader's images;
+        keeps `self.best` (abs_rel).  One host synchronisation, at the end."""
+        self.set_eval()
+        losses, images = {}, 0
+        with torch.no_grad():
+            for batch_idx, inputs in enumerate(val_loader):
+                outputs, _ = self.process_batch(inputs, batch_idx, is_train=False)
+                n = outputs["depth", 0, 0].shape[0]
+                self.compute_depth_losses(outputs, losses, list(range(images, images + n)), accumulate=True)
+                images += n
+        result = {name: float(losses[name]) / max(images, 1) for name in self.depth_metric_names}
+        if result["de/abs_rel"] < getattr(self, "best", float("inf")):
+            self.best = result["de/abs_rel"]
+        self.set_train()
+        return result
 
     def argmin_masks(self, outputs, scale_index=0):
         """The reference's `self.ident` bookkeeping (trainer.py:1002-1003 etc.): per sample, where a

@@ -162,6 +162,28 @@ int bbd_project3d_fwd(const float* points, const float* K, const float* T, float
                       int n, int H, int W, double eps, void* stream);
 int bbd_ssim_fwd(const float* x, const float* y, float* out, int n, int H, int W, void* stream);
 
+/* Validation metrics on the device: one workgroup per image.
+ *   flags 0                       : Trainer.compute_depth_losses, KITTI branch (trainer.py:594-617):
+ *                                   pred = depth [n,h,w]; F.interpolate(bilinear, align_corners=False)
+ *                                   to the ground-truth size, clamp to [clamp_lo, clamp_hi], mask
+ *                                   (min_depth < gt < max_depth inside the window), torch.median
+ *                                   scaling (lower median), clamp, layers.compute_depth_errors.
+ *   BBD_EVAL_PRED_IS_DISP         : evaluate_depth.py:244-297: pred = disparity, cv2.resize (linear)
+ *                                   then 1/disp, times scale_factor (opt.pred_depth_scale_factor).
+ *   BBD_EVAL_MEDIAN_MIDPOINT      : np.median (mean of the two middle values) instead of torch.median.
+ *   BBD_EVAL_NO_MEDIAN_SCALING    : opt.disable_median_scaling (stereo evaluation).
+ * gt is a ragged buffer; desc[i] = {offset_lo, offset_hi (elements), GH, GW, r0, r1, c0, c1} with
+ * [r0,r1) x [c0,c1) the crop window (Garg crop, trainer.py:603-606; whole image = 0,GH,0,GW).
+ * out[i] = {abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3, ratio, median_gt, median_pred, count, 0}. */
+#define BBD_EVAL_DESC 8
+#define BBD_EVAL_OUT 12
+#define BBD_EVAL_PRED_IS_DISP 1
+#define BBD_EVAL_MEDIAN_MIDPOINT 2
+#define BBD_EVAL_NO_MEDIAN_SCALING 4
+int bbd_depth_metrics(const float* pred, const float* gt, const int32_t* desc, float* out, int n, int h,
+                      int w, double min_depth, double max_depth, double clamp_lo, double clamp_hi,
+                      double scale_factor, int flags, void* stream);
+
 /* Device self-test: the kernels replace hipcc's IEEE division sequence by a cheaper one that is
  * exact for moderate exponents (bbd_math.h).  Runs blocks*256*iters random operand tuples through
  * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */
