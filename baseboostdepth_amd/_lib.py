@@ -45,8 +45,13 @@ SIGNATURES = {
     "bbd_project3d_fwd": [_p, _p, _p, _p, _i, _i, _i, _d, _p],
     "bbd_ssim_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_depth_metrics": [_p, _p, _p, _p, _i, _i, _i, _d, _d, _d, _d, _d, _i, _p],
+    "bbd_resample_h_u8": [_p, _p, _p, _i, _i, _p, _p, _i, _p],
+    "bbd_resample_v_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p],
+    "bbd_color_jitter_u8": [_p, _p, _p, _i, _i, _i, _p, _p],
+    "bbd_u8_to_float_chw": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
 }
+RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4
 EVAL_DESC, EVAL_OUT = 8, 12
 EVAL_PRED_IS_DISP, EVAL_MEDIAN_MIDPOINT, EVAL_NO_MEDIAN_SCALING = 1, 2, 4
 

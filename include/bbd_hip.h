@@ -184,6 +184,40 @@ int bbd_depth_metrics(const float* pred, const float* gt, const int32_t* desc, f
                       int w, double min_depth, double max_depth, double clamp_lo, double clamp_hi,
                       double scale_factor, int flags, void* stream);
 
+/* ---- Loader image pipeline: replaces the per-item Pillow/torchvision work of
+ * datasets/mono_dataset.py:186-205 (Resize(LANCZOS) chain, ColorJitter, ToTensor) and the stacking of
+ * Trainer.custom_collate (trainer.py:867-886).  Images are uint8 HWC (as PIL decodes them) inside one
+ * device buffer; every job addresses its source and destination by offset, so results land directly
+ * in the rows of the collated batch tensors.  Bit-exact against Pillow (bbd_image_math.h).
+ *
+ * Resample job (int32[BBD_RESAMPLE_JOB]): src byte offset lo,hi | dst byte offset lo,hi | in_h, in_w,
+ * out_size, ksize | coef_off, bounds_off (int32 elements into coef / bounds), flags, pad.
+ *   bbd_resample_h_u8: [in_h,in_w,C] -> [in_h,out_size,C]   (flags & BBD_RESAMPLE_FLIP mirrors the source
+ *                      columns = PIL transpose(FLIP_LEFT_RIGHT) before the resize, kitti_dataset.py:58-59)
+ *   bbd_resample_v_u8: [in_h,in_w,C] -> [out_size,in_w,C]
+ * coef[out][ksize] are Pillow's 22-bit fixed-point filter taps, bounds[out] = (first source index, count);
+ * the host builds them (baseboostdepth_amd/imageops.py:resample_table, Resample.c precompute_coeffs). */
+#define BBD_RESAMPLE_JOB 12
+#define BBD_RESAMPLE_FLIP 1
+int bbd_resample_h_u8(const uint8_t* src, uint8_t* dst, const int32_t* jobs, int n_jobs, int max_in_h,
+                      const int32_t* coef, const int32_t* bounds, int channels, void* stream);
+int bbd_resample_v_u8(const uint8_t* src, uint8_t* dst, const int32_t* jobs, int n_jobs, int max_out_h,
+                      int max_row_bytes, const int32_t* coef, const int32_t* bounds, int channels, void* stream);
+
+/* torchvision ColorJitter (functional_pil, order and factors drawn by the host per image) followed by
+ * ToTensor, for n_jobs uint8 [H,W,3] images -> fp32 [3,H,W] at dst + offset (floats).
+ * Jitter job (int32[BBD_JITTER_JOB]): src byte offset lo,hi | dst float offset lo,hi | op[4] in
+ * application order (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none) | param[4]: float bits of
+ * the factor, or for hue the uint8 offset int(hue_factor*255) & 255.  lsum_scratch: uint32[n_jobs]. */
+#define BBD_JITTER_JOB 12
+int bbd_color_jitter_u8(const uint8_t* src, float* dst, const int32_t* jobs, int n_jobs, int H, int W,
+                        uint32_t* lsum_scratch, void* stream);
+
+/* ToTensor only. Convert job (int32[BBD_CONVERT_JOB]): src byte offset lo,hi | dst float offset lo,hi. */
+#define BBD_CONVERT_JOB 4
+int bbd_u8_to_float_chw(const uint8_t* src, float* dst, const int32_t* jobs, int n_jobs, int H, int W,
+                        void* stream);
+
 /* Device self-test: the kernels replace hipcc's IEEE division sequence by a cheaper one that is
  * exact for moderate exponents (bbd_math.h).  Runs blocks*256*iters random operand tuples through
  * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */

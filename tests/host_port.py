@@ -10,15 +10,17 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "host_port", "bbd_host_port.cpp")
+SRC_IMAGE = os.path.join(HERE, "host_port", "bbd_image_port.cpp")
 LIB = os.path.join(HERE, "host_port", "libbbd_host_port.so")
-DEPS = [SRC, os.path.join(HERE, "..", "baseboostdepth_amd", "csrc", "bbd_math.h"),
+DEPS = [SRC, SRC_IMAGE, os.path.join(HERE, "..", "baseboostdepth_amd", "csrc", "bbd_math.h"),
+        os.path.join(HERE, "..", "baseboostdepth_amd", "csrc", "bbd_image_math.h"),
         os.path.join(HERE, "..", "include", "bbd_hip.h")]
 
 
 def build():
     if os.path.isfile(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS):
         return LIB
-    cmd = ["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-std=c++17", "-o", LIB, SRC]
+    cmd = ["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC", "-std=c++17", "-o", LIB, SRC, SRC_IMAGE]
     subprocess.run(cmd, check=True)
     return LIB
 

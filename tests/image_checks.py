@@ -1,0 +1,57 @@
+"""Backend-agnostic checks of the loader image pipeline against Pillow (used by the CPU host-port
+tier and by the GPU tier)."""
+import numpy as np
+import torch
+
+from oracle import loader_ref
+from baseboostdepth_amd import imageops
+
+RESIZE_CASES = [(375, 1242, 192, 640), (370, 1226, 192, 640), (376, 1241, 192, 640),
+                (100, 300, 192, 640), (192, 640, 192, 640), (61, 77, 32, 64)]
+
+
+def check_resize(pipe, h, w, oh, ow):
+    rng = np.random.default_rng(h * 7 + w)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(3)]
+    src = torch.from_numpy(np.concatenate([i.ravel() for i in imgs])).to(pipe.device)
+    jobs = [(k * h * w * 3, h, w, flip) for k, flip in enumerate([False, True, False])]
+    got = pipe.resize(src, jobs, oh, ow).cpu().numpy()
+    for k, flip in enumerate([False, True, False]):
+        assert np.array_equal(got[k], loader_ref.resize_lanczos(imgs[k], oh, ow, flip)), (k, flip)
+
+
+def check_ragged_and_pyramid(pipe):
+    rng = np.random.default_rng(5)
+    shapes = [(375, 1242), (370, 1226), (374, 1238), (192, 640)]
+    imgs = [rng.integers(0, 256, s + (3,), dtype=np.uint8) for s in shapes]
+    offs = np.cumsum([0] + [i.size for i in imgs])
+    src = torch.from_numpy(np.concatenate([i.ravel() for i in imgs])).to(pipe.device)
+    lvl0 = pipe.resize(src, [(int(offs[k]), s[0], s[1], k == 1) for k, s in enumerate(shapes)], 192, 640)
+    levels = [lvl0]
+    for _ in range(3):
+        levels.append(pipe.halve(levels[-1]))
+    for k in range(len(imgs)):
+        want = loader_ref.pyramid(loader_ref.resize_lanczos(imgs[k], 192, 640, k == 1), 4)
+        for s in range(4):
+            assert np.array_equal(levels[s][k].cpu().numpy(), want[s]), (k, s)
+
+
+def check_color_jitter(pipe, H=48, W=160, seed=11):
+    rng = np.random.default_rng(seed)
+    imgs = rng.integers(0, 256, (6, H, W, 3), dtype=np.uint8)
+    imgs[5] = (np.linspace(0, 255, W)[None, :, None] * np.ones((H, 1, 3))).astype(np.uint8)   # smooth ramp
+    seqs = []
+    for k in range(6):
+        order = rng.permutation(4)
+        fac = {0: rng.uniform(0.8, 1.2), 1: rng.uniform(0.8, 1.2), 2: rng.uniform(0.8, 1.2), 3: rng.uniform(-0.1, 0.1)}
+        seqs.append([(int(o), float(fac[int(o)])) for o in order])
+    seqs[4] = seqs[4][:2]                                        # shorter sequence (ops disabled)
+    dev_imgs = torch.from_numpy(imgs).to(pipe.device)
+    dst = torch.zeros(8, 3, H, W, device=pipe.device)
+    pipe.jitter_to_float(dev_imgs, list(range(6)), seqs, dst, [7, 0, 3, 2, 5, 6])
+    pipe.to_float(dev_imgs, [1, 2], dst, [1, 4])
+    dst = dst.cpu()
+    for k, row in enumerate([7, 0, 3, 2, 5, 6]):
+        want = loader_ref.to_tensor(loader_ref.color_jitter(imgs[k], seqs[k]))
+        assert torch.equal(dst[row], want), (k, seqs[k])
+    assert torch.equal(dst[1], loader_ref.to_tensor(imgs[1])) and torch.equal(dst[4], loader_ref.to_tensor(imgs[2]))
