@@ -1,0 +1,297 @@
+"""KITTI loader in index-table form.
+
+Reference: `datasets/mono_dataset.py` (`MonoDataset.__getitem__`, `preprocess`), `datasets/
+kitti_dataset.py` (`KITTIRAWDataset`), `Trainer.custom_collate` (trainer.py:867-886) and the loaders
+built in trainer.py:120-131, :214-220.  Same class names, constructor arguments, split-file format
+(`folder frame side [kt baseline]`), frame-set curriculum and random-draw order.
+
+What is different by design: `__getitem__` does only host work - frame-set selection, the random
+draws, JPEG decode - and returns a *recipe* (decoded uint8 frames + parameters).  Resize(LANCZOS),
+the scale pyramid, ColorJitter, ToTensor and the stacking of `custom_collate` run on the GPU for the
+whole batch (`DeviceCollate` -> imageops -> csrc/bbd_image.hip), bit-exact against Pillow, writing
+directly into the rows of the collated tensors.  `DeviceCollate(batch)` returns exactly the dict
+`Trainer.custom_collate` returns for the reference's per-item dicts.
+"""
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+from PIL import Image, ImageFile
+
+from . import imageops
+
+ImageFile.LOAD_TRUNCATED_IMAGES = True          # mono_dataset.py:3
+STEREO = "s"
+STEREO_ID = -50                                 # how 's' travels inside the "frames" tensor (mono_dataset.py:141-142)
+
+
+def readlines(filename):
+    """utils.py:readlines."""
+    with open(filename, "r") as f:
+        return f.read().splitlines()
+
+
+def pil_loader(path):
+    """mono_dataset.py:15-18; returns the decoded RGB frame as uint8 [h,w,3]."""
+    with open(path, "rb") as f:
+        with Image.open(f) as img:
+            return np.asarray(img.convert("RGB"))
+
+
+def draw_color_jitter(gen, brightness, contrast, saturation, hue):
+    """One call of torchvision 0.9 `ColorJitter.forward`: a random permutation of the four ops, each
+    factor drawn when its op comes up (`torch.tensor(1.0).uniform_(lo, hi)`).  Returns [(op, factor)]
+    in application order."""
+    ranges = {imageops.BRIGHTNESS: brightness, imageops.CONTRAST: contrast, imageops.SATURATION: saturation,
+              imageops.HUE: hue}
+    seq = []
+    for fn_id in torch.randperm(4, generator=gen).tolist():
+        lo, hi = ranges[fn_id]
+        seq.append((fn_id, torch.tensor(1.0).uniform_(lo, hi, generator=gen).item()))
+    return seq
+
+
+class MonoDataset:
+    """Same constructor as the reference (mono_dataset.py:22-36)."""
+
+    def __init__(self, filenames, epoch, height, width, kt_path=None, syns_path=None, rand=False, scales=[0],
+                 trimin=False, kt=False, is_train=False, img_ext=".jpg", naive_mix=False, seed=0):
+        self.filenames, self.epoch, self.height, self.width = filenames, epoch, height, width
+        self.kt_path, self.syns_path, self.rand, self.scales = kt_path, syns_path, rand, list(scales)
+        self.trimin, self.kt, self.is_train, self.img_ext, self.naive_mix = trimin, kt, is_train, img_ext, naive_mix
+        self.seed = seed
+        self.loader = pil_loader
+        self.brightness, self.contrast, self.saturation, self.hue = (0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1)
+        # curriculum (mono_dataset.py:58-63)
+        if self.epoch < 10:
+            self.to_use = 2 if self.trimin else 1
+            self.cutt_off = 0.1 + (0.04 * self.epoch)
+        else:
+            self.to_use = 7 if self.trimin else 5
+            self.cutt_off = (0.15 * self.epoch) - 0.9
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def _rngs(self, index):
+        """Per-item generators (the reference uses the worker-global `random` / torch RNG; a private
+        stream per (seed, epoch, index) keeps the draws reproducible under any thread schedule)."""
+        s = (self.seed * 1000003 + self.epoch) * 1000003 + index
+        return random.Random(s), torch.Generator().manual_seed(s & 0x7FFFFFFFFFFFFFFF)
+
+    def select_frames(self, index, rng, exists=os.path.isfile):
+        """Frame-set selection of `__getitem__` (mono_dataset.py:77-106) - host integers only.
+        Returns (do_color_aug, do_flip, folder, frame_index, side, frame_idxs)."""
+        do_color_aug = self.is_train and rng.random() > 0.5
+        do_flip = self.is_train and rng.random() > 0.5
+        line = self.filenames[index].split()
+        baseline = line[-1] if (self.rand and self.is_train) else 0
+        folder, frame_index, side = self.index_to_folder_and_frame_idx_kt(index)
+        if self.is_train:
+            if self.rand:
+                frame_idxs = sorted([i for i in range(-self.to_use, self.to_use + 1)
+                                     if (abs(i) * float(baseline)) <= self.cutt_off], key=abs)
+                if max(frame_idxs) < 3:
+                    frame_idxs.append(STEREO)
+            else:
+                frame_idxs = [0, 1, -1, STEREO]
+            mini = rng.randint(1, 6) if rng.random() > 0.7 else 0
+            pos = [i for i in range(1, 8 - mini) if exists(self.get_image_path_kt(self.kt_path, frame_index + i, side, folder))]
+            neg = [abs(i) for i in range(-1, -8 + mini, -1)
+                   if exists(self.get_image_path_kt(self.kt_path, frame_index + i, side, folder))]
+            if not pos or not neg:
+                raise ValueError("no neighbouring frame on disk for %r (the reference's max([]) raises too)"
+                                 % self.filenames[index])
+            limit = min(max(pos), max(neg))
+        else:
+            frame_idxs = [0]
+            limit = 7
+        frame_idxs = [x for x in frame_idxs if x != STEREO and abs(x) <= abs(limit)]
+        if max(frame_idxs) < 3:
+            frame_idxs.append(STEREO)
+        return do_color_aug, do_flip, folder, frame_index, side, frame_idxs
+
+    def __getitem__(self, index):
+        rng, gen = self._rngs(index)
+        do_color_aug, do_flip, folder, frame_index, side, frame_idxs = self.select_frames(index, rng)
+        item = {"frame_idxs": frame_idxs, "flip": bool(do_flip), "images": {}, "jitter": {}, "index": index}
+        if self.is_train:
+            other_side = {"r": "l", "l": "r"}[side]
+            for i in frame_idxs:
+                if i == STEREO:
+                    path = self.get_image_path_kt(self.kt_path, frame_index, other_side, folder)
+                else:
+                    path = self.get_image_path_kt(self.kt_path, frame_index + i, side, folder)
+                item["images"][i] = self.loader(path)
+            item["K"], item["inv_K"] = self.load_intrinsic_kt(0)
+        else:
+            item["images"][0] = self.loader(self.get_image_path_kt(self.kt_path, frame_index, side, folder))
+        if do_color_aug:
+            # `preprocess` (mono_dataset.py:193-205) calls the ColorJitter module once per full-resolution
+            # frame (result deleted at :128-131) and then once per scale-0 frame: keep that draw order
+            temporal = [f for f in item["images"] if f != STEREO]
+            for f in temporal:
+                draw_color_jitter(gen, self.brightness, self.contrast, self.saturation, self.hue)
+            for f in temporal:
+                item["jitter"][f] = draw_color_jitter(gen, self.brightness, self.contrast, self.saturation, self.hue)
+        stereo_T = np.eye(4, dtype=np.float32)
+        baseline_sign = -1 if do_flip else 1
+        side_sign = -1 if side in ["l"] else 1
+        stereo_T[0, 3] = side_sign * baseline_sign * 0.1
+        item["stereo_T"] = stereo_T
+        item["frames"] = torch.tensor([STEREO_ID if f == STEREO else f for f in frame_idxs])
+        item["cutt_off"] = torch.tensor(self.cutt_off)
+        item["to_use"] = torch.tensor(self.to_use)
+        return item
+
+
+class KITTIDataset(MonoDataset):
+    def load_intrinsic_kt(self, scale):
+        """kitti_dataset.py:14-23."""
+        K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+        K[0, :] *= self.width // (2 ** scale)
+        K[1, :] *= self.height // (2 ** scale)
+        return K, np.linalg.pinv(K)
+
+    def index_to_folder_and_frame_idx_kt(self, index):
+        """kitti_dataset.py:25-40."""
+        line = self.filenames[index].split()
+        folder = line[0]
+        frame_index = int(line[1]) if len(line) >= 3 else 0
+        side = line[2] if len(line) >= 3 else None
+        return folder, frame_index, side
+
+
+class KITTIRAWDataset(KITTIDataset):
+    def get_image_path_kt(self, data_path, frame_index, side, folder):
+        """kitti_dataset.py:49-54 (always `.jpg`, like the reference)."""
+        side_map = {"l": 2, "r": 3}
+        return os.path.join(data_path, folder, "image_0{}/data".format(side_map[side]),
+                            "{:010d}{}".format(frame_index, ".jpg"))
+
+
+class DeviceCollate:
+    """Recipes of one batch -> the dict `Trainer.custom_collate` returns, built on the device.
+
+    Every decoded frame of the batch is packed into one pinned uint8 buffer and uploaded with a single
+    copy; job tables then route (item, frame) -> row of `("color", f, 0)` / `("color_aug", f, 0)` /
+    `("color", 0, s)`.  Rows follow the reference's stacking order: the items that have the key, in batch
+    order."""
+
+    def __init__(self, height, width, scales, device, backend=None):
+        self.height, self.width, self.scales = height, width, list(scales)
+        self.device = torch.device(device)
+        self.pipe = imageops.ImagePipeline(self.device, backend)
+
+    def __call__(self, batch):
+        H, W, dev = self.height, self.width, self.device
+        train = "K" in batch[0]
+        # ---- host: which keys exist, and which row each (item, frame) owns (trainer.py:867-886)
+        max_frames = [int(torch.max(item["frames"]).item()) for item in batch]
+        out = {}
+        if train:
+            out["ordering"] = [[0, STEREO] if m == 0 else [0, m, -m] for m in max_frames]
+            top = max(max_frames)
+            if top == 0:
+                frame_ids = [0, STEREO]
+            else:
+                frame_ids = list(range(-top, top + 1))
+                if any(m in (0, 1, 2) for m in max_frames):
+                    frame_ids.append(STEREO)
+        else:
+            frame_ids = [0]
+        # ---- one upload of all decoded frames
+        entries = [(b, f) for b, item in enumerate(batch) for f in item["images"] if f in frame_ids]
+        sizes = [batch[b]["images"][f].size for b, f in entries]
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        staging = torch.empty(int(offsets[-1]), dtype=torch.uint8)
+        if dev.type == "cuda":
+            staging = staging.pin_memory()
+        flat = staging.numpy()
+        for (b, f), off in zip(entries, offsets):
+            img = batch[b]["images"][f]
+            flat[off:off + img.size] = img.reshape(-1)
+        src = staging.to(dev, non_blocking=True)
+        jobs = [(int(off), batch[b]["images"][f].shape[0], batch[b]["images"][f].shape[1], batch[b]["flip"])
+                for (b, f), off in zip(entries, offsets)]
+        level0 = self.pipe.resize(src, jobs, H, W)                       # uint8 [n_img, H, W, 3]
+        where = {e: i for i, e in enumerate(entries)}
+        # ---- ("color", f, 0) and ("color_aug", f, 0)
+        for f in frame_ids:
+            owners = [b for b, item in enumerate(batch) if f in item["images"]]
+            if not owners:
+                continue
+            picks = [where[(b, f)] for b in owners]
+            color = torch.empty(len(owners), 3, H, W, device=dev)
+            self.pipe.to_float(level0, picks, color, list(range(len(owners))))
+            out[("color", f, 0)] = color
+            if f == STEREO:
+                continue
+            aug = torch.empty(len(owners), 3, H, W, device=dev)
+            jit = [(r, b) for r, b in enumerate(owners) if f in batch[b]["jitter"]]
+            plain = [(r, b) for r, b in enumerate(owners) if f not in batch[b]["jitter"]]
+            self.pipe.jitter_to_float(level0, [where[(b, f)] for _, b in jit], [batch[b]["jitter"][f] for _, b in jit],
+                                      aug, [r for r, _ in jit])
+            self.pipe.to_float(level0, [where[(b, f)] for _, b in plain], aug, [r for r, _ in plain])
+            out[("color_aug", f, 0)] = aug
+        # ---- pyramid of the target frame: ("color", 0, s), s >= 1, chained like Resize[s](scale s-1)
+        if max(self.scales) > 0:
+            owners = [b for b, item in enumerate(batch) if 0 in item["images"]]
+            idx = torch.tensor([where[(b, 0)] for b in owners], device=dev)
+            level = level0.index_select(0, idx)
+            for s in range(1, max(self.scales) + 1):
+                level = self.pipe.halve(level)
+                if s in self.scales:
+                    t = torch.empty(len(owners), 3, H >> s, W >> s, device=dev)
+                    self.pipe.to_float(level, list(range(len(owners))), t, list(range(len(owners))))
+                    out[("color", 0, s)] = t
+        if train:
+            out[("K", 0)] = torch.from_numpy(np.stack([item["K"] for item in batch])).to(dev)
+            out[("inv_K", 0)] = torch.from_numpy(np.stack([item["inv_K"] for item in batch])).to(dev)
+            out["stereo_T"] = torch.from_numpy(np.stack([item["stereo_T"] for item in batch])).to(dev)
+            out["frames"] = frame_ids
+            out["cutt"] = batch[0]["cutt_off"]
+            out["to_use"] = batch[0]["to_use"]
+        return out
+
+
+class DeviceLoader:
+    """Iterates a dataset in batches: decode on a thread pool (Pillow releases the GIL), prefetching
+    `prefetch` batches ahead; collation on the device.  Stands in for `DataLoader(dataset, batch_size,
+    shuffle, collate_fn=custom_collate, num_workers, drop_last)` of trainer.py:218-220."""
+
+    def __init__(self, dataset, batch_size, collate, shuffle=True, drop_last=True, num_workers=8, prefetch=2, seed=0):
+        self.dataset, self.batch_size, self.collate = dataset, batch_size, collate
+        self.shuffle, self.drop_last, self.num_workers, self.prefetch, self.seed = shuffle, drop_last, num_workers, prefetch, seed
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _batches(self):
+        order = list(range(len(self.dataset)))
+        if self.shuffle:
+            random.Random(self.seed * 7919 + self.dataset.epoch).shuffle(order)
+        for i in range(0, len(order), self.batch_size):
+            chunk = order[i:i + self.batch_size]
+            if len(chunk) == self.batch_size or not self.drop_last:
+                yield chunk
+
+    def __iter__(self):
+        with ThreadPoolExecutor(max_workers=max(1, self.num_workers)) as pool:
+            pending = []
+            batches = self._batches()
+
+            def submit():
+                chunk = next(batches, None)
+                if chunk is not None:
+                    pending.append([pool.submit(self.dataset.__getitem__, i) for i in chunk])
+
+            for _ in range(self.prefetch + 1):
+                submit()
+            while pending:
+                futures = pending.pop(0)
+                submit()
+                yield self.collate([f.result() for f in futures])

@@ -55,3 +55,58 @@ def check_color_jitter(pipe, H=48, W=160, seed=11):
         want = loader_ref.to_tensor(loader_ref.color_jitter(imgs[k], seqs[k]))
         assert torch.equal(dst[row], want), (k, seqs[k])
     assert torch.equal(dst[1], loader_ref.to_tensor(imgs[1])) and torch.equal(dst[4], loader_ref.to_tensor(imgs[2]))
+
+
+# ---------------------------------------------------------------------------- loader end to end
+def make_kitti_tree(root, drives=(("2011_09_26/2011_09_26_drive_0001_sync", 375, 1242),
+                                  ("2011_09_30/2011_09_30_drive_0020_sync", 370, 1226)), frames=24, seed=0):
+    """A small KITTI-raw-shaped directory of synthetic JPEGs (both cameras) + split lines with baselines."""
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    lines = []
+    for folder, h, w in drives:
+        base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 40, 3), dtype=np.uint8)
+        big = np.array(Image.fromarray(base).resize((w + 300, h), Image.BICUBIC))
+        for cam, dx in (("image_02", 0), ("image_03", 9)):
+            d = os.path.join(root, folder, cam, "data")
+            os.makedirs(d, exist_ok=True)
+            for t in range(frames):
+                img = big[:, 5 * t + dx: 5 * t + dx + w]
+                Image.fromarray(img).save(os.path.join(d, "%010d.jpg" % t), quality=92)
+        for t in range(8, frames - 8):
+            for side in "lr":
+                lines.append("%s %d %s kt %.6f" % (folder, t, side, float(rng.uniform(0.02, 0.6))))
+    return lines
+
+
+def check_loader_batches(tmpdir, device, backend, epoch, trimin, scales, batch_size=4, n_batches=2, H=96, W=320):
+    """DeviceCollate(recipes) == Trainer.custom_collate([reference-shaped items built with Pillow])."""
+    import types
+    from baseboostdepth_amd import datasets
+    from baseboostdepth_amd.trainer import Trainer
+    lines = make_kitti_tree(str(tmpdir))
+    ds = datasets.KITTIRAWDataset(lines, epoch, H, W, kt_path=str(tmpdir), rand=True, is_train=True, scales=scales,
+                                  kt=True, naive_mix=True, trimin=trimin, seed=3)
+    collate = datasets.DeviceCollate(H, W, scales, device, backend)
+    loader = datasets.DeviceLoader(ds, batch_size, collate, shuffle=True, drop_last=True, num_workers=4, seed=1)
+    ref_tr = Trainer.__new__(Trainer)
+    ref_tr.opt = types.SimpleNamespace(scales=list(scales))
+    seen = 0
+    chunks = list(loader._batches())
+    for chunk, got in zip(chunks, loader):
+        recipes = [ds[i] for i in chunk]                       # per-item RNG streams: same draws again
+        want = ref_tr.custom_collate([loader_ref.preprocess_item(r, scales, H, W) for r in recipes])
+        assert set(got) == set(want), (sorted(map(str, got)), sorted(map(str, want)))
+        for k, v in want.items():
+            if torch.is_tensor(v) and v.dim() > 0:
+                assert torch.equal(got[k].cpu(), v), k
+            elif torch.is_tensor(v):
+                assert float(got[k]) == float(v), k
+            else:
+                assert got[k] == v, k
+        seen += 1
+        if seen == n_batches:
+            break
+    assert seen == n_batches
+    return got
