@@ -180,10 +180,28 @@ class DeviceCollate:
     `("color", 0, s)`.  Rows follow the reference's stacking order: the items that have the key, in batch
     order."""
 
-    def __init__(self, height, width, scales, device, backend=None):
+    def __init__(self, height, width, scales, device, backend=None, ring=3, pack_threads=8):
         self.height, self.width, self.scales = height, width, list(scales)
         self.device = torch.device(device)
         self.pipe = imageops.ImagePipeline(self.device, backend)
+        self._ring, self._next = [None] * ring, 0
+        self._pack_pool = ThreadPoolExecutor(max_workers=pack_threads)
+
+    def _staging(self, nbytes):
+        """Next pinned staging buffer of the ring (grow-only); waits until the upload that last used it
+        has finished.  Host tensors (CPU test tier) are plain memory and need no event."""
+        slot = self._next
+        self._next = (self._next + 1) % len(self._ring)
+        entry = self._ring[slot]
+        if entry is not None and entry[1] is not None:
+            entry[1].synchronize()
+        if entry is None or entry[0].numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 1, dtype=torch.uint8)
+            if self.device.type == "cuda":
+                buf = buf.pin_memory()
+            entry = (buf, torch.cuda.Event() if self.device.type == "cuda" else None)
+            self._ring[slot] = entry
+        return entry
 
     def __call__(self, batch):
         H, W, dev = self.height, self.width, self.device
@@ -202,18 +220,22 @@ class DeviceCollate:
                     frame_ids.append(STEREO)
         else:
             frame_ids = [0]
-        # ---- one upload of all decoded frames
+        # ---- one upload of all decoded frames (packed into a recycled pinned buffer by the pack pool)
         entries = [(b, f) for b, item in enumerate(batch) for f in item["images"] if f in frame_ids]
+        entries.sort(key=lambda e: e[1] != 0)           # target frames first: the pyramid reads rows [0, B)
         sizes = [batch[b]["images"][f].size for b, f in entries]
         offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        staging = torch.empty(int(offsets[-1]), dtype=torch.uint8)
-        if dev.type == "cuda":
-            staging = staging.pin_memory()
+        total = int(offsets[-1])
+        staging, done = self._staging(total)
         flat = staging.numpy()
-        for (b, f), off in zip(entries, offsets):
-            img = batch[b]["images"][f]
-            flat[off:off + img.size] = img.reshape(-1)
-        src = staging.to(dev, non_blocking=True)
+
+        def pack(k):
+            b, f = entries[k]
+            flat[offsets[k]:offsets[k + 1]] = batch[b]["images"][f].reshape(-1)
+        list(self._pack_pool.map(pack, range(len(entries))))
+        src = staging[:total].to(dev, non_blocking=True)
+        if done is not None:
+            done.record()
         jobs = [(int(off), batch[b]["images"][f].shape[0], batch[b]["images"][f].shape[1], batch[b]["flip"])
                 for (b, f), off in zip(entries, offsets)]
         level0 = self.pipe.resize(src, jobs, H, W)                       # uint8 [n_img, H, W, 3]
@@ -239,8 +261,8 @@ class DeviceCollate:
         # ---- pyramid of the target frame: ("color", 0, s), s >= 1, chained like Resize[s](scale s-1)
         if max(self.scales) > 0:
             owners = [b for b, item in enumerate(batch) if 0 in item["images"]]
-            idx = torch.tensor([where[(b, 0)] for b in owners], device=dev)
-            level = level0.index_select(0, idx)
+            assert [where[(b, 0)] for b in owners] == list(range(len(owners)))
+            level = level0[:len(owners)]
             for s in range(1, max(self.scales) + 1):
                 level = self.pipe.halve(level)
                 if s in self.scales:
@@ -248,12 +270,13 @@ class DeviceCollate:
                     self.pipe.to_float(level, list(range(len(owners))), t, list(range(len(owners))))
                     out[("color", 0, s)] = t
         if train:
-            out[("K", 0)] = torch.from_numpy(np.stack([item["K"] for item in batch])).to(dev)
-            out[("inv_K", 0)] = torch.from_numpy(np.stack([item["inv_K"] for item in batch])).to(dev)
-            out["stereo_T"] = torch.from_numpy(np.stack([item["stereo_T"] for item in batch])).to(dev)
+            cams = torch.from_numpy(np.stack([np.stack([item[k] for item in batch]) for k in ("K", "inv_K", "stereo_T")]))
+            cams = cams.to(dev)                                         # [3,B,4,4], one upload
+            out[("K", 0)], out[("inv_K", 0)], out["stereo_T"] = cams[0], cams[1], cams[2]
             out["frames"] = frame_ids
             out["cutt"] = batch[0]["cutt_off"]
             out["to_use"] = batch[0]["to_use"]
+        self.pipe.flush()
         return out
 
 

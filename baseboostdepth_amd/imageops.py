@@ -81,11 +81,13 @@ def hue_offset(hue_factor):
 
 
 class TableBank:
-    """Coefficient tables of all (in, out) size pairs a batch needs, concatenated for one upload."""
+    """Coefficient tables of every (in, out) size pair seen so far, concatenated; lives for the life of
+    the pipeline and is re-uploaded only when a new pair appears (a handful of KITTI image sizes)."""
 
     def __init__(self):
         self.coef, self.bounds, self.index = [], [], {}
         self.coef_len = self.bounds_len = 0
+        self.device_tensors = None
 
     def get(self, in_size, out_size):
         key = (in_size, out_size)
@@ -96,22 +98,57 @@ class TableBank:
             self.bounds.append(b.ravel())
             self.coef_len += c.size
             self.bounds_len += b.size
+            self.device_tensors = None
         return self.index[key]
 
     def tensors(self, device):
-        return (torch.from_numpy(np.concatenate(self.coef)).to(device),
-                torch.from_numpy(np.concatenate(self.bounds)).to(device))
+        if self.device_tensors is None:
+            self.device_tensors = (torch.from_numpy(np.concatenate(self.coef)).to(device),
+                                   torch.from_numpy(np.concatenate(self.bounds)).to(device))
+        return self.device_tensors
+
+
+class _Slot:
+    """Placeholder for an address that exists only after `flush()` uploaded the tables."""
+
+    def __init__(self, kind, offset=0):
+        self.kind, self.offset = kind, offset
 
 
 class ImagePipeline:
-    """Launches the image kernels on `device` (or through the CPU test port passed as `backend`)."""
+    """Plans the image kernels of a batch, then launches them: every call below only *records* work
+    (job tables go into one host arena); `flush()` uploads the arena with a single copy and enqueues the
+    launches in order on the current stream of `device` (or runs them through the CPU test port passed
+    as `backend`).  Output tensors are allocated at planning time and are valid after `flush()`."""
 
     def __init__(self, device, backend=None):
         self.device = torch.device(device)
         self.backend = backend or ops.default_backend()
+        self.bank = TableBank()
+        self._arena, self._arena_len, self._pending, self._keep = [], 0, [], []
 
-    def _dev(self, array):
-        return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
+    def _table(self, rows, width):
+        arr = np.ascontiguousarray(np.array(rows, np.int32).reshape(-1, width))
+        off = self._arena_len
+        self._arena.append(arr.ravel())
+        self._arena_len += arr.size
+        return _Slot("arena", off)
+
+    def _launch(self, name, anchor, *args):
+        self._pending.append((name, anchor, args))
+
+    def flush(self):
+        if not self._pending:
+            return
+        arena = torch.from_numpy(np.concatenate(self._arena)).to(self.device)
+        coef, bounds = self.bank.tensors(self.device) if self.bank.coef else (None, None)
+        base = {"arena": arena, "coef": coef, "bounds": bounds}
+        import ctypes
+        for name, anchor, args in self._pending:
+            real = [ctypes.c_void_p(base[a.kind].data_ptr() + 4 * a.offset) if isinstance(a, _Slot) else a for a in args]
+            self.backend.run(name, anchor, *real)
+        self._keep = [arena]                       # stays alive until the next flush (kernels are async)
+        self._arena, self._arena_len, self._pending = [], 0, []
 
     # ---------------------------------------------------------------- resize
     def resize(self, src, images, out_h, out_w):
@@ -120,16 +157,14 @@ class ImagePipeline:
         LANCZOS)` of each (horizontal pass first, like ImagingResample)."""
         n = len(images)
         out = torch.empty(n, out_h, out_w, 3, dtype=torch.uint8, device=self.device)
-        bank = TableBank()
         hjobs, vjobs, tmp_off = [], [], 0
-        direct = []                      # images that need no horizontal pass read the source directly
         for i, (off, h, w, flip) in enumerate(images):
             dst_off = i * out_h * out_w * 3
             need_h = (w != out_w) or flip
             need_v = h != out_h
             v_src = None
             if need_h:
-                co, bo, k = bank.get(w, out_w)
+                co, bo, k = self.bank.get(w, out_w)
                 h_dst = (tmp_off if need_v else dst_off)
                 hjobs.append((need_v, _split64(off) + _split64(h_dst) + (h, w, out_w, k, co, bo,
                                                                         RESAMPLE_FLIP if flip else 0, 0)))
@@ -139,28 +174,25 @@ class ImagePipeline:
             else:
                 v_src = ("src", off)
             if need_v:
-                co, bo, k = bank.get(h, out_h)
+                co, bo, k = self.bank.get(h, out_h)
                 vjobs.append((v_src[0], _split64(v_src[1]) + _split64(dst_off) + (h, out_w, out_h, k, co, bo, 0, 0)))
-            elif not need_h:
-                direct.append((off, dst_off, h * w * 3))
-        for off, dst_off, nbytes in direct:
-            out.view(-1)[dst_off:dst_off + nbytes] = src.view(-1)[off:off + nbytes]
-        if not hjobs and not vjobs:
-            return out
-        coef, bounds = bank.tensors(self.device)
+            elif not need_h:                       # same size, no flip: plain copy
+                nbytes = h * w * 3
+                out.view(-1)[dst_off:dst_off + nbytes] = src.view(-1)[off:off + nbytes]
         tmp = torch.empty(max(tmp_off, 1), dtype=torch.uint8, device=self.device)
+        self._keep.append(tmp)
         for to_tmp in (True, False):
             jobs = [j for t, j in hjobs if t == to_tmp]
             if jobs:
-                jt = self._dev(np.array(jobs, np.int32))
-                self.backend.run("bbd_resample_h_u8", out, ptr(src), ptr(tmp if to_tmp else out), ptr(jt), len(jobs),
-                                 max(j[4] for j in jobs), ptr(coef), ptr(bounds), 3)
+                self._launch("bbd_resample_h_u8", out, ptr(src), ptr(tmp if to_tmp else out),
+                             self._table(jobs, RESAMPLE_JOB), len(jobs), max(j[4] for j in jobs), _Slot("coef"),
+                             _Slot("bounds"), 3)
         for origin in ("tmp", "src"):
             jobs = [j for o, j in vjobs if o == origin]
             if jobs:
-                jt = self._dev(np.array(jobs, np.int32))
-                self.backend.run("bbd_resample_v_u8", out, ptr(tmp if origin == "tmp" else src), ptr(out), ptr(jt),
-                                 len(jobs), out_h, out_w * 3, ptr(coef), ptr(bounds), 3)
+                self._launch("bbd_resample_v_u8", out, ptr(tmp if origin == "tmp" else src), ptr(out),
+                             self._table(jobs, RESAMPLE_JOB), len(jobs), out_h, out_w * 3, _Slot("coef"),
+                             _Slot("bounds"), 3)
         return out
 
     def halve(self, level):
@@ -178,8 +210,8 @@ class ImagePipeline:
         _, H, W, _ = images_u8.shape
         assert dst.is_contiguous() and dst.shape[1:] == (3, H, W)
         jobs = [_split64(p * H * W * 3) + _split64(r * 3 * H * W) for p, r in zip(picks, rows)]
-        jt = self._dev(np.array(jobs, np.int32).reshape(-1, CONVERT_JOB))
-        self.backend.run("bbd_u8_to_float_chw", dst, ptr(images_u8), ptr(dst), ptr(jt), len(jobs), H, W)
+        self._launch("bbd_u8_to_float_chw", dst, ptr(images_u8), ptr(dst), self._table(jobs, CONVERT_JOB), len(jobs),
+                     H, W)
 
     def jitter_to_float(self, images_u8, picks, params, dst, rows):
         """dst[rows[k]] = ToTensor(ColorJitter with params[k] applied to images_u8[picks[k]]).
@@ -194,6 +226,7 @@ class ImagePipeline:
             opcodes = [op for op, _ in seq] + [-1] * (4 - len(seq))
             bits = [hue_offset(f) if op == HUE else float_bits(f) for op, f in seq] + [0] * (4 - len(seq))
             jobs.append(_split64(p * H * W * 3) + _split64(r * 3 * H * W) + tuple(opcodes) + tuple(bits))
-        jt = self._dev(np.array(jobs, np.int32).reshape(-1, JITTER_JOB))
         scratch = torch.empty(len(jobs), dtype=torch.int32, device=self.device)
-        self.backend.run("bbd_color_jitter_u8", dst, ptr(images_u8), ptr(dst), ptr(jt), len(jobs), H, W, ptr(scratch))
+        self._keep.append(scratch)
+        self._launch("bbd_color_jitter_u8", dst, ptr(images_u8), ptr(dst), self._table(jobs, JITTER_JOB), len(jobs), H,
+                     W, ptr(scratch))

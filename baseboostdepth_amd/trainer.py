@@ -110,8 +110,28 @@ class Trainer:
             last = self.train_step(inputs)
         return last
 
-    def train(self, loader_factory, num_epochs=None):
-        """`loader_factory(epoch)` -> iterable of batches; checkpoints every `save_frequency` epochs."""
+    def kitti_loader(self, epoch):
+        """The reference's per-epoch training loader (trainer.py:206-220) in index-table form: a
+        `KITTIRAWDataset` rebuilt every epoch (curriculum), decoded on host threads, collated on the GPU."""
+        from . import datasets
+        opt = self.opt
+        if not hasattr(self, "train_filenames"):
+            self.train_filenames = datasets.readlines(os.path.join(
+                getattr(opt, "splits_dir", "splits"), "eigen_zhou", "{}.txt".format(opt.training_file)))
+        if getattr(opt, "rand", False):
+            opt.scales = [0, 1, 2, 3] if epoch < 10 else [0]
+        ds = datasets.KITTIRAWDataset(self.train_filenames, epoch, opt.height, opt.width, kt_path=opt.kt_path,
+                                      rand=getattr(opt, "rand", False), is_train=True, scales=opt.scales, kt=True,
+                                      naive_mix=True, trimin=opt.trimin, seed=getattr(opt, "pytorch_random_seed", 0))
+        collate = datasets.DeviceCollate(opt.height, opt.width, opt.scales, self.device, self.backend)
+        return datasets.DeviceLoader(ds, opt.batch_size, collate, shuffle=True, drop_last=True,
+                                     num_workers=getattr(opt, "num_workers", 8),
+                                     seed=getattr(opt, "pytorch_random_seed", 0))
+
+    def train(self, loader_factory=None, num_epochs=None):
+        """`loader_factory(epoch)` -> iterable of batches (default: `kitti_loader`); checkpoints every
+        `save_frequency` epochs (trainer.py:168-193)."""
+        loader_factory = loader_factory or self.kitti_loader
         for self.epoch in range(self.epoch, num_epochs or self.opt.num_epochs):
             self.run_epoch(loader_factory(self.epoch))
             if (self.epoch + 1) % getattr(self.opt, "save_frequency", 1) == 0 and getattr(self.opt, "save_models", False):

@@ -15,7 +15,9 @@ def check_resize(pipe, h, w, oh, ow):
     imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(3)]
     src = torch.from_numpy(np.concatenate([i.ravel() for i in imgs])).to(pipe.device)
     jobs = [(k * h * w * 3, h, w, flip) for k, flip in enumerate([False, True, False])]
-    got = pipe.resize(src, jobs, oh, ow).cpu().numpy()
+    got = pipe.resize(src, jobs, oh, ow)
+    pipe.flush()
+    got = got.cpu().numpy()
     for k, flip in enumerate([False, True, False]):
         assert np.array_equal(got[k], loader_ref.resize_lanczos(imgs[k], oh, ow, flip)), (k, flip)
 
@@ -30,6 +32,7 @@ def check_ragged_and_pyramid(pipe):
     levels = [lvl0]
     for _ in range(3):
         levels.append(pipe.halve(levels[-1]))
+    pipe.flush()
     for k in range(len(imgs)):
         want = loader_ref.pyramid(loader_ref.resize_lanczos(imgs[k], 192, 640, k == 1), 4)
         for s in range(4):
@@ -50,6 +53,7 @@ def check_color_jitter(pipe, H=48, W=160, seed=11):
     dst = torch.zeros(8, 3, H, W, device=pipe.device)
     pipe.jitter_to_float(dev_imgs, list(range(6)), seqs, dst, [7, 0, 3, 2, 5, 6])
     pipe.to_float(dev_imgs, [1, 2], dst, [1, 4])
+    pipe.flush()
     dst = dst.cpu()
     for k, row in enumerate([7, 0, 3, 2, 5, 6]):
         want = loader_ref.to_tensor(loader_ref.color_jitter(imgs[k], seqs[k]))

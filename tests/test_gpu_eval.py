@@ -116,3 +116,53 @@ def test_trainer_val_loop_single_sync():
     losses = {}
     tr.compute_depth_losses(out, losses, [2, 3])
     assert set(losses) == set(tr.depth_metric_names) and losses["de/abs_rel"].is_cuda
+
+
+def test_evaluate_split_matches_per_image_oracle(tmp_path, capsys):
+    """evaluation.evaluate (evaluate_depth.py drop-in) on a synthetic split: weights folder written by
+    Trainer.save_model, frames from the device loader, metrics == oracle per image on the same disparities."""
+    import types
+    import image_checks
+    from test_gpu_trainer import make_opt
+    from baseboostdepth_amd import datasets, evaluation
+    from baseboostdepth_amd.layers import disp_to_depth
+    from baseboostdepth_amd.trainer import Trainer
+    H, W = 96, 320
+    lines = image_checks.make_kitti_tree(str(tmp_path / "kitti"), frames=20)
+    test_files = [l.rsplit(" ", 2)[0] for l in lines][:10]
+    split = tmp_path / "splits" / "eigen"
+    split.mkdir(parents=True)
+    (split / "test_files.txt").write_text("\n".join(test_files) + "\n")
+    g = torch.Generator().manual_seed(6)
+    gts = np.empty(10, dtype=object)
+    for i in range(10):
+        gh, gw = (375, 1242) if i % 2 else (370, 1226)
+        gts[i] = (torch.rand(gh, gw, generator=g) * 85 * (torch.rand(gh, gw, generator=g) < 0.06)).numpy().astype(np.float32)
+    np.savez_compressed(split / "gt_depths.npz", data=gts)
+    opt = make_opt(H, W, 2, [0, 1, 2, 3], False)
+    opt.log_dir, opt.model_name = str(tmp_path), "m"
+    tr = Trainer(opt)
+    tr.save_model("w")
+    eopt = types.SimpleNamespace(eval_mono=True, eval_stereo=False, cuda=0, num_layers=18, kt_path=str(tmp_path / "kitti"),
+                                 load_weights_folder=str(tmp_path / "m" / "models" / "weights_w"), splits_dir=str(tmp_path / "splits"),
+                                 eval_split="eigen", disable_median_scaling=False, pred_depth_scale_factor=1, min_depth=0.1,
+                                 max_depth=100.0, num_workers=2, height=H, width=W)
+    mean_errors, ratios = evaluation.evaluate(eopt, batch_size=4)
+    assert "abs_rel" in capsys.readouterr().out and ratios.shape == (10,)
+    # oracle on the disparities the same weights produce
+    ds = datasets.KITTIRAWDataset(test_files, 0, H, W, kt_path=str(tmp_path / "kitti"), is_train=False, kt=True, naive_mix=True)
+    coll = datasets.DeviceCollate(H, W, [0], "cuda:0")
+    tr.set_eval()
+    want = []
+    with torch.no_grad():
+        for i in range(10):
+            x = coll([ds[i]])[("color", 0, 0)]
+            disp, _ = disp_to_depth(tr.models["depth"](tr.models["encoder"](x))[("disp", 0)], 0.1, 100.0)
+            want.append(eval_ref.evaluate_image_ref(disp[0, 0].cpu().numpy(), gts[i]))
+    _close(mean_errors, np.mean([w["metrics"] for w in want], 0), rtol=2e-4)
+    _close(ratios, [w["ratio"] for w in want], rtol=2e-4)
+    eopt.eval_mono, eopt.eval_stereo = False, True
+    mean_s, none = evaluation.evaluate(eopt, batch_size=5)
+    assert none is None
+    # (the stereo arithmetic itself is checked in test_metrics_match_oracle_both_modes)
+    assert np.isfinite(mean_s).all() and not np.allclose(mean_s, mean_errors)

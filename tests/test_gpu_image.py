@@ -43,5 +43,6 @@ def test_jitter_covers_every_rgb_triple(pipe):
     seq = [(imageops.HUE, 0.07), (imageops.SATURATION, 1.13), (imageops.BRIGHTNESS, 0.9), (imageops.CONTRAST, 1.1)]
     dst = torch.zeros(1, 3, 4096, 4096, device=pipe.device)
     pipe.jitter_to_float(torch.from_numpy(img).to(pipe.device), [0], [seq], dst, [0])
+    pipe.flush()
     want = loader_ref.to_tensor(loader_ref.color_jitter(img[0], seq))
     assert torch.equal(dst[0].cpu(), want)
