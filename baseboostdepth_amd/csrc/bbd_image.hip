@@ -43,8 +43,14 @@ __device__ __forceinline__ size_t off64(int32_t lo, int32_t hi) {
 }
 
 // out[row][x][c] = clip8(2^21 + sum_j k[x][j] * in[row][xmin + j][c]); flip mirrors the source columns.
+// A workgroup stages RH source rows in LDS with aligned dword loads (rows start at arbitrary byte
+// addresses: 1242*3 is not a multiple of 4), then every thread produces its output columns for all RH
+// rows, reading each filter tap once.  Rows wider than the LDS budget take the direct-from-L2 path.
+constexpr int H_LDS_ROW = 6160;   // bytes per staged row: up to 2048 px * 3 + alignment slack
+template <int C>
 __global__ __launch_bounds__(NT) void resample_h_kernel(const uint8_t* src, uint8_t* dst, const ResampleJob* jobs,
-                                                        const int32_t* coef, const int32_t* bounds, int C) {
+                                                        const int32_t* coef, const int32_t* bounds) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_rows[RH][H_LDS_ROW];
   const ResampleJob jb = jobs[blockIdx.y];
   const int row0 = blockIdx.x * RH;
   if (row0 >= jb.in_h) return;
@@ -53,41 +59,99 @@ __global__ __launch_bounds__(NT) void resample_h_kernel(const uint8_t* src, uint
   const int out_w = jb.out_size, in_w = jb.in_w;
   const int flip = jb.flags & BBD_RESAMPLE_FLIP;
   const int rows = jb.in_h - row0 < RH ? jb.in_h - row0 : RH;
+  const int rowbytes = in_w * C;
+  const bool staged = rowbytes + 8 <= H_LDS_ROW;
+  int mis[RH];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) mis[r] = 0;
+  if (staged) {
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      if (r >= rows) break;
+      const uint8_t* irow = in + (size_t)(row0 + r) * rowbytes;
+      mis[r] = (int)((uintptr_t)irow & 3u);
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(irow - mis[r]);
+      const int nw = (rowbytes + mis[r]) >> 2;            // whole dwords inside the row; tail by bytes
+      uint32_t* d = reinterpret_cast<uint32_t*>(s_rows[r]);
+      for (int i = threadIdx.x; i < nw; i += NT) d[i] = w[i];
+      const int tail = (rowbytes + mis[r]) & 3;
+      if ((int)threadIdx.x < tail) s_rows[r][4 * nw + threadIdx.x] = irow[4 * nw - mis[r] + threadIdx.x];
+    }
+    __syncthreads();
+  }
   for (int x = threadIdx.x; x < out_w; x += NT) {
     const int xmin = bounds[jb.bounds_off + 2 * x], xmax = bounds[jb.bounds_off + 2 * x + 1];
     const int32_t* k = coef + jb.coef_off + (size_t)x * jb.ksize;
-    for (int r = 0; r < rows; ++r) {
-      const uint8_t* irow = in + (size_t)(row0 + r) * in_w * C;
-      for (int c = 0; c < C; ++c) {
-        int32_t acc = 1 << (BBD_RESAMPLE_PRECISION - 1);
-        for (int j = 0; j < xmax; ++j) {
-          const int sx = flip ? in_w - 1 - (xmin + j) : xmin + j;
-          acc += (int32_t)irow[(size_t)sx * C + c] * k[j];
-        }
-        out[((size_t)(row0 + r) * out_w + x) * C + c] = bbd_img_clip8(acc);
+    int32_t acc[RH][C];
+#pragma unroll
+    for (int r = 0; r < RH; ++r)
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[r][c] = 1 << (BBD_RESAMPLE_PRECISION - 1);
+    for (int j = 0; j < xmax; ++j) {
+      const int kj = k[j];
+      const int sx = (flip ? in_w - 1 - (xmin + j) : xmin + j) * C;
+      if (staged) {
+#pragma unroll
+        for (int r = 0; r < RH; ++r)
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[r][c] += (int32_t)s_rows[r][mis[r] + sx + c] * kj;
+      } else {
+#pragma unroll
+        for (int r = 0; r < RH; ++r)
+          if (r < rows)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[r][c] += (int32_t)in[(size_t)(row0 + r) * rowbytes + sx + c] * kj;
       }
     }
+#pragma unroll
+    for (int r = 0; r < RH; ++r)
+      if (r < rows)
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[((size_t)(row0 + r) * out_w + x) * C + c] = bbd_img_clip8(acc[r][c]);
   }
 }
 
 // out[y][b] = clip8(2^21 + sum_j k[y][j] * in[ymin + j][b]) over byte columns b of a row (W*C bytes).
+// Each thread owns 4 adjacent byte columns: one dword load per tap when the rows are dword-aligned
+// (640*3 bytes per row and dword-aligned image offsets - the loader's case), byte loads otherwise.
 __global__ __launch_bounds__(NT) void resample_v_kernel(const uint8_t* src, uint8_t* dst, const ResampleJob* jobs,
                                                         const int32_t* coef, const int32_t* bounds, int C) {
   const ResampleJob jb = jobs[blockIdx.z];
   const int y0 = blockIdx.y * RV;
   const int rowbytes = jb.in_w * C;
-  const int b = blockIdx.x * NT + threadIdx.x;
+  const int b = (blockIdx.x * NT + threadIdx.x) * 4;
   if (y0 >= jb.out_size || b >= rowbytes) return;
   const uint8_t* in = src + off64(jb.src_lo, jb.src_hi);
   uint8_t* out = dst + off64(jb.dst_lo, jb.dst_hi);
   const int ys = jb.out_size - y0 < RV ? jb.out_size - y0 : RV;
+  const bool words = ((rowbytes & 3) == 0) && (((uintptr_t)in & 3u) == 0) && (((uintptr_t)out & 3u) == 0);
+  const int nb = rowbytes - b < 4 ? rowbytes - b : 4;
   for (int r = 0; r < ys; ++r) {
     const int y = y0 + r;
     const int ymin = bounds[jb.bounds_off + 2 * y], ymax = bounds[jb.bounds_off + 2 * y + 1];
     const int32_t* k = coef + jb.coef_off + (size_t)y * jb.ksize;
-    int32_t acc = 1 << (BBD_RESAMPLE_PRECISION - 1);
-    for (int j = 0; j < ymax; ++j) acc += (int32_t)in[(size_t)(ymin + j) * rowbytes + b] * k[j];
-    out[(size_t)y * rowbytes + b] = bbd_img_clip8(acc);
+    int32_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = 1 << (BBD_RESAMPLE_PRECISION - 1);
+    if (words) {
+      for (int j = 0; j < ymax; ++j) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(in + (size_t)(ymin + j) * rowbytes + b);
+        const int kj = k[j];
+        acc[0] += (int32_t)(v & 255u) * kj;
+        acc[1] += (int32_t)((v >> 8) & 255u) * kj;
+        acc[2] += (int32_t)((v >> 16) & 255u) * kj;
+        acc[3] += (int32_t)(v >> 24) * kj;
+      }
+      const uint32_t o = (uint32_t)bbd_img_clip8(acc[0]) | ((uint32_t)bbd_img_clip8(acc[1]) << 8) |
+                         ((uint32_t)bbd_img_clip8(acc[2]) << 16) | ((uint32_t)bbd_img_clip8(acc[3]) << 24);
+      *reinterpret_cast<uint32_t*>(out + (size_t)y * rowbytes + b) = o;
+    } else {
+      for (int j = 0; j < ymax; ++j) {
+        const int kj = k[j];
+        for (int i = 0; i < nb; ++i) acc[i] += (int32_t)in[(size_t)(ymin + j) * rowbytes + b + i] * kj;
+      }
+      for (int i = 0; i < nb; ++i) out[(size_t)y * rowbytes + b + i] = bbd_img_clip8(acc[i]);
+    }
   }
 }
 
@@ -172,9 +236,12 @@ extern "C" {
 int bbd_resample_h_u8(const uint8_t* src, uint8_t* dst, const int32_t* jobs, int n_jobs, int max_in_h,
                       const int32_t* coef, const int32_t* bounds, int channels, void* stream) {
   if (!src || !dst || !jobs || !coef || !bounds || n_jobs <= 0 || max_in_h <= 0 || channels <= 0) return BBD_E_BADARG;
-  hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)((max_in_h + RH - 1) / RH), (unsigned)n_jobs), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), src, dst, reinterpret_cast<const ResampleJob*>(jobs), coef,
-                     bounds, channels);
+  const dim3 grid((unsigned)((max_in_h + RH - 1) / RH), (unsigned)n_jobs);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ResampleJob* jt = reinterpret_cast<const ResampleJob*>(jobs);
+  if (channels == 3) hipLaunchKernelGGL(resample_h_kernel<3>, grid, dim3(NT), 0, st, src, dst, jt, coef, bounds);
+  else if (channels == 1) hipLaunchKernelGGL(resample_h_kernel<1>, grid, dim3(NT), 0, st, src, dst, jt, coef, bounds);
+  else return BBD_E_BADARG;
   return status();
 }
 
@@ -183,7 +250,7 @@ int bbd_resample_v_u8(const uint8_t* src, uint8_t* dst, const int32_t* jobs, int
   if (!src || !dst || !jobs || !coef || !bounds || n_jobs <= 0 || max_out_h <= 0 || max_row_bytes <= 0 || channels <= 0)
     return BBD_E_BADARG;
   hipLaunchKernelGGL(resample_v_kernel,
-                     dim3((unsigned)((max_row_bytes + NT - 1) / NT), (unsigned)((max_out_h + RV - 1) / RV),
+                     dim3((unsigned)((max_row_bytes + NT * 4 - 1) / (NT * 4)), (unsigned)((max_out_h + RV - 1) / RV),
                           (unsigned)n_jobs),
                      dim3(NT), 0, static_cast<hipStream_t>(stream), src, dst,
                      reinterpret_cast<const ResampleJob*>(jobs), coef, bounds, channels);

@@ -581,6 +581,8 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   // missing loss pixels: their 3x3 adjoint is a plain 9-term sum (block-uniform fast path).
   const bool interior = tc.tx0 >= 2 && tc.tx0 + TW + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
   float gdepth[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float qdepth[PPT] = {1.0f, 1.0f, 1.0f, 1.0f};     // depth of the thread's own 4 pixels (sample-gradient phase)
+  if (q_row_ok) load_strip(depth + qy * W + qx0, qx0, W, (qx0 + PPT <= W) && ((W & 3) == 0), qdepth);
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
         if (qx >= W) continue;
         if (gx[0][j] == 0.0f && gx[1][j] == 0.0f && gx[2][j] == 0.0f) continue;
         BbdSample sm;
-        bbd_project(pj, qx, qy, depth[qy * W + qx], dm, &sm);
+        bbd_project(pj, qx, qy, qdepth[j], dm, &sm);
         BbdTaps t;
         bbd_taps(sm.ix, sm.iy, dm, &t);
         float gix = 0.0f, giy = 0.0f;
@@ -759,8 +761,8 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
         gdepth[j] += gd;
 #pragma unroll
         for (int k = 0; k < 12; ++k) gP[k] += gp1[k];
-        // keep the four pixels' projections from being interleaved: this phase is the kernel's
-        // register peak, and 168 VGPRs is the line between 2 and 3 waves per SIMD
+        // keep the four pixels' projections from being interleaved (register peak of the kernel).
+        // Measured: issuing 2 or 4 pixels' gathers together before the arithmetic is 2-7 % SLOWER.
         __builtin_amdgcn_sched_barrier(0);
       }
     }

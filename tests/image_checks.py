@@ -7,7 +7,8 @@ from oracle import loader_ref
 from baseboostdepth_amd import imageops
 
 RESIZE_CASES = [(375, 1242, 192, 640), (370, 1226, 192, 640), (376, 1241, 192, 640),
-                (100, 300, 192, 640), (192, 640, 192, 640), (61, 77, 32, 64)]
+                (100, 300, 192, 640), (192, 640, 192, 640), (61, 77, 32, 64),
+                (33, 2101, 16, 643)]                   # wider than the LDS row budget; odd row bytes
 
 
 def check_resize(pipe, h, w, oh, ow):
