@@ -537,35 +537,36 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
 
   BBD_STAMP(0);
-  if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
-  // the coefficient planes are sparse (only loss pixels won by the current candidate are non-zero):
-  // cleared once here, and each candidate's entries are cleared again by the thread that owns them
-  for (int i = threadIdx.x; i < 3 * CPLANE / 4; i += NT)
-    reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-
+  // Setup in two steps so that one memory round trip covers all of it: first every global load is
+  // issued (arg-min ids, target cells, depth cells, the thread's own strip), then the LDS work that
+  // does not depend on them (clearing the sparse coefficient planes), then the loads are consumed.
+  //
   // Loss pixels of the (TH+2)x(TW+2) region that see this tile's texels: every thread owns a fixed
   // set of them and keeps their arg-min id in registers (255 = outside the image).
   constexpr int NP_CELLS = (CH * CW + NT - 1) / NT;
   int pcell[NP_CELLS];
   unsigned parg[NP_CELLS];
-  {
-    unsigned mine = 0u;
 #pragma unroll
-    for (int k = 0; k < NP_CELLS; ++k) {
-      const int i = k * NT + (int)threadIdx.x;
-      const int r = i / CW, c = i - r * CW;
-      const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
-      const bool in = i < CH * CW && py >= 0 && py < H && px >= 0 && px < W;
-      pcell[k] = r * CS + c;
-      parg[k] = in ? (unsigned)am[py * W + px] : 255u;
-      if (in) mine |= 1u << parg[k];
-    }
-    if (mine) atomicOr(&s_present, mine);
+  for (int k = 0; k < NP_CELLS; ++k) {
+    const int i = k * NT + (int)threadIdx.x;
+    const int r = i / CW, c = i - r * CW;
+    const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
+    const bool in = i < CH * CW && py >= 0 && py < H && px >= 0 && px < W;
+    pcell[k] = r * CS + c;
+    parg[k] = in ? (unsigned)am[py * W + px] : 255u;
   }
   Cells<BH, BW, BS, 2> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(a.target + (size_t)b * img, hw, cl, s_y);
+  float tcell[Cells<BH, BW, BS, 2>::N][3];
+  {
+    const float* tg = a.target + (size_t)b * img;
+#pragma unroll
+    for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
+      tcell[k][0] = tg[cl.pix[k]];
+      tcell[k][1] = tg[cl.pix[k] + hw];
+      tcell[k][2] = tg[cl.pix[k] + 2 * hw];
+    }
+  }
   float dcell[Cells<BH, BW, BS, 2>::N];
   load_depth(depth, cl, dcell);
 
@@ -583,6 +584,26 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   float gdepth[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
   float qdepth[PPT] = {1.0f, 1.0f, 1.0f, 1.0f};     // depth of the thread's own 4 pixels (sample-gradient phase)
   if (q_row_ok) load_strip(depth + qy * W + qx0, qx0, W, (qx0 + PPT <= W) && ((W & 3) == 0), qdepth);
+
+  if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
+  // the coefficient planes are sparse (only loss pixels won by the current candidate are non-zero):
+  // cleared once here, and each candidate's entries are cleared again by the thread that owns them
+  for (int i = threadIdx.x; i < 3 * CPLANE / 4; i += NT)
+    reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  {
+    unsigned mine = 0u;
+#pragma unroll
+    for (int k = 0; k < NP_CELLS; ++k)
+      if (parg[k] != 255u) mine |= 1u << parg[k];
+    if (mine) atomicOr(&s_present, mine);
+  }
+#pragma unroll
+  for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
+    s_y[0][cl.lds[k]] = tcell[k][0];
+    s_y[1][cl.lds[k]] = tcell[k][1];
+    s_y[2][cl.lds[k]] = tcell[k][2];
+  }
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
@@ -676,10 +697,11 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
           for (int pl = 0; pl < 3; ++pl) {
             float cw[3][8];
             load_window<CS>(s_cf[pl], ly, lx0, cw);
+            float col[PPT + 2];                 // column sums shared by the strip's 4 pixels
 #pragma unroll
-            for (int j = 0; j < PPT; ++j)
+            for (int i = 0; i < PPT + 2; ++i) col[i] = (cw[0][i] + cw[1][i]) + cw[2][i];
 #pragma unroll
-              for (int dr = 0; dr < 3; ++dr) S3[pl][j] += (cw[dr][j] + cw[dr][j + 1]) + cw[dr][j + 2];
+            for (int j = 0; j < PPT; ++j) S3[pl][j] = (col[j] + col[j + 1]) + col[j + 2];
           }
         } else {
           // adjoint multiplicities of reflect-pad + 3x3 mean (0 where the loss pixel is outside the image)

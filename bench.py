@@ -37,8 +37,9 @@ SCALES = [0, 1, 2, 3]
 def make_options(batch, device_index, config):
     import types
     boosted = config != "md2"
+    one_scale = config in ("boosted", "boosted15")
     return types.SimpleNamespace(
-        height=H, width=W, batch_size=batch, scales=([0] if boosted else list(SCALES)), frame_ids=[0, -1, 1],
+        height=H, width=W, batch_size=batch, scales=([0] if one_scale else list(SCALES)), frame_ids=[0, -1, 1],
         min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False,
         trimin=boosted, decomp=boosted, pose_error=5.5, incremental_skip=boosted, partial_skip=boosted,
         materialize_warps=False, num_layers=18, weights_init="scratch", learning_rate=1e-4,
@@ -170,8 +171,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
-    ap.add_argument("--config", default="md2", choices=["md2", "boosted"],
-                    help="md2 = BASELINE configs[1]/[3] (the headline); boosted = configs[2] worst case m=7")
+    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5"],
+                    help="md2 = BASELINE configs[1]/[3] (the headline); configs[2] (SURVEY 8d config 3): boosted = "
+                         "worst case m=7 for every sample, boosted15 = the epoch-15 offset distribution (standard "
+                         "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
@@ -207,9 +210,18 @@ def main():
             m.to(memory_format=torch.channels_last)
     trainer.set_train()
     bdist.attach(trainer)
-    ms = [1] * args.batch if args.config == "md2" else [7] * args.batch
+    import random as _random
+    draw = _random.Random(1234 + rank)
+    if args.config == "md2":
+        ms = [1] * args.batch
+    elif args.config == "boosted":
+        ms = [7] * args.batch
+    elif args.config == "boosted15":             # P(m = 1..7) at epoch 15
+        ms = draw.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448], k=args.batch)
+    else:                                        # epoch 5: P(m = 0,1,2) = .062 .573 .366
+        ms = draw.choices(range(0, 3), [.062, .573, .366], k=args.batch)
     inputs = synthetic_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
-    if args.config != "md2":
+    if args.config in ("boosted", "boosted15"):
         inputs["cutt"] = torch.tensor(1.35)      # epoch >= 10 regime: incremental + partial pose modes
     backend = ops.default_backend()
 
@@ -273,8 +285,9 @@ def main():
             "config": {"workload": "MD2 ResNet-18 encoder+DepthDecoder+PoseNet training step, 640x192, "
                                    "per-GPU batch %d, frames [0,-1,1], %d scales, HIP fused warp+SSIM+min"
                                    % (args.batch, S) if args.config == "md2" else
-                                   "BaseBoostDepth boosted step (trimin+decomp+incremental+partial, m=7, 18 "
-                                   "candidates/px), ResNet-18, 640x192, per-GPU batch %d, 1 scale" % args.batch,
+                                   "BaseBoostDepth boosted step (trimin+decomp+incremental+partial, config %s, "
+                                   "per-sample max offsets %s), ResNet-18, 640x192, per-GPU batch %d, %d scale(s)"
+                                   % (args.config, ms, args.batch, S),
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
             "roofline": roofline, "kernels": kernels,
         }
