@@ -49,6 +49,9 @@ SIGNATURES = {
     "bbd_resample_v_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p],
     "bbd_color_jitter_u8": [_p, _p, _p, _i, _i, _i, _p, _p],
     "bbd_u8_to_float_chw": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_bn_scratch_doubles": [_i, _i, _i],
+    "bbd_bn_act_fwd": [_p] * 10 + [_i, _i, _i, _d, _d, _i, _p],
+    "bbd_bn_act_bwd": [_p] * 11 + [_i, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
 }
 RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4
@@ -82,6 +85,9 @@ class HipLibrary:
 
     def num_tiles(self, H, W):
         return self._dll.bbd_num_tiles(H, W)
+
+    def bn_scratch_doubles(self, N, C, HW):
+        return self._dll.bbd_bn_scratch_doubles(N, C, HW)
 
     def call(self, name, *args):
         rc = getattr(self._dll, name)(*args)

@@ -1,0 +1,311 @@
+// bbd_nn.hip - fused training-mode BatchNorm2d (+ residual add) (+ ReLU), forward and backward.
+//
+// The encoders are torchvision-layout ResNets (networks/resnet_encoder.py:12-91): every convolution is
+// followed by BatchNorm2d, then either ReLU or "+ identity, ReLU".  In eager PyTorch-ROCm that is one
+// MIOpen batch-norm launch plus separate add / clamp / threshold kernels, each a full round trip over
+// the activation (profiles/r01/bench_md2_one_steady_step_v6.csv: 2.6 ms BN + ~1.3 ms add/ReLU per step).
+// Here the tail of a block is two launches each way over NCHW fp32:
+//
+//   forward : stats   per channel sum / sum of squares (fp64 partials, fixed-order combine)
+//             apply   y = relu(gamma * (x - mean) * invstd + beta + residual); running stats updated
+//   backward: reduce  g = dy * (y > 0);  per channel sum(g), sum(g * xhat)
+//             apply   dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  dresidual = g;
+//                     dgamma = sum(g * xhat), dbeta = sum(g)
+//
+// Same definition as torch.nn.functional.batch_norm(training=True): biased variance for the
+// normalisation, unbiased for running_var, momentum update of the running statistics.  HBM-bound
+// elementwise / reduction work: coalesced float4 accesses of each (n, c) plane, one workgroup per
+// (channel, slice of the plane), deterministic (no floating-point atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bbd_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_SPLIT = 64;
+
+struct BnArgs {
+  const float* x;        // [N,C,HW] conv output
+  const float* res;      // residual or NULL
+  const float* gamma;    // [C]
+  const float* beta;     // [C]
+  float* y;              // [N,C,HW]
+  double* part;          // [C, split, 2] scratch
+  float* mean;           // [C] saved for backward
+  float* invstd;         // [C]
+  float* run_mean;       // [C] or NULL
+  float* run_var;        // [C] or NULL
+  // backward
+  const float* dy;
+  float* dx;
+  float* dres;           // or NULL
+  float* dgamma;
+  float* dbeta;
+  int N, C, HW, split, relu;
+  float eps, momentum;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// slice [lo, hi) of the HW plane owned by blockIdx.x (multiples of 4 when HW % 4 == 0)
+__device__ __forceinline__ void plane_slice(int HW, int split, int* lo, int* hi) {
+  int len = (HW + split - 1) / split;
+  len = (len + 3) & ~3;
+  *lo = blockIdx.x * len;
+  *hi = min(HW, *lo + len);
+}
+
+__global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y;
+  int lo, hi;
+  plane_slice(a.HW, a.split, &lo, &hi);
+  float s = 0.0f, ss = 0.0f;
+  double ds = 0.0, dss = 0.0;
+  const bool vec = (a.HW & 3) == 0;
+  for (int n = 0; n < a.N; ++n) {
+    const float* p = a.x + ((size_t)n * a.C + c) * a.HW;
+    if (vec) {
+      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+        const float v = p[i];
+        s += v;
+        ss += v * v;
+      }
+    }
+    ds += (double)s; dss += (double)ss;     // short fp32 runs, fp64 across images
+    s = 0.0f; ss = 0.0f;
+  }
+  const double ts = block_sum(ds, sh), tss = block_sum(dss, sh);
+  if (threadIdx.x == 0) {
+    a.part[((size_t)c * a.split + blockIdx.x) * 2] = ts;
+    a.part[((size_t)c * a.split + blockIdx.x) * 2 + 1] = tss;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
+  __shared__ float s_mean, s_scale, s_shift;
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tss = 0.0;
+    for (int k = 0; k < a.split; ++k) {
+      ts += a.part[((size_t)c * a.split + k) * 2];
+      tss += a.part[((size_t)c * a.split + k) * 2 + 1];
+    }
+    const double cnt = (double)a.N * (double)a.HW;
+    const double mean = ts / cnt;
+    double var = tss / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    s_mean = (float)mean;
+    s_scale = a.gamma[c] * invstd;
+    s_shift = a.beta[c];
+    if (blockIdx.x == 0) {
+      a.mean[c] = (float)mean;
+      a.invstd[c] = invstd;
+      if (a.run_mean) {
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        a.run_mean[c] = (1.0f - a.momentum) * a.run_mean[c] + a.momentum * (float)mean;
+        a.run_var[c] = (1.0f - a.momentum) * a.run_var[c] + a.momentum * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const float mean = s_mean, scale = s_scale, shift = s_shift;
+  int lo, hi;
+  plane_slice(a.HW, a.split, &lo, &hi);
+  const bool vec = (a.HW & 3) == 0;
+  for (int n = 0; n < a.N; ++n) {
+    const size_t base = ((size_t)n * a.C + c) * a.HW;
+    if (vec) {
+      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+        const float4 v = *reinterpret_cast<const float4*>(a.x + base + i);
+        float4 o;
+        o.x = (v.x - mean) * scale + shift; o.y = (v.y - mean) * scale + shift;
+        o.z = (v.z - mean) * scale + shift; o.w = (v.w - mean) * scale + shift;
+        if (a.res) {
+          const float4 r = *reinterpret_cast<const float4*>(a.res + base + i);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (a.relu) {
+          o.x = o.x > 0.0f ? o.x : 0.0f; o.y = o.y > 0.0f ? o.y : 0.0f;
+          o.z = o.z > 0.0f ? o.z : 0.0f; o.w = o.w > 0.0f ? o.w : 0.0f;
+        }
+        *reinterpret_cast<float4*>(a.y + base + i) = o;
+      }
+    } else {
+      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+        float o = (a.x[base + i] - mean) * scale + shift;
+        if (a.res) o += a.res[base + i];
+        if (a.relu) o = o > 0.0f ? o : 0.0f;
+        a.y[base + i] = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y;
+  int lo, hi;
+  plane_slice(a.HW, a.split, &lo, &hi);
+  const float mean = a.mean[c], invstd = a.invstd[c];
+  double dg = 0.0, dgx = 0.0;
+  const bool vec = (a.HW & 3) == 0;
+  for (int n = 0; n < a.N; ++n) {
+    const size_t base = ((size_t)n * a.C + c) * a.HW;
+    float sg = 0.0f, sgx = 0.0f;
+    if (vec) {
+      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+        float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
+        const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
+        if (a.relu) {
+          const float4 y = *reinterpret_cast<const float4*>(a.y + base + i);
+          g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f;
+          g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
+        }
+        sg += (g.x + g.y) + (g.z + g.w);
+        sgx += (g.x * ((x.x - mean) * invstd) + g.y * ((x.y - mean) * invstd)) +
+               (g.z * ((x.z - mean) * invstd) + g.w * ((x.w - mean) * invstd));
+      }
+    } else {
+      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+        float g = a.dy[base + i];
+        if (a.relu && !(a.y[base + i] > 0.0f)) g = 0.0f;
+        sg += g;
+        sgx += g * ((a.x[base + i] - mean) * invstd);
+      }
+    }
+    dg += (double)sg;
+    dgx += (double)sgx;
+  }
+  const double tg = block_sum(dg, sh), tgx = block_sum(dgx, sh);
+  if (threadIdx.x == 0) {
+    a.part[((size_t)c * a.split + blockIdx.x) * 2] = tg;
+    a.part[((size_t)c * a.split + blockIdx.x) * 2 + 1] = tgx;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
+  __shared__ float s_k[3];
+  const int c = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double tg = 0.0, tgx = 0.0;
+    for (int k = 0; k < a.split; ++k) {
+      tg += a.part[((size_t)c * a.split + k) * 2];
+      tgx += a.part[((size_t)c * a.split + k) * 2 + 1];
+    }
+    const double cnt = (double)a.N * (double)a.HW;
+    s_k[0] = (float)(tg / cnt);
+    s_k[1] = (float)(tgx / cnt);
+    s_k[2] = a.gamma[c] * a.invstd[c];
+    if (blockIdx.x == 0) {
+      a.dgamma[c] = (float)tgx;
+      a.dbeta[c] = (float)tg;
+    }
+  }
+  __syncthreads();
+  const float mg = s_k[0], mgx = s_k[1], k = s_k[2];
+  const float mean = a.mean[c], invstd = a.invstd[c];
+  int lo, hi;
+  plane_slice(a.HW, a.split, &lo, &hi);
+  const bool vec = (a.HW & 3) == 0;
+  for (int n = 0; n < a.N; ++n) {
+    const size_t base = ((size_t)n * a.C + c) * a.HW;
+    if (vec) {
+      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+        float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
+        const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
+        if (a.relu) {
+          const float4 y = *reinterpret_cast<const float4*>(a.y + base + i);
+          g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f;
+          g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
+        }
+        if (a.dres) *reinterpret_cast<float4*>(a.dres + base + i) = g;
+        float4 o;
+        o.x = k * (g.x - mg - ((x.x - mean) * invstd) * mgx);
+        o.y = k * (g.y - mg - ((x.y - mean) * invstd) * mgx);
+        o.z = k * (g.z - mg - ((x.z - mean) * invstd) * mgx);
+        o.w = k * (g.w - mg - ((x.w - mean) * invstd) * mgx);
+        *reinterpret_cast<float4*>(a.dx + base + i) = o;
+      }
+    } else {
+      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+        float g = a.dy[base + i];
+        if (a.relu && !(a.y[base + i] > 0.0f)) g = 0.0f;
+        if (a.dres) a.dres[base + i] = g;
+        a.dx[base + i] = k * (g - mg - ((a.x[base + i] - mean) * invstd) * mgx);
+      }
+    }
+  }
+}
+
+int pick_split(int N, int HW) {
+  long long per = (long long)N * HW;
+  int s = (int)((per + 4095) / 4096);
+  if (s < 1) s = 1;
+  if (s > MAX_SPLIT) s = MAX_SPLIT;
+  const int max_by_plane = (HW + 3) / 4;     // at least one float4 of the plane per slice
+  return s < max_by_plane ? s : max_by_plane;
+}
+
+int status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bbd_bn_scratch_doubles(int N, int C, int HW) { return C * pick_split(N, HW) * 2; }
+
+int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                   float* save_mean, float* save_invstd, float* running_mean, float* running_var, double* scratch,
+                   int N, int C, int HW, double eps, double momentum, int relu, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch || N <= 0 || C <= 0 || HW <= 0)
+    return BBD_E_BADARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return BBD_E_BADARG;
+  BnArgs a = {};
+  a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.y = y; a.part = scratch; a.mean = save_mean;
+  a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.N = N; a.C = C; a.HW = HW;
+  a.split = pick_split(N, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)a.split, (unsigned)C);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, st, a);
+  return status();
+}
+
+int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* save_mean,
+                   const float* save_invstd, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                   double* scratch, int N, int C, int HW, int relu, void* stream) {
+  if (!x || !grad_y || !gamma || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !scratch ||
+      N <= 0 || C <= 0 || HW <= 0 || (relu && !y))
+    return BBD_E_BADARG;
+  BnArgs a = {};
+  a.x = x; a.y = const_cast<float*>(y); a.dy = grad_y; a.gamma = gamma; a.mean = const_cast<float*>(save_mean);
+  a.invstd = const_cast<float*>(save_invstd); a.dx = grad_x; a.dres = grad_residual; a.dgamma = grad_gamma;
+  a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.split = pick_split(N, HW); a.relu = relu;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)a.split, (unsigned)C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
+  return status();
+}
+
+}  // extern "C"

@@ -5,9 +5,33 @@ here with torchvision-identical module names - `conv1, bn1, layer{1..4}.{i}.conv
 layer{k}.0.downsample.{0,1}, fc` - so `encoder.pth` checkpoints written by the reference
 (trainer.py:783-805) load with `load_state_dict` unchanged, including the unused `fc`.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FusedBatchNorm2d(nn.BatchNorm2d):
+    """`nn.BatchNorm2d` (same parameters, buffers and state-dict keys) whose training-mode forward on
+    the GPU also absorbs what follows it in a ResNet block: `relu(bn(x) + residual)` runs as two HIP
+    launches each way (csrc/bbd_nn.hip) instead of MIOpen batch-norm + add + clamp kernels.  Host
+    tensors, eval mode and exotic configurations take the stock PyTorch ops."""
+
+    fused = os.environ.get("BBD_FUSED_BN", "1") != "0"
+
+    def forward(self, x, residual=None, relu=False):
+        if (self.fused and x.is_cuda and self.training and self.affine and self.track_running_stats
+                and self.momentum is not None and x.dtype == torch.float32 and x.dim() == 4):
+            from .. import ops
+            self.num_batches_tracked.add_(1)
+            return ops.batch_norm_act(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
+                                      self.momentum, self.eps, relu)
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
 
 
 class BasicBlock(nn.Module):
@@ -16,17 +40,16 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.downsample = downsample
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + identity)
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), residual=identity, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -35,20 +58,19 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = FusedBatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=identity, relu=True)
 
 
 _CONFIGS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
@@ -64,7 +86,7 @@ class ResNetTrunk(nn.Module):
         block, layers = _CONFIGS[num_layers]
         self.inplanes = 64
         self.conv1 = nn.Conv2d(num_input_images * 3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = FusedBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -85,7 +107,7 @@ class ResNetTrunk(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(
                 nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
-                nn.BatchNorm2d(planes * block.expansion))
+                FusedBatchNorm2d(planes * block.expansion))
         layers = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
@@ -110,7 +132,7 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         e = self.encoder
         x = (input_image - 0.45) / 0.225
-        f0 = e.relu(e.bn1(e.conv1(x)))
+        f0 = e.bn1(e.conv1(x), relu=True)
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)

@@ -315,3 +315,48 @@ def fused_reprojection_min(depth, proj, target, ident, noise, plan, frame_tensor
     """Returns (loss_sum [S], min_loss [S,B,H,W], argmin u8 [S,B,H,W], warped [S,NP,3,H,W] | None)."""
     return _FusedReprojectionMin.apply(depth, proj, target, ident, noise, plan, frame_tensors, bool(no_ssim),
                                        bool(materialize), backend or default_backend())
+
+
+# ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)
+class _BatchNormAct(torch.autograd.Function):
+    """Training-mode BatchNorm2d, optional residual add and ReLU in two launches each way
+    (csrc/bbd_nn.hip) - the tail of every ResNet block of the encoders."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, backend):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        if residual is not None:
+            residual = residual.contiguous()
+            assert residual.shape == x.shape
+        backend._check(x, weight, bias, residual, running_mean, running_var)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(backend.lib.bn_scratch_doubles(N, C, H * W), device=x.device, dtype=torch.float64)
+        backend.run("bbd_bn_act_fwd", x, ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd),
+                    ptr(running_mean), ptr(running_var), ptr(scratch), N, C, H * W, float(eps), float(momentum),
+                    int(relu))
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.meta = (bool(relu), residual is not None, backend)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        relu, has_res, backend = ctx.meta
+        N, C, H, W = x.shape
+        grad_y = grad_y.contiguous()
+        grad_x = torch.empty_like(x)
+        grad_res = torch.empty_like(x) if has_res else None
+        grad_w = torch.empty(C, device=x.device, dtype=torch.float32)
+        grad_b = torch.empty(C, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(backend.lib.bn_scratch_doubles(N, C, H * W), device=x.device, dtype=torch.float64)
+        backend.run("bbd_bn_act_bwd", x, ptr(x), ptr(y), ptr(grad_y), ptr(weight), ptr(mean), ptr(invstd), ptr(grad_x),
+                    ptr(grad_res), ptr(grad_w), ptr(grad_b), ptr(scratch), N, C, H * W, int(relu))
+        return grad_x, grad_w, grad_b, grad_res, None, None, None, None, None, None
+
+
+def batch_norm_act(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, backend=None):
+    return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu,
+                               backend or default_backend())

@@ -1,0 +1,101 @@
+"""GPU tier of the fused BatchNorm(+residual)(+ReLU) kernels (csrc/bbd_nn.hip) against the stock PyTorch
+ops they replace inside the encoders: forward, running statistics, all four gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("shape,res,relu", [((12, 64, 96, 320), False, True), ((12, 64, 48, 160), True, True),
+                                            ((4, 128, 24, 80), False, False), ((3, 7, 5, 9), True, True),
+                                            ((12, 512, 6, 20), True, True), ((2, 5, 1, 3), False, True)])
+def test_fused_bn_matches_torch(shape, res, relu):
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    N, C, H, W = shape
+    x0 = (torch.randn(shape, generator=g) * 1.7 + 0.3).to(DEV)
+    r0 = torch.randn(shape, generator=g).to(DEV) if res else None
+    w0 = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    b0 = torch.randn(C, generator=g).to(DEV)
+    gy = torch.randn(shape, generator=g).to(DEV)
+    rm0, rv0 = torch.randn(C, generator=g).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if res else None
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        rm, rv = rm0.clone(), rv0.clone()
+        if fused:
+            y = ops.batch_norm_act(x, w, b, r, rm, rv, 0.1, 1e-5, relu)
+        else:
+            y = F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5)
+            if res:
+                y = y + r
+            if relu:
+                y = F.relu(y)
+        y.backward(gy)
+        return y.detach(), rm, rv, x.grad, w.grad, b.grad, (r.grad if res else None)
+
+    got, want = run(True), run(False)
+    names = ["y", "running_mean", "running_var", "grad_x", "grad_w", "grad_b", "grad_res"]
+    tol = [1e-5, 1e-5, 1e-5, 2e-4, 2e-4, 2e-4, 1e-6]
+    for n, a, b, t in zip(names, got, want, tol):
+        if b is None:
+            assert a is None
+            continue
+        assert _rel(a, b) < t, (n, _rel(a, b))
+    # deterministic
+    again = run(True)
+    assert torch.equal(again[0], got[0]) and torch.equal(again[3], got[3]) and torch.equal(again[4], got[4])
+
+
+def test_encoder_fused_vs_stock_and_state_dict():
+    from baseboostdepth_amd import networks
+    from baseboostdepth_amd.networks import encoder as enc_mod
+    torch.manual_seed(0)
+    enc = networks.ResnetEncoder(18, False).to(DEV).train()
+    keys = set(enc.state_dict().keys())
+    assert "encoder.layer1.0.bn1.running_var" in keys and "encoder.layer2.0.downsample.1.num_batches_tracked" in keys
+    x = torch.rand(4, 3, 96, 320, device=DEV)
+    state = {k: v.clone() for k, v in enc.state_dict().items()}
+
+    def run(fused):
+        enc.load_state_dict(state)
+        enc.zero_grad(set_to_none=True)
+        enc_mod.FusedBatchNorm2d.fused = fused
+        feats = enc(x)
+        loss = sum((f * f).mean() for f in feats)
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        return [f.detach().clone() for f in feats], grads, {k: v.clone() for k, v in enc.state_dict().items()}
+
+    try:
+        f1, g1, s1 = run(True)
+        f0, g0, s0 = run(False)
+    finally:
+        enc_mod.FusedBatchNorm2d.fused = True
+    for a, b in zip(f1, f0):
+        assert _rel(a, b) < 2e-4
+    for n in g0:
+        assert _rel(g1[n], g0[n]) < 3e-2, n          # deep random-init net: ReLU masks flip at rounding level
+    for k in s0:
+        if s0[k].is_floating_point():
+            assert _rel(s1[k], s0[k]) < 1e-4, k
+        else:
+            assert torch.equal(s1[k], s0[k]), k
+    # eval mode goes through the stock path and still works
+    enc.eval()
+    with torch.no_grad():
+        assert enc(x)[0].shape == (4, 64, 48, 160)
