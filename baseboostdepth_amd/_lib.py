@@ -52,6 +52,10 @@ SIGNATURES = {
     "bbd_bn_scratch_doubles": [_i, _i, _i],
     "bbd_bn_act_fwd": [_p] * 10 + [_i, _i, _i, _d, _d, _i, _p],
     "bbd_bn_act_bwd": [_p] * 11 + [_i, _i, _i, _i, _p],
+    "bbd_reflect_pad1_fwd": [_p, _p, _i, _i, _i, _p],
+    "bbd_reflect_pad1_bwd": [_p, _p, _i, _i, _i, _p],
+    "bbd_maxpool3s2_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_maxpool3s2_bwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
 }
 RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4

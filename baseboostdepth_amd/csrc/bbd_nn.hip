@@ -254,6 +254,128 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ReflectionPad2d(1) (layers.py:118-133, every decoder convolution) and MaxPool2d(3, 2, 1)
+// (networks/resnet_encoder.py: the torchvision stem), forward and gather-form backward: no atomics,
+// deterministic, one coalesced pass.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect1(int i, int n) {   // index into the un-padded axis for padded index i
+  i -= 1;
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// Row-tiled launches: a workgroup of 64 x 4 threads owns 4 rows of one plane (blockIdx.y = plane), the
+// 64 lanes of a wave sweep the row, so every access is a coalesced run with no index division.
+constexpr int RW = 64, RR = 4;
+
+__global__ __launch_bounds__(RW * RR) void reflect_pad1_fwd_kernel(const float* __restrict__ in,
+                                                                   float* __restrict__ out, int H, int W) {
+  const int PH = H + 2, PW = W + 2;
+  const int py = blockIdx.x * RR + threadIdx.y;
+  if (py >= PH) return;
+  const size_t pl = blockIdx.y;
+  const float* src = in + (pl * H + reflect1(py, H)) * W;
+  float* dst = out + (pl * PH + py) * PW;
+  for (int px = threadIdx.x; px < PW; px += RW) dst[px] = src[reflect1(px, W)];
+}
+
+// grad_in[y][x] = sum of grad_out over every padded position that reads (y, x)
+__global__ __launch_bounds__(RW * RR) void reflect_pad1_bwd_kernel(const float* __restrict__ gout,
+                                                                   float* __restrict__ gin, int H, int W) {
+  const int PH = H + 2, PW = W + 2;
+  const int y = blockIdx.x * RR + threadIdx.y;
+  if (y >= H) return;
+  const size_t pl = blockIdx.y;
+  const float* g = gout + pl * PH * PW;
+  float* dst = gin + (pl * H + y) * W;
+  int ys[3], ny = 0;                       // padded rows that map onto y (wave-uniform)
+  ys[ny++] = y + 1;
+  if (y == 1) ys[ny++] = 0;
+  if (y == H - 2) ys[ny++] = PH - 1;
+  for (int x = threadIdx.x; x < W; x += RW) {
+    float acc = 0.0f;
+    for (int a = 0; a < ny; ++a) {
+      const float* row = g + (size_t)ys[a] * PW;
+      acc += row[x + 1];
+      if (x == 1) acc += row[0];
+      if (x == W - 2) acc += row[PW - 1];
+    }
+    dst[x] = acc;
+  }
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1): ATen's scan order and tie / NaN rule (first maximum in
+// row-major window order; a NaN replaces the running maximum).  `code` = window position 0..8.
+__global__ __launch_bounds__(RW * RR) void maxpool3s2_fwd_kernel(const float* __restrict__ in,
+                                                                 float* __restrict__ out, uint8_t* __restrict__ code,
+                                                                 int H, int W, int OH, int OW) {
+  const int oy = blockIdx.x * RR + threadIdx.y;
+  if (oy >= OH) return;
+  const size_t pl = blockIdx.y;
+  const float* p = in + pl * H * W;
+  for (int ox = threadIdx.x; ox < OW; ox += RW) {
+    float best = -INFINITY;
+    int bc = -1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * oy - 1 + dy;
+      if (y < 0 || y >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = 2 * ox - 1 + dx;
+        if (x < 0 || x >= W) continue;
+        const float v = p[(size_t)y * W + x];
+        if (bc < 0 || v > best || v != v) { best = v; bc = dy * 3 + dx; }
+      }
+    }
+    out[(pl * OH + oy) * OW + ox] = best;
+    code[(pl * OH + oy) * OW + ox] = (uint8_t)bc;
+  }
+}
+
+// Backward, one thread per output window (oy, ox): it owns the 2x2 input block whose top-left pixel is
+// the window centre (2oy, 2ox) and gathers from the <= 4 windows that overlap the block, so every code /
+// gradient value is read once per neighbour and the stores are two coalesced float2 rows.
+__global__ __launch_bounds__(RW * RR) void maxpool3s2_bwd_kernel(const float* __restrict__ gout,
+                                                                 const uint8_t* __restrict__ code,
+                                                                 float* __restrict__ gin, int H, int W, int OH,
+                                                                 int OW) {
+  const int oy = blockIdx.x * RR + threadIdx.y;
+  if (oy >= OH) return;
+  const size_t pl = blockIdx.y;
+  const float* g = gout + pl * OH * OW;
+  const uint8_t* cd = code + pl * OH * OW;
+  float* dst = gin + pl * H * W;
+  const bool down = oy + 1 < OH;
+  const int y0 = 2 * oy, y1 = 2 * oy + 1;
+  for (int ox = threadIdx.x; ox < OW; ox += RW) {
+    const bool right = ox + 1 < OW;
+    const size_t i00 = (size_t)oy * OW + ox;
+    const int c00 = cd[i00];
+    const float g00 = g[i00];
+    const int c01 = right ? cd[i00 + 1] : -1;
+    const float g01 = right ? g[i00 + 1] : 0.0f;
+    const int c10 = down ? cd[i00 + OW] : -1;
+    const float g10 = down ? g[i00 + OW] : 0.0f;
+    const int c11 = (down && right) ? cd[i00 + OW + 1] : -1;
+    const float g11 = (down && right) ? g[i00 + OW + 1] : 0.0f;
+    // window (oy,ox) covers rows 2oy-1..2oy+1: the block's pixels sit at window positions 4,5 / 7,8
+    const float a = c00 == 4 ? g00 : 0.0f;                                            // (y0, x0)
+    const float b = (c00 == 5 ? g00 : 0.0f) + (c01 == 3 ? g01 : 0.0f);                // (y0, x0+1)
+    const float c = (c00 == 7 ? g00 : 0.0f) + (c10 == 1 ? g10 : 0.0f);                // (y0+1, x0)
+    const float d = ((c00 == 8 ? g00 : 0.0f) + (c01 == 6 ? g01 : 0.0f)) +
+                    ((c10 == 2 ? g10 : 0.0f) + (c11 == 0 ? g11 : 0.0f));              // (y0+1, x0+1)
+    const int x0 = 2 * ox;
+    dst[(size_t)y0 * W + x0] = a;
+    if (x0 + 1 < W) dst[(size_t)y0 * W + x0 + 1] = b;
+    if (y1 < H) {
+      dst[(size_t)y1 * W + x0] = c;
+      if (x0 + 1 < W) dst[(size_t)y1 * W + x0 + 1] = d;
+    }
+  }
+}
+
 int pick_split(int N, int HW) {
   long long per = (long long)N * HW;
   int s = (int)((per + 4095) / 4096);
@@ -305,6 +427,37 @@ int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const fl
   const dim3 grid((unsigned)a.split, (unsigned)C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
+  return status();
+}
+
+int bbd_reflect_pad1_fwd(const float* in, float* out, int planes, int H, int W, void* stream) {
+  if (!in || !out || planes <= 0 || planes > 65535 || H < 2 || W < 2) return BBD_E_BADARG;
+  hipLaunchKernelGGL(reflect_pad1_fwd_kernel, dim3((unsigned)((H + 2 + RR - 1) / RR), (unsigned)planes), dim3(RW, RR), 0,
+                     static_cast<hipStream_t>(stream), in, out, H, W);
+  return status();
+}
+
+int bbd_reflect_pad1_bwd(const float* grad_out, float* grad_in, int planes, int H, int W, void* stream) {
+  if (!grad_out || !grad_in || planes <= 0 || planes > 65535 || H < 2 || W < 2) return BBD_E_BADARG;
+  hipLaunchKernelGGL(reflect_pad1_bwd_kernel, dim3((unsigned)((H + RR - 1) / RR), (unsigned)planes), dim3(RW, RR), 0,
+                     static_cast<hipStream_t>(stream), grad_out, grad_in, H, W);
+  return status();
+}
+
+int bbd_maxpool3s2_fwd(const float* in, float* out, uint8_t* code, int planes, int H, int W, void* stream) {
+  if (!in || !out || !code || planes <= 0 || planes > 65535 || H < 1 || W < 1) return BBD_E_BADARG;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;          // floor((H + 2 - 3) / 2) + 1
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)((OH + RR - 1) / RR), (unsigned)planes), dim3(RW, RR), 0,
+                     static_cast<hipStream_t>(stream), in, out, code, H, W, OH, OW);
+  return status();
+}
+
+int bbd_maxpool3s2_bwd(const float* grad_out, const uint8_t* code, float* grad_in, int planes, int H, int W,
+                       void* stream) {
+  if (!grad_out || !code || !grad_in || planes <= 0 || planes > 65535 || H < 1 || W < 1) return BBD_E_BADARG;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((OH + RR - 1) / RR), (unsigned)planes), dim3(RW, RR), 0,
+                     static_cast<hipStream_t>(stream), grad_out, code, grad_in, H, W, OH, OW);
   return status();
 }
 

@@ -69,12 +69,24 @@ def _transformation_from_parameters_torch(axisangle, translation, invert=False):
     return torch.matmul(R, T) if invert else torch.matmul(T, R)
 
 
+class ReflectionPad1(nn.ReflectionPad2d):
+    """`nn.ReflectionPad2d(1)`; fp32 GPU tensors take the HIP kernels (gather-form backward)."""
+
+    def __init__(self):
+        super().__init__(1)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and min(x.shape[2:]) >= 2 and ops.FUSED_NN:
+            return ops.reflect_pad1(x)
+        return super().forward(x)
+
+
 class Conv3x3(nn.Module):
     """Reflection-padded 3x3 convolution (layers.py:118-133)."""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
-        self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
+        self.pad = ReflectionPad1() if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x):

@@ -34,6 +34,19 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         return F.relu(y) if relu else y
 
 
+class MaxPool3s2(nn.MaxPool2d):
+    """The stem's `nn.MaxPool2d(3, 2, 1)`; fp32 GPU tensors take the HIP kernels (atomic-free backward)."""
+
+    def __init__(self):
+        super().__init__(kernel_size=3, stride=2, padding=1)
+
+    def forward(self, x):
+        from .. import ops
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and ops.FUSED_NN:
+            return ops.maxpool3s2(x)
+        return super().forward(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -88,7 +101,7 @@ class ResNetTrunk(nn.Module):
         self.conv1 = nn.Conv2d(num_input_images * 3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = FusedBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = MaxPool3s2()
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

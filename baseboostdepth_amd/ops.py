@@ -7,12 +7,17 @@ tier injects a host build of the same arithmetic through the `backend=` seam - s
 tests/host_port.py - but nothing in this package can fall back to it.)
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 from ._lib import POSE_STRIDE, PROJ_STRIDE, MAX_FRAME_SLOTS, ptr
 from .plan import frame_slot
+
+
+# BBD_FUSED_NN=0 sends the encoder / decoder glue (pad, max-pool) back to the stock ATen kernels (A/B runs)
+FUSED_NN = os.environ.get("BBD_FUSED_NN", "1") != "0"
 
 
 class KernelTimer:
@@ -360,3 +365,58 @@ class _BatchNormAct(torch.autograd.Function):
 def batch_norm_act(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, backend=None):
     return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu,
                                backend or default_backend())
+
+
+# ---------------------------------------------------------------------------- ReflectionPad2d(1), MaxPool2d(3,2,1)
+class _ReflectPad1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, backend):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        backend._check(x)
+        out = torch.empty(N, C, H + 2, W + 2, device=x.device, dtype=torch.float32)
+        backend.run("bbd_reflect_pad1_fwd", x, ptr(x), ptr(out), N * C, H, W)
+        ctx.meta = (N, C, H, W, backend)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        N, C, H, W, backend = ctx.meta
+        grad_out = grad_out.contiguous()
+        grad_in = torch.empty(N, C, H, W, device=grad_out.device, dtype=torch.float32)
+        backend.run("bbd_reflect_pad1_bwd", grad_out, ptr(grad_out), ptr(grad_in), N * C, H, W)
+        return grad_in, None
+
+
+def reflect_pad1(x, backend=None):
+    """nn.ReflectionPad2d(1) (layers.py:124); gather-form backward instead of ATen's atomics."""
+    return _ReflectPad1.apply(x, backend or default_backend())
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, backend):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        backend._check(x)
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty(N, C, OH, OW, device=x.device, dtype=torch.float32)
+        code = torch.empty(N, C, OH, OW, device=x.device, dtype=torch.uint8)
+        backend.run("bbd_maxpool3s2_fwd", x, ptr(x), ptr(out), ptr(code), N * C, H, W)
+        ctx.save_for_backward(code)
+        ctx.meta = (N, C, H, W, backend)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (code,) = ctx.saved_tensors
+        N, C, H, W, backend = ctx.meta
+        grad_out = grad_out.contiguous()
+        grad_in = torch.empty(N, C, H, W, device=grad_out.device, dtype=torch.float32)
+        backend.run("bbd_maxpool3s2_bwd", grad_out, ptr(grad_out), ptr(code), ptr(grad_in), N * C, H, W)
+        return grad_in, None
+
+
+def maxpool3s2(x, backend=None):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem."""
+    return _MaxPool3s2.apply(x, backend or default_backend())

@@ -235,6 +235,18 @@ int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const fl
                    float* grad_gamma, float* grad_beta, double* scratch, int N, int C, int HW, int relu,
                    void* stream);
 
+/* ReflectionPad2d(1) in front of every decoder convolution (layers.py:118-133) and the stem's
+ * MaxPool2d(kernel 3, stride 2, padding 1) (networks/resnet_encoder.py:28), forward and gather-form
+ * (atomic-free, deterministic) backward; `planes` = N*C, tensors NCHW fp32.
+ *   pad : in [planes,H,W] -> out [planes,H+2,W+2]
+ *   pool: in [planes,H,W] -> out [planes,OH,OW], OH = (H-1)/2+1; `code` u8 [planes,OH,OW] = position
+ *         0..8 of the maximum inside its window (ATen's tie / NaN rule), consumed by the backward */
+int bbd_reflect_pad1_fwd(const float* in, float* out, int planes, int H, int W, void* stream);
+int bbd_reflect_pad1_bwd(const float* grad_out, float* grad_in, int planes, int H, int W, void* stream);
+int bbd_maxpool3s2_fwd(const float* in, float* out, uint8_t* code, int planes, int H, int W, void* stream);
+int bbd_maxpool3s2_bwd(const float* grad_out, const uint8_t* code, float* grad_in, int planes, int H, int W,
+                       void* stream);
+
 /* Device self-test: the kernels replace hipcc's IEEE division sequence by a cheaper one that is
  * exact for moderate exponents (bbd_math.h).  Runs blocks*256*iters random operand tuples through
  * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */
