@@ -111,6 +111,7 @@ class OverlappedGradientAverager(GradientAverager):
             self.slices.append(flat.flat[lo:hi])          # reverse order keeps each bucket contiguous
             for i in idxs:
                 self.bucket_of[i] = b
+        self.streams = []          # HIP streams gradients may be produced on (set by attach())
         self._reset()
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -142,9 +143,21 @@ class OverlappedGradientAverager(GradientAverager):
         for i in self.buckets[b]:
             flat.params[i].grad = flat.views[i]
 
+    def _join_streams(self):
+        """The trainer runs the pose network on a second HIP stream, and autograd replays every backward
+        node (and fires this hook) on its forward stream: a bucket may hold gradients produced on the
+        other stream, so the stream that packs and hands the bucket to RCCL first waits for both."""
+        if not self.streams:
+            return
+        cur = torch.cuda.current_stream(self.flat.flat.device)
+        for st in self.streams:
+            if st != cur:
+                cur.wait_stream(st)
+
     def _launch_ready(self, force=False):
         while self.launched < len(self.buckets) and (force or self.pending[self.launched] == 0):
             b = self.launched
+            self._join_streams()
             self._pack_bucket(b)
             self.works.append(self._reduce(self.slices[b], async_op=True))
             self.launched += 1
@@ -197,4 +210,7 @@ def attach(trainer, group=None):
         bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
         trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket) if overlap
                              else GradientAverager(flat, group))
+        side = trainer._pose_stream() if hasattr(trainer, "_pose_stream") else None
+        if overlap and side is not None:
+            trainer.grad_sync.streams = [torch.cuda.default_stream(trainer.device), side]
     return flat

@@ -74,6 +74,14 @@ class Trainer:
         for m in self.models.values():
             m.eval()
 
+    def _pose_stream(self):
+        """Second HIP stream for the pose network (BBD_POSE_STREAM=0 disables it)."""
+        if self.device.type != "cuda" or os.environ.get("BBD_POSE_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        return self._side_stream
+
     def _backend(self):
         if self.backend is None:
             self.backend = ops.default_backend()
@@ -144,9 +152,24 @@ class Trainer:
         if is_train:
             self.valid_frames = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
             self.valid_frames_trimin(inputs)
-            outputs = self.predict_poses(inputs)
+            side = self._pose_stream()
+            if side is None:
+                outputs = self.predict_poses(inputs)
+            else:
+                # the pose network and the depth network are independent until the warp: run the pose
+                # passes on a second HIP stream so their small-grid layers overlap the depth network's
+                # (autograd replays each backward node on its forward stream, so the backward overlaps too)
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    outputs = self.predict_poses(inputs)
             feats = self.models["encoder"](inputs["color_aug", 0, 0])
             outputs.update(self.models["depth"](feats))
+            if side is not None:
+                main.wait_stream(side)
+                for v in outputs.values():              # produced on `side`, consumed on `main` from here on
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
             outputs.update(self.generate_images_pred(inputs, outputs))
             losses = self.compute_losses(inputs, outputs)
         else:
