@@ -114,8 +114,14 @@ class Trainer:
         if getattr(self.opt, "rand", False):
             self.opt.scales = [0, 1, 2, 3] if self.epoch < 10 else [0]
         last = None
+        log_frequency = getattr(self.opt, "log_frequency", 0)
         for self.batch_idx, inputs in enumerate(loader):
             last = self.train_step(inputs)
+            # the reference validates every `log_frequency` steps (trainer.py:266-283)
+            if log_frequency and self.batch_idx > 0 and self.batch_idx % log_frequency == 0:
+                val_loader = self.kitti_val_loader()
+                if val_loader is not None:
+                    self.last_val = self.val(val_loader)
         return last
 
     def kitti_loader(self, epoch):
@@ -135,6 +141,28 @@ class Trainer:
         return datasets.DeviceLoader(ds, opt.batch_size, collate, shuffle=True, drop_last=True,
                                      num_workers=getattr(opt, "num_workers", 8),
                                      seed=getattr(opt, "pytorch_random_seed", 0))
+
+    def kitti_val_loader(self):
+        """Validation split of trainer.py:127-131 + ground truth of :150-151, built once: `val_files.txt`
+        through the device loader (batch 16 instead of 1 - metrics are per image either way) and
+        `gt_depths.npz` packed into HBM.  None when the split files are not there (synthetic runs)."""
+        if getattr(self, "_val_loader", None) is not None or getattr(self, "_val_missing", False):
+            return getattr(self, "_val_loader", None)
+        from . import datasets
+        opt = self.opt
+        split = os.path.join(getattr(opt, "splits_dir", "splits"), "eigen_zhou")
+        files, gt = os.path.join(split, "val_files.txt"), os.path.join(split, "gt_depths.npz")
+        if not (getattr(opt, "kt_path", None) and os.path.isfile(files) and os.path.isfile(gt)):
+            self._val_missing = True
+            return None
+        import numpy as np
+        self.set_ground_truth(np.load(gt, fix_imports=True, encoding="latin1", allow_pickle=True)["data"])
+        ds = datasets.KITTIRAWDataset(datasets.readlines(files), 0, opt.height, opt.width, kt_path=opt.kt_path,
+                                      is_train=False, kt=True, naive_mix=True)
+        self._val_loader = datasets.DeviceLoader(ds, 16, datasets.DeviceCollate(opt.height, opt.width, [0], self.device,
+                                                                               self.backend),
+                                                 shuffle=False, drop_last=False, num_workers=getattr(opt, "num_workers", 8))
+        return self._val_loader
 
     def train(self, loader_factory=None, num_epochs=None):
         """`loader_factory(epoch)` -> iterable of batches (default: `kitti_loader`); checkpoints every

@@ -38,3 +38,32 @@ def test_train_step_on_loader_batches(tmp_path):
         if step == 2:
             break
     assert all(torch.isfinite(torch.tensor(losses))) and len(losses) == 3
+
+
+def test_training_loop_with_periodic_validation(tmp_path):
+    """Trainer.train() over the KITTI device loader with the reference's periodic validation
+    (val_files.txt + gt_depths.npz under splits/eigen_zhou), all from a synthetic tree."""
+    import numpy as np
+    from test_gpu_trainer import make_opt
+    from baseboostdepth_amd.trainer import Trainer
+    H, W, B = 64, 192, 4
+    root = tmp_path / "kitti"
+    lines = image_checks.make_kitti_tree(str(root), frames=20)
+    split = tmp_path / "splits" / "eigen_zhou"
+    split.mkdir(parents=True)
+    (split / "train_files_baselines.txt").write_text("\n".join(lines) + "\n")
+    val = [l.rsplit(" ", 2)[0] for l in lines][:6]
+    (split / "val_files.txt").write_text("\n".join(val) + "\n")
+    g = torch.Generator().manual_seed(0)
+    gts = np.empty(6, dtype=object)
+    for i in range(6):
+        gts[i] = (torch.rand(375, 1242, generator=g) * 70 * (torch.rand(375, 1242, generator=g) < 0.05)).numpy().astype(np.float32)
+    np.savez_compressed(split / "gt_depths.npz", data=gts)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.kt_path, opt.splits_dir, opt.training_file = str(root), str(tmp_path / "splits"), "train_files_baselines"
+    opt.rand, opt.num_workers, opt.log_frequency, opt.num_epochs, opt.pytorch_random_seed = True, 2, 2, 1, 0
+    tr = Trainer(opt)
+    tr.train()
+    assert tr.step == len(lines) // B
+    assert set(tr.last_val) == set(tr.depth_metric_names) and all(np.isfinite(v) for v in tr.last_val.values())
+    assert tr.best == tr.last_val["de/abs_rel"] or tr.best < tr.last_val["de/abs_rel"]
