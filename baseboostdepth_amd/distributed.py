@@ -64,18 +64,26 @@ class GradientAverager:
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self.use_avg = True
 
     def _reduce(self, tensor, async_op=False):
-        if self.backend == "nccl":          # RCCL: average in the collective
-            return dist.all_reduce(tensor, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        if self.backend == "nccl" and self.use_avg:      # RCCL: average in the collective
+            try:
+                return dist.all_reduce(tensor, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            except RuntimeError:                          # a build without ncclAvg: sum, divide afterwards
+                self.use_avg = False
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    @property
+    def divide_after(self):
+        return not (self.backend == "nccl" and self.use_avg)
 
     def __call__(self):
         self.flat.pack()
         if self.world == 1:
             return
         self._reduce(self.flat.flat)
-        if self.backend != "nccl":          # gloo (CPU tests) has no AVG
+        if self.divide_after:               # gloo (CPU tests) has no AVG
             self.flat.flat.div_(self.world)
 
 
@@ -166,7 +174,7 @@ class OverlappedGradientAverager(GradientAverager):
         self._launch_ready(force=True)
         for w in self.works:
             w.wait()
-        if self.backend != "nccl":
+        if self.divide_after:
             self.flat.flat.div_(self.world)
         self._reset()
 
