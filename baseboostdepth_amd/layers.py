@@ -5,7 +5,6 @@ Same names, constructor arguments and return shapes as the reference so that `tr
 kernels through the C ABI (include/bbd_hip.h), including the pose-matrix composition
 (`transformation_from_parameters`, one launch each way on GPU tensors).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .plan import STEREO, ReprojectionPlan, get_plan
+from .plan import STEREO
 from .layers import transformation_from_parameters
 
 

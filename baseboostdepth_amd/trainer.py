@@ -16,8 +16,7 @@ import torch
 import torch.optim as optim
 
 from . import networks, ops
-from .layers import (SSIM, BackprojectDepth, Project3D, compute_depth_errors, disp_to_depth, get_smooth_loss,
-                     transformation_from_parameters)
+from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
 from .plan import STEREO, get_plan
 
 

@@ -4,7 +4,6 @@ import numpy as np
 import torch
 
 from oracle import loader_ref
-from baseboostdepth_amd import imageops
 
 RESIZE_CASES = [(375, 1242, 192, 640), (370, 1226, 192, 640), (376, 1241, 192, 640),
                 (100, 300, 192, 640), (192, 640, 192, 640), (61, 77, 32, 64),

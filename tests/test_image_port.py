@@ -7,7 +7,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch
 from PIL import Image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

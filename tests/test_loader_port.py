@@ -2,7 +2,6 @@
 through the host port == the reference's per-item Pillow pipeline + custom_collate; frame-set selection
 against the oracle restatement and the split's published statistics."""
 import os
-import random
 import sys
 
 import numpy as np
