@@ -75,7 +75,8 @@ class ReflectionPad1(nn.ReflectionPad2d):
         super().__init__(1)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and min(x.shape[2:]) >= 2 and ops.FUSED_NN:
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and min(x.shape[2:]) >= 2 and ops.FUSED_NN
+                and x.shape[0] * x.shape[1] <= 65535):
             return ops.reflect_pad1(x)
         return super().forward(x)
 

@@ -42,7 +42,8 @@ class MaxPool3s2(nn.MaxPool2d):
 
     def forward(self, x):
         from .. import ops
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and ops.FUSED_NN:
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and ops.FUSED_NN
+                and x.shape[0] * x.shape[1] <= 65535):
             return ops.maxpool3s2(x)
         return super().forward(x)
 
