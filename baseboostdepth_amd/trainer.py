@@ -139,7 +139,8 @@ class Trainer:
         collate = datasets.DeviceCollate(opt.height, opt.width, opt.scales, self.device, self.backend)
         return datasets.DeviceLoader(ds, opt.batch_size, collate, shuffle=True, drop_last=True,
                                      num_workers=getattr(opt, "num_workers", 8),
-                                     seed=getattr(opt, "pytorch_random_seed", 0))
+                                     seed=getattr(opt, "pytorch_random_seed", 0),
+                                     workers=getattr(opt, "loader_workers", "process"))
 
     def kitti_val_loader(self):
         """Validation split of trainer.py:127-131 + ground truth of :150-151, built once: `val_files.txt`

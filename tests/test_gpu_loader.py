@@ -29,7 +29,8 @@ def test_train_step_on_loader_batches(tmp_path):
     tr = Trainer(opt)
     ds = datasets.KITTIRAWDataset(lines, 2, H, W, kt_path=str(tmp_path), rand=True, is_train=True, scales=opt.scales,
                                   kt=True, naive_mix=True, trimin=True, seed=5)
-    loader = datasets.DeviceLoader(ds, B, datasets.DeviceCollate(H, W, opt.scales, "cuda:0"), num_workers=4, seed=2)
+    loader = datasets.DeviceLoader(ds, B, datasets.DeviceCollate(H, W, opt.scales, "cuda:0"), num_workers=4, seed=2,
+                                   workers="process")       # decode in worker processes, frames through /dev/shm
     losses = []
     for step, batch in enumerate(loader):
         assert batch[("color", 0, 0)].is_cuda

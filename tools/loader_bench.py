@@ -21,14 +21,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batches", type=int, default=20)
+    ap.add_argument("--batches", type=int, default=100)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--mode", default="process", choices=["process", "thread"])
     a = ap.parse_args()
     import image_checks
     from baseboostdepth_amd import datasets
     tmp = tempfile.mkdtemp(prefix="bbd_kitti_")
-    lines = image_checks.make_kitti_tree(tmp, frames=40)
+    lines = image_checks.make_kitti_tree(tmp, frames=40) * 40      # 3 840 split lines over the same files
     H, W = 192, 640
     ds = datasets.KITTIRAWDataset(lines, 0, H, W, kt_path=tmp, rand=False, is_train=True, scales=[0, 1, 2, 3], kt=True,
                                   naive_mix=True, trimin=False, seed=1)
@@ -49,21 +50,21 @@ def main():
     dev_ms = e0.elapsed_time(e1) / 10
     frames = sum(len(r["images"]) for r in recipes)
     # end to end: decode on the pool + collate
-    loader = datasets.DeviceLoader(ds, a.batch, collate, num_workers=a.workers, prefetch=3, seed=0)
+    loader = datasets.DeviceLoader(ds, a.batch, collate, num_workers=a.workers, prefetch=3, seed=0, workers=a.mode)
     n, t0 = 0, None
     for i, batch in enumerate(loader):
-        if i == 2:
+        if i == 5:                       # past worker start-up and the prefetch backlog
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        if i >= 2:
+        if i >= 5:
             n += batch[("color", 0, 0)].shape[0]
-        if i == a.batches + 1:
+        if i == a.batches + 4:
             break
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"collate_device_ms_per_batch": round(dev_ms, 3), "collate_wall_ms_per_batch": round(wall * 1e3, 3),
                       "frames_per_batch": frames, "loader_samples_per_s": round((n - a.batch) / dt, 1),
-                      "loader_frames_per_s": round((n - a.batch) * frames / a.batch / dt, 1), "workers": a.workers,
+                      "loader_frames_per_s": round((n - a.batch) * frames / a.batch / dt, 1), "workers": a.workers, "mode": a.mode,
                       "cpu_count": os.cpu_count(), "batch": a.batch, "size": "1242x375 -> 640x192, 4 scales for frame 0"}))
 
 
