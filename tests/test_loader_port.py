@@ -57,3 +57,22 @@ def test_stereo_sign_and_eval_items(tmp_path):
     assert list(item["images"]) == [0] and not item["flip"] and not item["jitter"]
     batch = datasets.DeviceCollate(64, 128, [0], "cpu", HostPortBackend())([val[0], val[1]])
     assert batch[("color", 0, 0)].shape == (2, 3, 64, 128) and torch.equal(batch[("color", 0, 0)], batch[("color_aug", 0, 0)])
+
+
+def test_worker_processes_with_shared_ring_equal_thread_pool(tmp_path):
+    """Process workers decode into the shared-memory ring; batches equal the in-process thread pool's."""
+    lines = image_checks.make_kitti_tree(str(tmp_path), frames=20)
+    ds = datasets.KITTIRAWDataset(lines, 2, 64, 128, kt_path=str(tmp_path), rand=True, is_train=True, scales=[0, 1, 2, 3],
+                                  kt=True, naive_mix=True, trimin=True, seed=3)
+    col = datasets.DeviceCollate(64, 128, [0, 1, 2, 3], "cpu", HostPortBackend())
+    a = list(datasets.DeviceLoader(ds, 4, col, num_workers=2, seed=1, workers="process"))
+    b = list(datasets.DeviceLoader(ds, 4, col, num_workers=2, seed=1, workers="thread"))
+    assert len(a) == len(b) == len(lines) // 4
+    for x, y in zip(a, b):
+        assert set(x) == set(y)
+        for k in x:
+            if torch.is_tensor(x[k]) and x[k].dim() > 0:
+                assert torch.equal(x[k], y[k]), k
+            elif not torch.is_tensor(x[k]):
+                assert x[k] == y[k], k
+    assert datasets._RING is None                      # ring released at the end of the epoch
