@@ -100,7 +100,9 @@ class HipLibrary:
 
     @staticmethod
     def stream_for(tensor):
-        return ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+        # raw handle of torch's CURRENT stream on the tensor's device (the C accessor: this is on the
+        # path of every launch, torch.cuda.current_stream() builds a Python Stream object each time)
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(tensor.get_device()))
 
 
 _LIB = None
