@@ -43,6 +43,7 @@ _FLAGS = [
     ("--post_process", dict(action="store_true")),
     # this build
     ("--materialize_warps", dict(action="store_true")), ("--synthetic", dict(action="store_true")),
+    ("--step_graph", dict(action="store_true")), ("--loader_workers", dict(type=str, default="process", choices=["process", "thread"])),
 ]
 # other zoos / datasets of the reference: parsed, refused when set
 _OUT_OF_SCOPE = ["--SYNS_eval", "--SQL", "--SQL_L", "--CA_depth", "--DIFFNet", "--ViT", "--chamfer", "--stereo_guide",

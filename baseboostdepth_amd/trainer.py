@@ -50,7 +50,10 @@ class Trainer:
         # same Adam hyper-parameters as the reference (trainer.py:111); on the GPU the single-kernel
         # "fused" implementation replaces ~20 multi-tensor launches per step
         fused = self.device.type == "cuda" and getattr(opt, "fused_adam", True)
-        self.model_optimizer = optim.Adam(self.parameters_to_train, opt.learning_rate, fused=fused)
+        self.use_graph = bool(fused and (getattr(opt, "step_graph", False) or os.environ.get("BBD_STEP_GRAPH") == "1"))
+        self.model_optimizer = optim.Adam(self.parameters_to_train, opt.learning_rate, fused=fused,
+                                          capturable=self.use_graph)
+        self._graphs = {}
         self.model_lr_scheduler = optim.lr_scheduler.MultiStepLR(
             self.model_optimizer, milestones=[11, 13, 15, 16, 17, 18, 19], gamma=0.4)
         if getattr(opt, "load_weights_folder", "None") not in (None, "None"):
@@ -87,10 +90,55 @@ class Trainer:
         return self.backend
 
     # ------------------------------------------------------------------ the step (trainer.py:250-263)
+    # ------------------------------------------------------------------ whole-step hipGraph (opt-in)
+    def _graph_key(self, inputs):
+        """Batches that replay the same graph: same candidate plan, same tensor shapes, same lr."""
+        shapes = tuple(sorted((str(k), tuple(v.shape)) for k, v in inputs.items() if torch.is_tensor(v) and v.is_cuda))
+        return (str(inputs["ordering"]), str(inputs.get("frames")), float(inputs["cutt"]), tuple(self.opt.scales), shapes,
+                tuple(g["lr"] for g in self.model_optimizer.param_groups))
+
+    def _graph_step(self, inputs):
+        """Capture `process_batch + backward + optimizer.step` for this batch signature once, then replay it:
+        ~1 340 launches per step become one hipGraphLaunch, which takes the training thread's 16 ms of
+        launch work off the host (BaseBoostDepth's `--rand` batches change their frame sets per batch, so
+        they keep the eager path; fixed-frame-set training - the MD2 baseline - replays)."""
+        key = self._graph_key(inputs)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inputs.items()}
+            warm = torch.cuda.Stream(device=self.device)
+            warm.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(warm):                       # eager warm-up: caches, MIOpen solutions, Adam state
+                for _ in range(3):
+                    self._eager_step(dict(static))
+            torch.cuda.current_stream(self.device).wait_stream(warm)
+            self.model_optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outputs, losses = self.process_batch(dict(static))
+                losses["loss"].backward()
+                self.model_optimizer.step()
+            entry = self._graphs[key] = (graph, static, outputs, losses)
+        graph, static, outputs, losses = entry
+        for k, v in inputs.items():
+            if torch.is_tensor(v) and v.is_cuda:
+                static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        self.step += 1
+        return outputs, losses
+
     def train_step(self, inputs):
         """One optimisation step on a collated batch, as the body of `run_epoch` does it."""
         if "frames" in inputs:
             self.opt.frame_ids = sorted(inputs["frames"], key=_frame_sort_key)
+        if self.use_graph and self.grad_sync is None and self.device.type == "cuda":
+            for key, ipt in inputs.items():
+                if key not in ["frames", "ordering", "cutt"] and torch.is_tensor(ipt):
+                    inputs[key] = ipt.to(self.device, non_blocking=True)
+            return self._graph_step(inputs)
+        return self._eager_step(inputs)
+
+    def _eager_step(self, inputs):
         outputs, losses = self.process_batch(inputs)
         if self.flat_grads is not None:
             self.flat_grads.zero()
@@ -195,9 +243,10 @@ class Trainer:
             outputs.update(self.models["depth"](feats))
             if side is not None:
                 main.wait_stream(side)
-                for v in outputs.values():              # produced on `side`, consumed on `main` from here on
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(main)
+                if not torch.cuda.is_current_stream_capturing():
+                    for v in outputs.values():          # produced on `side`, consumed on `main` from here on
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
             outputs.update(self.generate_images_pred(inputs, outputs))
             losses = self.compute_losses(inputs, outputs)
         else:

@@ -176,3 +176,34 @@ def test_two_ranks_on_one_gpu_exchange_gradients():
                           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "tools", "ddp_check.py")],
                          env=env, capture_output=True, text=True, timeout=900)
     assert "DDP_CHECK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+def test_step_graph_replay_matches_eager():
+    """Opt-in whole-step hipGraph (`opt.step_graph`): capture after three eager warm-up steps, then every
+    batch with the same signature is one graph launch.  Same parameters as the eager loop on the same
+    batch sequence (up to MIOpen's atomically accumulated weight gradients)."""
+    import warnings
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, B = 96, 320, 4
+    batches = [synthetic_batch([1] * B, H, W, [0, 1, 2, 3], device=DEV, seed=20 + i) for i in range(3)]
+
+    def run(graph):
+        opt = make_opt(H, W, B, [0, 1, 2, 3], False)
+        opt.step_graph = graph
+        torch.manual_seed(5)
+        tr = Trainer(opt)
+        tr.set_train()
+        seq = [0, 1, 2, 1] if graph else [0, 0, 0, 0, 1, 2, 1]     # the graph's first call = 3 warm-ups + 1 replay
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in seq:
+                _, losses = tr.train_step(dict(batches[i]))
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"]), tr
+
+    pe, le, _ = run(False)
+    pg, lg, trg = run(True)
+    assert trg.use_graph and len(trg._graphs) == 1 and trg.step == 7
+    assert abs(le - lg) < 5e-3 * abs(le)
+    assert float((pe - pg).abs().max()) < 2e-3 * float(pe.abs().max())     # 7 Adam steps of lr 1e-4 on O(1) weights
