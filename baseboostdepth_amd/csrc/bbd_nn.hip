@@ -37,6 +37,7 @@ struct BnArgs {
   float* invstd;         // [C]
   float* run_mean;       // [C] or NULL
   float* run_var;        // [C] or NULL
+  long long* batches;    // num_batches_tracked (int64 scalar) or NULL
   // backward
   const float* dy;
   float* dx;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
         a.run_mean[c] = (1.0f - a.momentum) * a.run_mean[c] + a.momentum * (float)mean;
         a.run_var[c] = (1.0f - a.momentum) * a.run_var[c] + a.momentum * (float)unbiased;
       }
+      if (a.batches && c == 0) *a.batches += 1;
     }
   }
   __syncthreads();
@@ -397,14 +399,15 @@ extern "C" {
 int bbd_bn_scratch_doubles(int N, int C, int HW) { return C * pick_split(N, HW) * 2; }
 
 int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
-                   float* save_mean, float* save_invstd, float* running_mean, float* running_var, double* scratch,
-                   int N, int C, int HW, double eps, double momentum, int relu, void* stream) {
+                   float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                   long long* num_batches_tracked, double* scratch, int N, int C, int HW, double eps, double momentum,
+                   int relu, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch || N <= 0 || C <= 0 || HW <= 0)
     return BBD_E_BADARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return BBD_E_BADARG;
   BnArgs a = {};
   a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.y = y; a.part = scratch; a.mean = save_mean;
-  a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.N = N; a.C = C; a.HW = HW;
+  a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.batches = num_batches_tracked; a.N = N; a.C = C; a.HW = HW;
   a.split = pick_split(N, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)a.split, (unsigned)C);

@@ -25,9 +25,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         if (self.fused and x.is_cuda and self.training and self.affine and self.track_running_stats
                 and self.momentum is not None and x.dtype == torch.float32 and x.dim() == 4):
             from .. import ops
-            self.num_batches_tracked.add_(1)
             return ops.batch_norm_act(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
-                                      self.momentum, self.eps, relu)
+                                      self.momentum, self.eps, relu, num_batches_tracked=self.num_batches_tracked)
         y = super().forward(x)
         if residual is not None:
             y = y + residual

@@ -328,7 +328,7 @@ class _BatchNormAct(torch.autograd.Function):
     (csrc/bbd_nn.hip) - the tail of every ResNet block of the encoders."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, backend):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, batches, momentum, eps, relu, backend):
         x = x.contiguous()
         N, C, H, W = x.shape
         if residual is not None:
@@ -340,7 +340,7 @@ class _BatchNormAct(torch.autograd.Function):
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
         scratch = torch.empty(backend.lib.bn_scratch_doubles(N, C, H * W), device=x.device, dtype=torch.float64)
         backend.run("bbd_bn_act_fwd", x, ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd),
-                    ptr(running_mean), ptr(running_var), ptr(scratch), N, C, H * W, float(eps), float(momentum),
+                    ptr(running_mean), ptr(running_var), ptr(batches), ptr(scratch), N, C, H * W, float(eps), float(momentum),
                     int(relu))
         ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
         ctx.meta = (bool(relu), residual is not None, backend)
@@ -359,12 +359,13 @@ class _BatchNormAct(torch.autograd.Function):
         scratch = torch.empty(backend.lib.bn_scratch_doubles(N, C, H * W), device=x.device, dtype=torch.float64)
         backend.run("bbd_bn_act_bwd", x, ptr(x), ptr(y), ptr(grad_y), ptr(weight), ptr(mean), ptr(invstd), ptr(grad_x),
                     ptr(grad_res), ptr(grad_w), ptr(grad_b), ptr(scratch), N, C, H * W, int(relu))
-        return grad_x, grad_w, grad_b, grad_res, None, None, None, None, None, None
+        return grad_x, grad_w, grad_b, grad_res, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, backend=None):
-    return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu,
-                               backend or default_backend())
+def batch_norm_act(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, backend=None,
+                   num_batches_tracked=None):
+    return _BatchNormAct.apply(x, weight, bias, residual, running_mean, running_var, num_batches_tracked, momentum,
+                               eps, relu, backend or default_backend())
 
 
 # ---------------------------------------------------------------------------- ReflectionPad2d(1), MaxPool2d(3,2,1)
