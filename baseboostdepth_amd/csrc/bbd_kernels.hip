@@ -105,7 +105,8 @@ struct Cells {
   int lds[N];    // r * STRIDE + c
   int pix[N];    // yy * W + xx of the (reflected) image pixel
   int xy[N];     // yy << 16 | xx
-  int own[N];    // 1 if the cell is an un-reflected interior pixel this tile owns (warped output)
+  int own[N];    // 0, or 1 + (r-HALO)*(COLS-2*HALO) + (c-HALO) if the cell is an un-reflected interior pixel
+                 // this tile owns (warped output, sample-derivative planes)
 
   __device__ __forceinline__ void init(int H, int W, int tx0, int ty0) {
 #pragma unroll
@@ -118,7 +119,8 @@ struct Cells {
       lds[k] = r * STRIDE + c;
       pix[k] = yy * W + xx;
       xy[k] = (yy << 16) | xx;
-      own[k] = (py == yy && px == xx && r >= HALO && r < ROWS - HALO && c >= HALO && c < COLS - HALO) ? 1 : 0;
+      own[k] = (py == yy && px == xx && r >= HALO && r < ROWS - HALO && c >= HALO && c < COLS - HALO)
+                   ? 1 + (r - HALO) * (COLS - 2 * HALO) + (c - HALO) : 0;
     }
   }
 };
@@ -153,7 +155,7 @@ template <typename CellsT, int PLANE>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
-                                              float* __restrict__ warped_out) {
+                                              float* __restrict__ warped_out, float (*dv)[TH * TW] = nullptr) {
   // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
@@ -177,12 +179,14 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
 #pragma unroll
   for (int k0 = 0; k0 < CellsT::N; k0 += BATCH) {
     BbdTaps t[BATCH];
+    int clip[BATCH];
 #pragma unroll
     for (int kk = 0; kk < BATCH; ++kk) {
       const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
       BbdSample sm;
       bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
       bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
+      clip[kk] = sm.clipx | (sm.clipy << 1);
     }
     float v[BATCH][3][4];
 #pragma unroll
@@ -211,6 +215,17 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
         o[0] = val[0];
         o[hw] = val[1];
         o[2 * hw] = val[2];
+      }
+      if (dv != nullptr && cl.own[k]) {
+        // backward: d warped / d (ix, iy) of the tile's own pixels from the taps already in registers
+        // (zero where the border clamp is active), so the sample-gradient phase needs no gathers
+        const int ci = cl.own[k] - 1;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float* vv = v[kk][ch];
+          dv[ch][ci] = (clip[kk] & 1) ? 0.0f : (vv[1] - vv[0]) * t[kk].s + (vv[3] - vv[2]) * t[kk].n;
+          dv[3 + ch][ci] = (clip[kk] & 2) ? 0.0f : (vv[2] - vv[0]) * t[kk].e + (vv[3] - vv[1]) * t[kk].w;
+        }
       }
     }
   }
@@ -516,6 +531,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE + 8];
   __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE];  // {A,B,C} of the channel in flight, sparse
   __shared__ uint16_t s_list[CH * CW];                            // coefficient cells won by the candidate
+  __shared__ __attribute__((aligned(16))) float s_dv[6][TH * TW];   // d warped_c / d ix (0..2), / d iy (3..5)
   __shared__ float s_red[4][12];
   __shared__ unsigned s_present;
   __shared__ int s_count;
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
     }
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds(src, dcell, pose_row, dm, hw, cl, s_x, nullptr);
+    warp_into_lds(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
@@ -762,30 +778,27 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
       float pj[21];
 #pragma unroll
       for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
+      // coordinate derivatives of this thread's 4 pixels, left in LDS by the warp phase
+      float dxy[6][PPT];
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) {
+        const float4 q = *reinterpret_cast<const float4*>(&s_dv[pl][ly * TW + lx0]);
+        dxy[pl][0] = q.x; dxy[pl][1] = q.y; dxy[pl][2] = q.z; dxy[pl][3] = q.w;
+      }
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         const int qx = qx0 + j;
         if (qx >= W) continue;
         if (gx[0][j] == 0.0f && gx[1][j] == 0.0f && gx[2][j] == 0.0f) continue;
+        const float gix = gx[0][j] * dxy[0][j] + gx[1][j] * dxy[1][j] + gx[2][j] * dxy[2][j];
+        const float giy = gx[0][j] * dxy[3][j] + gx[1][j] * dxy[4][j] + gx[2][j] * dxy[5][j];
         BbdSample sm;
-        bbd_project(pj, qx, qy, qdepth[j], dm, &sm);
-        BbdTaps t;
-        bbd_taps(sm.ix, sm.iy, dm, &t);
-        float gix = 0.0f, giy = 0.0f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float v[4];
-          bbd_fetch4(src + ch * hw, &t, v);
-          bbd_bilerp_grad(v, &t, gx[ch][j], &gix, &giy);
-        }
+        bbd_sample_smooth(pj, qx, qy, qdepth[j], &sm);
         float gd, gp1[12];
         bbd_project_grad(pj, &sm, gix, giy, &gd, gp1);
         gdepth[j] += gd;
 #pragma unroll
         for (int k = 0; k < 12; ++k) gP[k] += gp1[k];
-        // keep the four pixels' projections from being interleaved (register peak of the kernel).
-        // Measured: issuing 2 or 4 pixels' gathers together before the arithmetic is 2-7 % SLOWER.
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (cd.kind & FLAG_NO_POSE_GRAD) {

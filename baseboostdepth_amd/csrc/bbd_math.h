@@ -189,6 +189,31 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const Bb
   o->iy = iy < hm1 ? iy : hm1;
 }
 
+/* Backward only: the smooth factors of the projection chain rule (no texel selection depends on them,
+ * so the refined-reciprocal division is enough); the clamp is already folded into the stored coordinate
+ * derivatives, hence clipx = clipy = 0 here. */
+BBD_HD void bbd_sample_smooth(const float* proj, int xx, int yy, float depth, BbdSample* o) {
+  const float* P = proj;
+  const float* iK = proj + 12;
+  const float fx = (float)xx, fy = (float)yy;
+  o->cx = bbd_dot3_hom(iK, fx, fy);
+  o->cy = bbd_dot3_hom(iK + 3, fx, fy);
+  o->cz = bbd_dot3_hom(iK + 6, fx, fy);
+  o->X = depth * o->cx;
+  o->Y = depth * o->cy;
+  o->Z = depth * o->cz;
+  const float qx = bbd_dot4_hom(P, o->X, o->Y, o->Z);
+  const float qy = bbd_dot4_hom(P + 4, o->X, o->Y, o->Z);
+  o->zi = bbd_dot4_hom(P + 8, o->X, o->Y, o->Z) + BBD_EPS;
+  const float rz = bbd_rcp_approx(o->zi);
+  o->u = qx * rz;
+  o->v = qy * rz;
+  o->ix = o->u;
+  o->iy = o->v;
+  o->clipx = 0;
+  o->clipy = 0;
+}
+
 struct BbdTaps {
   int i0, i1;        /* element offsets (inside one channel plane) of the north and south texel pairs */
   float w, e, n, s;  /* distances: w = ix-x0, e = 1-w, n = iy-y0, s = 1-n */
