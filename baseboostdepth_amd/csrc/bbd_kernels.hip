@@ -22,6 +22,13 @@
 #include "../../include/bbd_hip.h"
 #include "bbd_math.h"
 
+#ifndef BBD_WARP_BATCH
+#define BBD_WARP_BATCH 3
+#endif
+#ifndef BBD_BWD_WARP_BATCH
+#define BBD_BWD_WARP_BATCH 2
+#endif
+
 namespace {
 
 constexpr int TW = 64;   // tile width  (pixels)
@@ -151,7 +158,7 @@ __device__ __forceinline__ void load_depth(const float* __restrict__ depth, cons
 }
 
 // Warp one source image into the staged region for one pose-table row.
-template <typename CellsT, int PLANE>
+template <int BATCH, typename CellsT, int PLANE>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
@@ -171,11 +178,8 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
 #endif
   // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
   // its gathers are in flight together (6 x 8-byte loads per cell), then the blends.  The batch
-  // size trades loads in flight against VGPRs (occupancy); BBD_WARP_BATCH is a tuning knob.
-#ifndef BBD_WARP_BATCH
-#define BBD_WARP_BATCH 3
-#endif
-  constexpr int BATCH = BBD_WARP_BATCH;
+  // size trades loads in flight against VGPRs (occupancy): measured best at 3 cells for the forward
+  // (3 waves/SIMD) and 2 for the backward (2 waves/SIMD); BBD_WARP_BATCH / BBD_BWD_WARP_BATCH override.
 #pragma unroll
   for (int k0 = 0; k0 < CellsT::N; k0 += BATCH) {
     BbdTaps t[BATCH];
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
       float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
       BBD_STAMP(4 + 4 * (c & 3));
-      warp_into_lds(src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
+      warp_into_lds<BBD_WARP_BATCH>(src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
       BBD_STAMP(5 + 4 * (c & 3));
       __syncthreads();
       BBD_STAMP(6 + 4 * (c & 3));
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
     }
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
+    warp_into_lds<BBD_BWD_WARP_BATCH>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
