@@ -56,6 +56,9 @@ SIGNATURES = {
     "bbd_reflect_pad1_bwd": [_p, _p, _i, _i, _i, _p],
     "bbd_maxpool3s2_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_maxpool3s2_bwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_dispconv_scratch_doubles": [_i],
+    "bbd_dispconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "bbd_dispconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
 }
 RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4
@@ -92,6 +95,9 @@ class HipLibrary:
 
     def bn_scratch_doubles(self, N, C, HW):
         return self._dll.bbd_bn_scratch_doubles(N, C, HW)
+
+    def dispconv_scratch_doubles(self, C):
+        return self._dll.bbd_dispconv_scratch_doubles(C)
 
     def call(self, name, *args):
         rc = getattr(self._dll, name)(*args)

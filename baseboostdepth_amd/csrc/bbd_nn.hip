@@ -378,6 +378,192 @@ __global__ __launch_bounds__(RW * RR) void maxpool3s2_bwd_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Disparity head of the depth decoder: Conv3x3(C -> 1) = ReflectionPad2d(1) + Conv2d(C, 1, 3) + bias
+// (layers.py:118-133, networks/depth_decoder.py:38-39, C = 16/32/64/128 at 192x640 .. 24x80).  With one
+// output channel the layer is a pure streaming reduction over C input planes; MIOpen runs it at
+// ~2.4 TFLOP/s (0.54 ms for C=16 at full resolution, forward+backward).  Here: one pass over x each way,
+// reflection handled by index (no padded copy), weights in LDS, deterministic weight-gradient partials.
+// ---------------------------------------------------------------------------------------------
+constexpr int DC_MAXC = 256;
+constexpr int DC_CHUNKS = 64;
+
+// 3 rows x 6 columns (px0-1 .. px0+4, reflected at the image border) of one plane around a 4-pixel strip
+__device__ __forceinline__ void load_strip_window(const float* __restrict__ plane, int r0, int r1, int r2, int px0,
+                                                  int cl, int cr, float win[3][6]) {
+  const int rows[3] = {r0, r1, r2};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float4 m = *reinterpret_cast<const float4*>(plane + rows[r] + px0);
+    win[r][0] = plane[rows[r] + cl];
+    win[r][1] = m.x; win[r][2] = m.y; win[r][3] = m.z; win[r][4] = m.w;
+    win[r][5] = plane[rows[r] + cr];
+  }
+}
+
+// One thread = 4 adjacent output pixels (W % 4 == 0: the strips and their 16-byte loads stay aligned);
+// per channel 3 x (float4 + 2 scalars) loads feed 36 multiply-adds.  Other widths: one pixel per thread.
+__global__ __launch_bounds__(NT) void dispconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int C, int H, int W) {
+  __shared__ float sw[DC_MAXC * 9];
+  for (int i = threadIdx.x; i < C * 9; i += NT) sw[i] = w[i];
+  __syncthreads();
+  const int hw = H * W;
+  const size_t n = blockIdx.y;
+  const float b = bias ? bias[0] : 0.0f;
+  if ((W & 3) == 0) {
+    const int strips = hw >> 2;
+    for (int t = blockIdx.x * NT + threadIdx.x; t < strips; t += gridDim.x * NT) {
+      const int p = t << 2;
+      const int py = p / W, px0 = p - py * W;
+      const int r0 = reflect1(py, H) * W, r1 = py * W, r2 = reflect1(py + 2, H) * W;
+      const int cl = reflect1(px0, W), cr = reflect1(px0 + 5, W);
+      float acc[4] = {b, b, b, b};
+      const float* xc = x + n * C * hw;
+      for (int c = 0; c < C; ++c, xc += hw) {
+        const float* k = sw + c * 9;
+        float win[3][6];
+        load_strip_window(xc, r0, r1, r2, px0, cl, cr, win);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] += (k[0] * win[0][j] + k[1] * win[0][j + 1] + k[2] * win[0][j + 2]) +
+                    (k[3] * win[1][j] + k[4] * win[1][j + 1] + k[5] * win[1][j + 2]) +
+                    (k[6] * win[2][j] + k[7] * win[2][j + 1] + k[8] * win[2][j + 2]);
+      }
+      *reinterpret_cast<float4*>(y + n * hw + p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    return;
+  }
+  for (int p = blockIdx.x * NT + threadIdx.x; p < hw; p += gridDim.x * NT) {
+    const int py = p / W, px = p - py * W;
+    const int r0 = reflect1(py, H) * W, r1 = py * W, r2 = reflect1(py + 2, H) * W;
+    const int c0 = reflect1(px, W), c2 = reflect1(px + 2, W);
+    float acc = b;
+    const float* xc = x + n * C * hw;
+    for (int c = 0; c < C; ++c, xc += hw) {
+      const float* k = sw + c * 9;
+      acc += (k[0] * xc[r0 + c0] + k[1] * xc[r0 + px] + k[2] * xc[r0 + c2]) +
+             (k[3] * xc[r1 + c0] + k[4] * xc[r1 + px] + k[5] * xc[r1 + c2]) +
+             (k[6] * xc[r2 + c0] + k[7] * xc[r2 + px] + k[8] * xc[r2 + c2]);
+    }
+    y[n * hw + p] = acc;
+  }
+}
+
+// grad wrt x:  gx[n,c,q] = sum_d w[c][d] * G_d(q),  G_d(q) = sum over the padded positions (u,v) that
+// read q of g[n, u - dy, v - dx] (zero outside the image) - G_d is shared by all channels.
+__global__ __launch_bounds__(NT) void dispconv_bwd_data_kernel(const float* __restrict__ gy,
+                                                               const float* __restrict__ w, float* __restrict__ gx,
+                                                               int C, int H, int W) {
+  __shared__ float sw[DC_MAXC * 9];
+  for (int i = threadIdx.x; i < C * 9; i += NT) sw[i] = w[i];
+  __syncthreads();
+  const int hw = H * W;
+  const size_t n = blockIdx.y;
+  const float* g = gy + n * hw;
+  for (int q = blockIdx.x * NT + threadIdx.x; q < hw; q += gridDim.x * NT) {
+    const int qy = q / W, qx = q - qy * W;
+    int us[3], vs[3], nu = 0, nv = 0;          // padded coordinates (0..H+1, 0..W+1) mapping onto (qy, qx)
+    us[nu++] = qy + 1;
+    if (qy == 1) us[nu++] = 0;
+    if (qy == H - 2) us[nu++] = H + 1;
+    vs[nv++] = qx + 1;
+    if (qx == 1) vs[nv++] = 0;
+    if (qx == W - 2) vs[nv++] = W + 1;
+    float G[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) G[d] = 0.0f;
+    for (int a = 0; a < nu; ++a)
+      for (int b = 0; b < nv; ++b) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int py = us[a] - dy;           // output row whose window row dy sits on padded row us[a]
+          if (py < 0 || py >= H) continue;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int px = vs[b] - dx;
+            if (px < 0 || px >= W) continue;
+            G[dy * 3 + dx] += g[py * W + px];
+          }
+        }
+      }
+    float* o = gx + n * C * hw + q;
+    for (int c = 0; c < C; ++c, o += hw) {
+      const float* k = sw + c * 9;
+      *o = ((k[0] * G[0] + k[1] * G[1] + k[2] * G[2]) + (k[3] * G[3] + k[4] * G[4] + k[5] * G[5])) +
+           (k[6] * G[6] + k[7] * G[7] + k[8] * G[8]);
+    }
+  }
+}
+
+// grad wrt w (and bias): block (chunk, c) accumulates its slice of the N*H*W pixels; fp64 partials.
+__global__ __launch_bounds__(NT) void dispconv_bwd_weight_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ gy,
+                                                                 double* __restrict__ part, int N, int C, int H,
+                                                                 int W) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y, hw = H * W;
+  float acc[10];
+#pragma unroll
+  for (int d = 0; d < 10; ++d) acc[d] = 0.0f;
+  if ((W & 3) == 0) {
+    const long long strips = ((long long)N * hw) >> 2;
+    for (long long t = (long long)blockIdx.x * NT + threadIdx.x; t < strips; t += (long long)gridDim.x * NT) {
+      const long long i = t << 2;
+      const int n = (int)(i / hw), p = (int)(i - (long long)n * hw);
+      const int py = p / W, px0 = p - py * W;
+      const float4 g4 = *reinterpret_cast<const float4*>(gy + i);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      const float* xc = x + ((size_t)n * C + c) * hw;
+      float win[3][6];
+      load_strip_window(xc, reflect1(py, H) * W, py * W, reflect1(py + 2, H) * W, px0, reflect1(px0, W),
+                        reflect1(px0 + 5, W), win);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc[r * 3 + d] += g[j] * win[r][j + d];
+        acc[9] += g[j];
+      }
+    }
+  } else {
+    const long long total = (long long)N * hw;
+    for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < total; i += (long long)gridDim.x * NT) {
+      const int n = (int)(i / hw), p = (int)(i - (long long)n * hw);
+      const int py = p / W, px = p - py * W;
+      const float g = gy[i];
+      const float* xc = x + ((size_t)n * C + c) * hw;
+      const int r0 = reflect1(py, H) * W, r1 = py * W, r2 = reflect1(py + 2, H) * W;
+      const int c0 = reflect1(px, W), c2 = reflect1(px + 2, W);
+      acc[0] += g * xc[r0 + c0]; acc[1] += g * xc[r0 + px]; acc[2] += g * xc[r0 + c2];
+      acc[3] += g * xc[r1 + c0]; acc[4] += g * xc[r1 + px]; acc[5] += g * xc[r1 + c2];
+      acc[6] += g * xc[r2 + c0]; acc[7] += g * xc[r2 + px]; acc[8] += g * xc[r2 + c2];
+      acc[9] += g;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 10; ++d) {
+    const double t = block_sum((double)acc[d], sh);
+    if (threadIdx.x == 0) part[((size_t)blockIdx.x * C + c) * 10 + d] = t;
+  }
+}
+
+// one wave per output: lanes = chunks (DC_CHUNKS == 64), fixed-order butterfly
+__global__ __launch_bounds__(64) void dispconv_bwd_weight_final_kernel(const double* __restrict__ part,
+                                                                      float* __restrict__ gw, float* __restrict__ gb,
+                                                                      int C) {
+  const int i = blockIdx.x;                    // 0 .. C*9 (the last one is the bias)
+  const int c = i < C * 9 ? i / 9 : 0, d = i < C * 9 ? i - c * 9 : 9;
+  double v = part[((size_t)threadIdx.x * C + c) * 10 + d];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if (threadIdx.x == 0) {
+    if (i < C * 9) gw[i] = (float)v;
+    else if (gb) gb[0] = (float)v;
+  }
+}
+
 int pick_split(int N, int HW) {
   long long per = (long long)N * HW;
   int s = (int)((per + 4095) / 4096);
@@ -461,6 +647,37 @@ int bbd_maxpool3s2_bwd(const float* grad_out, const uint8_t* code, float* grad_i
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((OH + RR - 1) / RR), (unsigned)planes), dim3(RW, RR), 0,
                      static_cast<hipStream_t>(stream), grad_out, code, grad_in, H, W, OH, OW);
+  return status();
+}
+
+int bbd_dispconv_scratch_doubles(int C) { return DC_CHUNKS * C * 10; }
+
+int bbd_dispconv_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int H, int W,
+                     void* stream) {
+  if (!x || !weight || !y || N <= 0 || C <= 0 || C > DC_MAXC || H < 2 || W < 2) return BBD_E_BADARG;
+  const int hw = H * W;
+  const int work = (W & 3) == 0 ? hw / 4 : hw;
+  const unsigned gx = (unsigned)((work + NT - 1) / NT);
+  hipLaunchKernelGGL(dispconv_fwd_kernel, dim3(gx, (unsigned)N), dim3(NT), 0, static_cast<hipStream_t>(stream), x,
+                     weight, bias, y, C, H, W);
+  return status();
+}
+
+int bbd_dispconv_bwd(const float* x, const float* weight, const float* grad_y, float* grad_x, float* grad_weight,
+                     float* grad_bias, double* scratch, int N, int C, int H, int W, void* stream) {
+  if (!x || !weight || !grad_y || !scratch || N <= 0 || C <= 0 || C > DC_MAXC || H < 2 || W < 2) return BBD_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int hw = H * W;
+  if (grad_x)
+    hipLaunchKernelGGL(dispconv_bwd_data_kernel, dim3((unsigned)((hw + NT - 1) / NT), (unsigned)N), dim3(NT), 0, st,
+                       grad_y, weight, grad_x, C, H, W);
+  if (grad_weight) {
+    hipLaunchKernelGGL(dispconv_bwd_weight_kernel, dim3((unsigned)DC_CHUNKS, (unsigned)C), dim3(NT), 0, st, x, grad_y,
+                       scratch, N, C, H, W);
+    static_assert(DC_CHUNKS == 64, "the final reduction maps chunks onto the 64 lanes of a wave");
+    hipLaunchKernelGGL(dispconv_bwd_weight_final_kernel, dim3((unsigned)(C * 9 + 1)), dim3(64), 0, st, scratch,
+                       grad_weight, grad_bias, C);
+  }
   return status();
 }
 

@@ -90,6 +90,9 @@ class Conv3x3(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x):
+        if (self.conv.out_channels == 1 and x.is_cuda and x.dtype == torch.float32 and ops.FUSED_NN
+                and isinstance(self.pad, ReflectionPad1) and self.conv.in_channels <= 256 and min(x.shape[2:]) >= 2):
+            return ops.dispconv(x, self.conv.weight, self.conv.bias)    # disparity head: one streaming kernel
         return self.conv(self.pad(x))
 
 

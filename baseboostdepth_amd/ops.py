@@ -421,3 +421,38 @@ class _MaxPool3s2(torch.autograd.Function):
 def maxpool3s2(x, backend=None):
     """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem."""
     return _MaxPool3s2.apply(x, backend or default_backend())
+
+
+# ---------------------------------------------------------------------------- disparity head Conv3x3(C -> 1)
+class _DispConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, backend):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        w = weight.contiguous()
+        backend._check(x, w, bias)
+        y = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
+        backend.run("bbd_dispconv_fwd", x, ptr(x), ptr(w), ptr(bias), ptr(y), N, C, H, W)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (bias is not None, backend)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, w = ctx.saved_tensors
+        has_bias, backend = ctx.meta
+        N, C, H, W = x.shape
+        grad_y = grad_y.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        grad_x = torch.empty_like(x) if need_x else None
+        grad_w = torch.empty_like(w) if need_w else None
+        grad_b = torch.empty(1, device=x.device, dtype=torch.float32) if (need_w and has_bias) else None
+        scratch = torch.empty(backend.lib.dispconv_scratch_doubles(C), device=x.device, dtype=torch.float64)
+        backend.run("bbd_dispconv_bwd", x, ptr(x), ptr(w), ptr(grad_y), ptr(grad_x), ptr(grad_w), ptr(grad_b),
+                    ptr(scratch), N, C, H, W)
+        return grad_x, grad_w, grad_b, None
+
+
+def dispconv(x, weight, bias, backend=None):
+    """layers.Conv3x3(C, 1): reflection pad + 3x3 convolution to ONE channel + bias (the decoder's disparity heads)."""
+    return _DispConv.apply(x, weight, bias, backend or default_backend())

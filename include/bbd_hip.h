@@ -248,6 +248,16 @@ int bbd_maxpool3s2_fwd(const float* in, float* out, uint8_t* code, int planes, i
 int bbd_maxpool3s2_bwd(const float* grad_out, const uint8_t* code, float* grad_in, int planes, int H, int W,
                        void* stream);
 
+/* Disparity head of the depth decoder: layers.Conv3x3(C, 1) = ReflectionPad2d(1) + Conv2d(C, 1, 3) + bias
+ * (layers.py:118-133, networks/depth_decoder.py:38-39), forward and backward without a padded copy.
+ * x [N,C,H,W], weight [C,3,3] (= conv.weight[0]), bias [1] or NULL, y / grad_y [N,1,H,W];
+ * grad_x or grad_weight(+grad_bias) may be NULL; scratch holds bbd_dispconv_scratch_doubles(C) doubles. */
+int bbd_dispconv_scratch_doubles(int C);
+int bbd_dispconv_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int H, int W,
+                     void* stream);
+int bbd_dispconv_bwd(const float* x, const float* weight, const float* grad_y, float* grad_x, float* grad_weight,
+                     float* grad_bias, double* scratch, int N, int C, int H, int W, void* stream);
+
 /* Device self-test: the kernels replace hipcc's IEEE division sequence by a cheaper one that is
  * exact for moderate exponents (bbd_math.h).  Runs blocks*256*iters random operand tuples through
  * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */

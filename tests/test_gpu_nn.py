@@ -137,3 +137,52 @@ def test_maxpool_matches_torch(shape):
     ya.backward(gy)
     yb.backward(gy)
     assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(12, 16, 192, 640), (2, 32, 96, 320), (3, 128, 24, 80), (2, 5, 2, 3), (1, 7, 9, 2)])
+def test_dispconv_matches_pad_plus_conv(shape):
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    N, C, H, W = shape
+    x0 = torch.randn(shape, generator=g).to(DEV)
+    w0 = (torch.randn(1, C, 3, 3, generator=g) * 0.2).to(DEV)
+    b0 = torch.randn(1, generator=g).to(DEV)
+    gy = torch.randn(N, 1, H, W, generator=g).to(DEV)
+
+    def run(fused):
+        x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+        y = ops.dispconv(x, w, b) if fused else F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
+        y.backward(gy)
+        return y.detach(), x.grad, w.grad, b.grad
+
+    got, want = run(True), run(False)
+    for n, a, b, t in zip(["y", "grad_x", "grad_w", "grad_b"], got, want, [1e-5, 1e-5, 1e-4, 1e-4]):
+        assert a.shape == b.shape and _rel(a, b) < t, (n, _rel(a, b))
+    again = run(True)
+    assert all(torch.equal(p, q) for p, q in zip(got, again))           # deterministic
+
+
+def test_depth_decoder_fused_vs_stock():
+    from baseboostdepth_amd import networks, ops
+    torch.manual_seed(1)
+    enc = networks.ResnetEncoder(18, False).to(DEV).eval()
+    dec = networks.DepthDecoder(enc.num_ch_enc, [0, 1, 2, 3]).to(DEV).train()
+    with torch.no_grad():
+        feats = [f.clone() for f in enc(torch.rand(2, 3, 96, 320, device=DEV))]
+
+    def run(flag):
+        ops.FUSED_NN = flag
+        dec.zero_grad(set_to_none=True)
+        out = dec([f.clone().requires_grad_(True) for f in feats])
+        sum((out[("disp", s)] ** 2).mean() for s in range(4)).backward()
+        return [out[("disp", s)].detach() for s in range(4)], {n: p.grad.clone() for n, p in dec.named_parameters()}
+
+    try:
+        d1, g1 = run(True)
+        d0, g0 = run(False)
+    finally:
+        ops.FUSED_NN = True
+    for a, b in zip(d1, d0):
+        assert _rel(a, b) < 1e-5
+    for n in g0:
+        assert _rel(g1[n], g0[n]) < 2e-3, n
