@@ -38,14 +38,16 @@ def main():
         if i == 20:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        tr.train_step(batch)
+        _, losses = tr.train_step(batch)
+        last = losses["loss"]
         if i >= 20:
             n += 12
         if i == 20 + a.steps - 1:
             break
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"images_per_s_with_loader": round(n / dt, 1), "ms_per_step": round(dt / (n / 12) * 1e3, 2),
+    assert torch.isfinite(last.detach()).item(), "loss diverged"
+    print(json.dumps({"final_loss": round(float(last.detach()), 5), "images_per_s_with_loader": round(n / dt, 1), "ms_per_step": round(dt / (n / 12) * 1e3, 2),
                       "workers": a.workers, "steps": n // 12}))
 
 
