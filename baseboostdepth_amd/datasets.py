@@ -383,8 +383,10 @@ class DeviceLoader:
     pool inside this process (small runs, tests)."""
 
     def __init__(self, dataset, batch_size, collate, shuffle=True, drop_last=True, num_workers=8, prefetch=2, seed=0,
-                 workers="thread", bytes_per_sample=None, background=True):
+                 workers="thread", bytes_per_sample=None, background=True, rank=0, world=1):
         self.dataset, self.batch_size, self.collate, self.background = dataset, batch_size, collate, background
+        assert 0 <= rank < world
+        self.rank, self.world = rank, world      # data parallel: this loader serves shard `rank` of `world`
         if bytes_per_sample is None:                  # ring-slot sizing: the frames one sample can have, KITTI-sized
             frames = 2 * getattr(dataset, "to_use", 7) + 2 if getattr(dataset, "is_train", True) else 1
             bytes_per_sample = frames * 1300 * 400 * 3
@@ -393,13 +395,18 @@ class DeviceLoader:
         self.workers = workers if num_workers > 0 else "thread"
 
     def __len__(self):
-        n = len(self.dataset)
+        n = len(self.dataset) // self.world
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _batches(self):
         order = list(range(len(self.dataset)))
         if self.shuffle:
             random.Random(self.seed * 7919 + self.dataset.epoch).shuffle(order)
+        if self.world > 1:
+            # one common shuffle (same seed on every rank), then disjoint equal-length shards: rank r takes
+            # indices r, r+world, ... of the first (n // world) * world entries
+            usable = (len(order) // self.world) * self.world
+            order = order[self.rank:usable:self.world]
         for i in range(0, len(order), self.batch_size):
             chunk = order[i:i + self.batch_size]
             if len(chunk) == self.batch_size or not self.drop_last:

@@ -99,8 +99,13 @@ class OverlappedGradientAverager(GradientAverager):
     xGMI is point-to-point, so a ring all-reduce is per-link bound: buckets are sized (32 MB) to be
     well past the latency regime while leaving 3-4 of them to pipeline against the conv backward."""
 
-    def __init__(self, flat, group=None, bucket_bytes=32 << 20):
+    def __init__(self, flat, group=None, bucket_bytes=32 << 20, never=()):
+        """`never`: parameters that are trainable but can never receive a gradient (the ResNet encoders'
+        unused `fc` layers, reference quirk SURVEY 5c-5).  Their hooks never fire, so they are not counted
+        in a bucket's pending set - otherwise the first buckets (reverse parameter order puts the `fc`
+        layers there) would never complete during backward and nothing would overlap."""
         super().__init__(flat, group)
+        self.never = {id(p) for p in never}
         order = list(range(len(flat.params)))[::-1]
         self.buckets, cur, cur_bytes = [], [], 0
         for idx in order:
@@ -125,7 +130,7 @@ class OverlappedGradientAverager(GradientAverager):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def _reset(self):
-        self.pending = [len(b) for b in self.buckets]
+        self.pending = [sum(1 for i in b if id(self.flat.params[i]) not in self.never) for b in self.buckets]
         self.launched = 0
         self.works = []
 
@@ -134,6 +139,10 @@ class OverlappedGradientAverager(GradientAverager):
             b = self.bucket_of[i]
             self.pending[b] -= 1
             self._launch_ready()
+        if id(self.flat.params[i]) in self.never:
+            def unexpected(param):
+                raise RuntimeError("parameter declared gradient-free received a gradient (bucket accounting)")
+            return unexpected
         return hook
 
     def _pack_bucket(self, b):
@@ -163,6 +172,8 @@ class OverlappedGradientAverager(GradientAverager):
                 cur.wait_stream(st)
 
     def _launch_ready(self, force=False):
+        # (a bucket holding only gradient-free parameters has nothing pending: it goes out, as zeros, with
+        # the first hook that fires - still in bucket order on every rank)
         while self.launched < len(self.buckets) and (force or self.pending[self.launched] == 0):
             b = self.launched
             self._join_streams()
@@ -171,6 +182,7 @@ class OverlappedGradientAverager(GradientAverager):
             self.launched += 1
 
     def __call__(self):
+        self.launched_in_backward = self.launched      # diagnostics: buckets whose exchange overlapped backward
         self._launch_ready(force=True)
         for w in self.works:
             w.wait()
@@ -216,7 +228,8 @@ def attach(trainer, group=None):
                     dist.broadcast(b.data, src=0, group=group)
         overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1"
         bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
-        trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket) if overlap
+        never = trainer.gradient_free_parameters() if hasattr(trainer, "gradient_free_parameters") else ()
+        trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket, never=never) if overlap
                              else GradientAverager(flat, group))
         side = trainer._pose_stream() if hasattr(trainer, "_pose_stream") else None
         if overlap and side is not None:

@@ -67,6 +67,18 @@ class Trainer:
         self.flat_grads = None
         self.epoch, self.step = 0, 0
 
+    def gradient_free_parameters(self):
+        """Trainable parameters no loss ever reaches: torchvision-layout ResNets carry an `fc` head the
+        encoders never call - they stay in `parameters_to_train` (Adam state layout as the
+        reference's `adam.pth`) but the gradient exchange must not wait for them."""
+        out = []
+        for name in ("encoder", "pose_encoder"):
+            enc = getattr(self.models.get(name), "encoder", None)
+            fc = getattr(enc, "fc", None)
+            if fc is not None:
+                out += list(fc.parameters())
+        return out
+
     # ------------------------------------------------------------------ mode switches
     def set_train(self):
         for m in self.models.values():
@@ -106,11 +118,35 @@ class Trainer:
         entry = self._graphs.get(key)
         if entry is None:
             static = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inputs.items()}
+            # eager warm-up (allocator, MIOpen solutions, Adam state tensors) must not TRAIN: parameters,
+            # BatchNorm buffers, the optimizer state and the step counter are restored afterwards, so the
+            # first batch of a signature is counted once (by the replay below), like on the eager path
+            had_state = len(self.model_optimizer.state) > 0
+            params = [p for g in self.model_optimizer.param_groups for p in g["params"]]
+            buffers = [b for m in self.models.values() for b in m.buffers()]
+            snap_p = [p.detach().clone() for p in params]
+            snap_b = [b.detach().clone() for b in buffers]
+            snap_s = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+                      for p, st in self.model_optimizer.state.items()} if had_state else None
+            step0 = self.step
             warm = torch.cuda.Stream(device=self.device)
             warm.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(warm):                       # eager warm-up: caches, MIOpen solutions, Adam state
+            with torch.cuda.stream(warm):
                 for _ in range(3):
                     self._eager_step(dict(static))
+                with torch.no_grad():
+                    for p, v in zip(params, snap_p):
+                        p.copy_(v)
+                    for b, v in zip(buffers, snap_b):
+                        b.copy_(v)
+                    for p, st in self.model_optimizer.state.items():
+                        for k, v in st.items():
+                            if torch.is_tensor(v):
+                                if snap_s is not None and p in snap_s and k in snap_s[p]:
+                                    v.copy_(snap_s[p][k])
+                                else:
+                                    v.zero_()          # fresh Adam state: exp_avg = exp_avg_sq = step = 0
+            self.step = step0
             torch.cuda.current_stream(self.device).wait_stream(warm)
             self.model_optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
@@ -183,12 +219,17 @@ class Trainer:
             opt.scales = [0, 1, 2, 3] if epoch < 10 else [0]
         ds = datasets.KITTIRAWDataset(self.train_filenames, epoch, opt.height, opt.width, kt_path=opt.kt_path,
                                       rand=getattr(opt, "rand", False), is_train=True, scales=opt.scales, kt=True,
-                                      naive_mix=True, trimin=opt.trimin, seed=getattr(opt, "pytorch_random_seed", 0))
+                                      naive_mix=True, trimin=opt.trimin,
+                                      seed=getattr(opt, "pytorch_random_seed", 0) + 7919 * self._rank_world()[0])
         collate = datasets.DeviceCollate(opt.height, opt.width, opt.scales, self.device, self.backend)
+        # data parallel: every rank shuffles with the SAME seed and takes every world-th index of that
+        # order (disjoint shards of one epoch, equal length); augmentation draws are per-rank
+        rank, world = self._rank_world()
         return datasets.DeviceLoader(ds, opt.batch_size, collate, shuffle=True, drop_last=True,
                                      num_workers=getattr(opt, "num_workers", 8),
                                      seed=getattr(opt, "pytorch_random_seed", 0),
-                                     workers=getattr(opt, "loader_workers", "process"))
+                                     workers=getattr(opt, "loader_workers", "process"),
+                                     rank=rank, world=world)
 
     def kitti_val_loader(self):
         """Validation split of trainer.py:127-131 + ground truth of :150-151, built once: `val_files.txt`
@@ -212,14 +253,50 @@ class Trainer:
                                                  shuffle=False, drop_last=False, num_workers=getattr(opt, "num_workers", 8))
         return self._val_loader
 
-    def train(self, loader_factory=None, num_epochs=None):
-        """`loader_factory(epoch)` -> iterable of batches (default: `kitti_loader`); checkpoints every
-        `save_frequency` epochs (trainer.py:168-193)."""
+    def _rank_world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def resume_epoch(self):
+        """Start epoch implied by `--load_weights_folder` (trainer.py:169-183): `weights_<N>` resumes at
+        epoch N+1, `weights_best` (or any non-numeric suffix) at epoch 10; `None` starts at 0."""
+        folder = getattr(self.opt, "load_weights_folder", "None")
+        if folder in (None, "None"):
+            return 0
+        suffix = os.path.basename(os.path.normpath(folder)).split("_")[-1]
+        try:
+            return int(suffix) + 1
+        except ValueError:
+            return 10
+
+    def train(self, loader_factory=None, num_epochs=None, steps_per_epoch=None):
+        """`loader_factory(epoch)` -> iterable of batches (default: `kitti_loader`).  As the reference
+        (trainer.py:168-193): resume at the epoch the loaded weights folder names, with the LR schedule and
+        the step counter fast-forwarded; a checkpoint every `save_frequency` epochs, unconditionally
+        (written by rank 0 only when several ranks train)."""
         loader_factory = loader_factory or self.kitti_loader
-        for self.epoch in range(self.epoch, num_epochs or self.opt.num_epochs):
+        rank, world = self._rank_world()
+        start = self.resume_epoch()
+        if start:
+            if steps_per_epoch is None:
+                steps_per_epoch = (len(getattr(self, "train_filenames", [])) // self.opt.batch_size) if hasattr(
+                    self, "train_filenames") else 0
+            self.step = start * steps_per_epoch
+            for _ in range(start):
+                self.model_lr_scheduler.step()
+        self.epoch = start
+        if rank == 0:
+            self.save_opts()
+        for self.epoch in range(start, num_epochs or self.opt.num_epochs):
             self.run_epoch(loader_factory(self.epoch))
-            if (self.epoch + 1) % getattr(self.opt, "save_frequency", 1) == 0 and getattr(self.opt, "save_models", False):
-                self.save_model()
+            if (self.epoch + 1) % getattr(self.opt, "save_frequency", 1) == 0:
+                if rank == 0:
+                    self.save_model()
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.barrier()
 
     def process_batch(self, inputs, batch_idx=None, is_train=True):
         for key, ipt in inputs.items():

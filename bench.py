@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
            --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF (a child
+`python -m torch.distributed.run`, one rank per GPU over RCCL) before anything touches the GPU and
+relays the child's output and exit status.
+
 A "step" is the reference's own definition (trainer.py:233,260-264): process_batch + zero_grad
 + backward + optimizer.step on one pre-resident synthetic KITTI-shaped batch (BASELINE.json
 configs[1]: MD2 ResNet-18 encoder + DepthDecoder + pose nets, 640x192, batch 12 per GPU, frames
@@ -148,7 +152,8 @@ def eager_hot_path_ab(trainer, inputs, opt, iters=10):
         trainer.compute_losses(inputs, out)["loss"].backward()
 
     def eager():
-        O.hot_path(inputs, disp, poses, plan.ms, opt.scales, False, False, inputs["noise"], H, W)["loss"].backward()
+        noise = torch.randn(plan.B, H, W, device=dev) * 0.00001     # drawn per step, like the fused path does
+        O.hot_path(inputs, disp, poses, plan.ms, opt.scales, False, False, noise, H, W)["loss"].backward()
 
     res = {}
     for name, fn in (("fused_hip_ms", fused), ("eager_rocm_ms", eager)):
@@ -165,28 +170,108 @@ def eager_hot_path_ab(trainer, inputs, opt, iters=10):
     return res
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`--gpus N` without a torchrun environment: run the N ranks as a CHILD process group (never exec -
+    this process must not have touched the GPU yet, and does not) and hand its exit status back."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args):
+    """Rendezvous check of the multi-rank path without the workload: every rank joins the process group,
+    one all-reduce and one broadcast run on the backend the benchmark would use (RCCL on GPUs; gloo when
+    BBD_DIST_BACKEND=gloo or there is no GPU), rank 0 prints one JSON line."""
+    import torch.distributed as dist
+    from baseboostdepth_amd import distributed as bdist
+    rank, local, world = bdist.init_from_env()
+    assert world == args.gpus, "world size %d != --gpus %d" % (world, args.gpus)
+    backend = dist.get_backend() if world > 1 else "none"
+    dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    t = torch.full((4,), float(rank + 1), device=dev)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    ok = bool((t == world * (world + 1) / 2).all()) if world > 1 else True
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "ranks": world, "n_gpus": world,
+                          "collective": {"nccl": "rccl"}.get(backend, backend), "all_reduce_ok": ok}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def eager_full_step(trainer, inputs, opt, iters=10):
+    """BASELINE configs[1] A/B, whole step: the SAME networks and optimizer on this GPU, but the hot path
+    as the oracle's eager PyTorch-ROCm op sequence (F.grid_sample / avg_pool2d / cat / min, one stream) -
+    what the reference's trainer would launch here.  Runs after the timed region; measurement only."""
+    from oracle.step_ref import md2_step
+    plan = trainer.plan
+    noise = torch.randn(plan.B, H, W, device=inputs[("color", 0, 0)].device) * 0.00001
+    fn = lambda: md2_step(trainer.models, trainer.model_optimizer, inputs, plan.ms, opt.scales, H, W, noise)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"ms_per_step": round(ms, 3), "images_per_sec": round(plan.B / ms * 1e3, 2),
+            "what": "same nets + Adam on this GPU, hot path as eager PyTorch-ROCm ops (oracle), batch %d" % plan.B}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
-    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5"],
+    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5", "vit"],
                     help="md2 = BASELINE configs[1]/[3] (the headline); configs[2] (SURVEY 8d config 3): boosted = "
                          "worst case m=7 for every sample, boosted15 = the epoch-15 offset distribution (standard "
-                         "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales)")
+                         "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales); "
+                         "vit = configs[4]: MonoViT (mpvit_small) encoder + HR decoder, MD2 frame set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--no-fused-adam", action="store_true")
     ap.add_argument("--no-eager-ab", action="store_true",
-                    help="skip timing the hot path as eager PyTorch-ROCm ops (oracle) vs the fused kernels")
-    args = ap.parse_args()
+                    help="skip timing the hot path / the whole step as eager PyTorch-ROCm ops (oracle) vs the fused kernels")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+
+    # ---- multi-rank launch: before ANY GPU call (torch.cuda.* initialises HIP; a process that has done so
+    #      must never be replaced, and the children must find the devices untouched)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    if args.dry_launch:
+        return dry_launch(args)
 
     from baseboostdepth_amd import distributed as bdist
     rank, local, world = bdist.init_from_env()
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    assert world == args.gpus, "world size %d != --gpus %d (launch with torchrun --nproc-per-node == --gpus, " \
+                               "or plain `python bench.py --gpus N`)" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path in the product)"
+    collective = "none"
+    if world > 1:
+        backend_name = torch.distributed.get_backend()
+        assert backend_name == "nccl" or os.environ.get("BBD_DIST_BACKEND"), \
+            "multi-GPU runs exchange gradients over RCCL (backend 'nccl'), got %r" % backend_name
+        collective = {"nccl": "rccl"}.get(backend_name, backend_name)
     if os.environ.get("BBD_SHARE_GPU0"):       # test hook: all ranks on GPU 0 (with BBD_DIST_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
@@ -212,7 +297,7 @@ def main():
     bdist.attach(trainer)
     import random as _random
     draw = _random.Random(1234 + rank)
-    if args.config == "md2":
+    if args.config in ("md2", "vit"):
         ms = [1] * args.batch
     elif args.config == "boosted":
         ms = [7] * args.batch
@@ -221,6 +306,8 @@ def main():
     else:                                        # epoch 5: P(m = 0,1,2) = .062 .573 .366
         ms = draw.choices(range(0, 3), [.062, .573, .366], k=args.batch)
     inputs = synthetic_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
+    # the identity-candidate noise is drawn INSIDE every step, as the reference does (trainer.py:518-523)
+    inputs.pop("noise")
     if args.config in ("boosted", "boosted15"):
         inputs["cutt"] = torch.tensor(1.35)      # epoch >= 10 regime: incremental + partial pose modes
     backend = ops.default_backend()
@@ -235,17 +322,23 @@ def main():
         trainer.train_step(inputs)
     timer = ops.KernelTimer()
     backend.timer = timer
+    # per-step durations for the median: one event at every step boundary on the main stream (no host sync)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         trainer.train_step(inputs)
+    marks[args.steps].record()
     sync_all()
     elapsed = time.perf_counter() - t0
     backend.timer = None
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if per_step else 0.0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, median_ms], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, median_ms = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         S = len(opt.scales)
@@ -260,8 +353,13 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["mean_ms"])
         # HBM bytes per launch from rocprofv3 PMC passes of the same workload (committed under profiles/)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_md2.json")
-        if args.config == "md2" and args.batch == 12 and os.path.isfile(tpath):
+        tpath = None
+        for rnd in ("r02", "r01"):
+            cand = os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % args.config)
+            if os.path.isfile(cand):
+                tpath = cand
+                break
+        if args.batch == 12 and tpath is not None:
             tj = json.load(open(tpath))
             traffic = tj.get(dom, {}).get("traffic_bytes")
             for k in kernels:
@@ -274,17 +372,23 @@ def main():
                         kernels[k]["valu_floor_ms"] = round(floor_ms, 4)
                         kernels[k]["frac_of_valu_floor"] = round(floor_ms / kernels[k]["mean_ms"], 3)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
-                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic}
+                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
+                    "traffic_source": os.path.relpath(tpath, ROOT) if (traffic is not None) else None}
         global_batch = args.batch * world
+        net = "MonoViT (mpvit_small) encoder + HR DepthDecoder" if args.config == "vit" else \
+              "MD2 ResNet-18 encoder+DepthDecoder"
         line = {
-            "metric": "training images/sec at 640x192, MD2 ResNet18",
+            "metric": "training images/sec at 640x192, MD2 ResNet18" if args.config != "vit" else
+                      "training images/sec at 640x192, MonoViT",
             "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "n_gpus": world, "ranks": world, "collective": collective,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MD2 ResNet-18 encoder+DepthDecoder+PoseNet training step, 640x192, "
+            "config": {"workload": "%s+PoseNet training step, 640x192, "
                                    "per-GPU batch %d, frames [0,-1,1], %d scales, HIP fused warp+SSIM+min"
-                                   % (args.batch, S) if args.config == "md2" else
+                                   % (net, args.batch, S) if args.config in ("md2", "vit") else
                                    "BaseBoostDepth boosted step (trimin+decomp+incremental+partial, config %s, "
                                    "per-sample max offsets %s), ResNet-18, 640x192, per-GPU batch %d, %d scale(s)"
                                    % (args.config, ms, args.batch, S),
@@ -293,12 +397,18 @@ def main():
         }
         if world == 1 and not args.no_eager_ab and args.config == "md2":
             line["hot_path_ab"] = eager_hot_path_ab(trainer, inputs, opt)
+            try:
+                line["eager_step"] = eager_full_step(trainer, inputs, opt)
+                line["eager_step_images_per_sec"] = line["eager_step"]["images_per_sec"]
+            except Exception as e:    # informational, never fail the benchmark on it
+                line["eager_step"] = "n/a (%s: %s)" % (type(e).__name__, e)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

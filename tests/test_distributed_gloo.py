@@ -124,6 +124,42 @@ def _worker_uneven_graphs(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_real_networks(rank, world, port, q):
+    """The four real networks: the ResNet encoders' unused `fc` layers never get a gradient, and with
+    reverse-parameter-order buckets they sit in the FIRST buckets - the exchange must still start inside
+    backward (it used to launch 0 of 4 buckets before the flush)."""
+    os.environ["BBD_NO_OVERLAP"] = "0"
+    os.environ["BBD_BUCKET_BYTES"] = str(32 << 20)
+    bdist = _setup(rank, world, port)
+    from baseboostdepth_amd import Trainer
+    from baseboostdepth_amd.options import MonodepthOptions
+    o = MonodepthOptions().parse("--no_cuda --weights_init scratch --height 64 --width 128 --batch_size 1".split())
+    torch.manual_seed(3)
+    tr = Trainer(o)
+    tr.set_train()
+    bdist.attach(tr)
+    sync = tr.grad_sync
+    assert len(tr.gradient_free_parameters()) == 4 and len(sync.buckets) >= 3
+    g = torch.Generator().manual_seed(10 + rank)
+    img = torch.rand(2, 3, 64, 128, generator=g)
+    tr.flat_grads.zero()
+    disp = tr.models["depth"](tr.models["encoder"](img))
+    aa, tt = tr.models["pose"]([tr.models["pose_encoder"](torch.cat([img, img.flip(0)], 1))])
+    loss = sum(d.mean() for d in disp.values()) + aa.sum() + tt.sum()
+    loss.backward()
+    sync()
+    early = sync.launched_in_backward
+    # result still equals the plain average of both ranks' gradients
+    mine = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in tr.parameters_to_train])
+    assert torch.equal(mine, tr.flat_grads.flat)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    same = all(torch.equal(g_, gathered[0]) for g_ in gathered)
+    q.put((rank, (early, len(sync.buckets), same)))
+    dist.destroy_process_group()
+
+
 def _worker_shard(rank, world, port, q):
     _setup(rank, world, port)
     from golden_io import Case
@@ -194,6 +230,34 @@ def test_overlapped_bucketed_average_world2():
 def test_overlapped_average_with_rank_specific_graphs():
     for rank, err in _run(_worker_uneven_graphs):
         assert err < 1e-6, (rank, err)
+
+
+def test_overlap_starts_inside_backward_on_the_real_networks():
+    for rank, (early, n_buckets, same) in _run(_worker_real_networks):
+        assert same
+        assert early >= n_buckets - 1, "rank %d launched %d of %d buckets inside backward" % (rank, early, n_buckets)
+
+
+def test_loader_shards_indices_by_rank():
+    from baseboostdepth_amd.datasets import DeviceLoader
+
+    class _DS:
+        epoch = 3
+        is_train = True
+
+        def __len__(self):
+            return 103
+
+    seen = []
+    for rank in range(4):
+        ld = DeviceLoader(_DS(), 5, collate=None, shuffle=True, drop_last=True, num_workers=0, seed=42, rank=rank, world=4)
+        idx = [i for chunk in ld._batches() for i in chunk]
+        assert len(idx) == len(ld) * 5 == 25
+        seen.append(set(idx))
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert not (seen[a] & seen[b]), "ranks %d and %d read the same samples" % (a, b)
+    assert len(set().union(*seen)) == 100
 
 
 def test_hot_path_shards_by_sample_world2():

@@ -46,6 +46,10 @@ def main():
     losses["loss"].backward()
     tr.grad_sync()
     torch.cuda.synchronize()
+    if hasattr(tr.grad_sync, "buckets"):      # the exchange must have started DURING backward, not after it
+        n_b, early = len(tr.grad_sync.buckets), tr.grad_sync.launched_in_backward
+        print("rank %d: %d of %d buckets launched inside backward" % (rank, early, n_b))
+        assert early >= n_b - 1, "gradient buckets did not overlap backward (%d of %d)" % (early, n_b)
     mine = tr.flat_grads.flat.clone()
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
