@@ -44,6 +44,10 @@ SIGNATURES = {
     "bbd_backproject_fwd": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_project3d_fwd": [_p, _p, _p, _p, _i, _i, _i, _d, _p],
     "bbd_ssim_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_backproject_bwd": [_p, _p, _p, _i, _i, _i, _p],
+    "bbd_project3d_bwd_blocks": [],
+    "bbd_project3d_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _d, _p],
+    "bbd_ssim_bwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "bbd_depth_metrics": [_p, _p, _p, _p, _i, _i, _i, _d, _d, _d, _d, _d, _i, _p],
     "bbd_resample_h_u8": [_p, _p, _p, _i, _i, _p, _p, _i, _p],
     "bbd_resample_v_u8": [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p],
@@ -89,6 +93,7 @@ class HipLibrary:
         self.smooth_chunks = self._dll.bbd_smooth_chunks()
         self.tile_w = self._dll.bbd_tile_w()
         self.tile_h = self._dll.bbd_tile_h()
+        self.project3d_bwd_blocks = self._dll.bbd_project3d_bwd_blocks()
 
     def num_tiles(self, H, W):
         return self._dll.bbd_num_tiles(H, W)

@@ -1012,6 +1012,164 @@ __global__ __launch_bounds__(NT) void ssim_map_kernel(const float* __restrict__ 
   }
 }
 
+// ---- backward of the stand-alone layers (closed forms of SURVEY Appendix A2-A5) -------------
+// BackprojectDepth: points = depth * (inv_K[:3,:3] . (x,y,1)) | 1  ->  d depth = sum_i g_i * c_i
+__global__ __launch_bounds__(NT) void backproject_bwd_kernel(const float* __restrict__ gpoints,
+                                                             const float* __restrict__ inv_K,
+                                                             float* __restrict__ gdepth, int n, int H, int W) {
+  const size_t hw = (size_t)H * W, total = (size_t)n * hw;
+  for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += (size_t)gridDim.x * NT) {
+    const int b = (int)(i / hw);
+    const size_t p = i - (size_t)b * hw;
+    const float fx = (float)(p % W), fy = (float)(p / W);
+    const float* k = inv_K + (size_t)b * 16;
+    const float* g = gpoints + (size_t)b * 4 * hw + p;
+    gdepth[i] = g[0] * bbd_dot3_hom(k, fx, fy) + g[hw] * bbd_dot3_hom(k + 4, fx, fy) +
+                g[2 * hw] * bbd_dot3_hom(k + 8, fx, fy);
+  }
+}
+
+// Project3D: grid = 2*((P.X)_{xy} / ((P.X)_z + eps) / (size-1) - 0.5).  Per pixel: d points = P^T gq;
+// per sample: d P = sum_pixels gq (x) X, written as one deterministic partial per workgroup
+// (gp_partial [n, gridDim.x, 12]); the caller sums them and forms d T = K[:3,:]^T dP, d K = dP T^T.
+constexpr int P3D_BLOCKS = 128;
+__global__ __launch_bounds__(NT) void project3d_bwd_kernel(const float* __restrict__ points,
+                                                           const float* __restrict__ K, const float* __restrict__ T,
+                                                           const float* __restrict__ ggrid,
+                                                           float* __restrict__ gpoints,
+                                                           float* __restrict__ gp_partial, int H, int W, float eps) {
+  __shared__ float s_red[4][12];
+  const int b = blockIdx.y;
+  const size_t hw = (size_t)H * W;
+  float row[28], P[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) row[r] = K[(size_t)b * 16 + r];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) row[12 + r] = T[(size_t)b * 16 + r];
+#pragma unroll
+  for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+      float acc = row[i2 * 4 + 0] * row[12 + j2];
+      acc = acc + row[i2 * 4 + 1] * row[12 + 4 + j2];
+      acc = acc + row[i2 * 4 + 2] * row[12 + 8 + j2];
+      acc = acc + row[i2 * 4 + 3] * row[12 + 12 + j2];
+      P[i2 * 4 + j2] = acc;
+    }
+  const float sx = 2.0f / (float)(W - 1), sy = 2.0f / (float)(H - 1);
+  float gP[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
+  for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < hw; p += (size_t)gridDim.x * NT) {
+    const float* q = points + (size_t)b * 4 * hw + p;
+    const float X[4] = {q[0], q[hw], q[2 * hw], q[3 * hw]};
+    const float qx = fmaf(P[3], X[3], fmaf(P[2], X[2], fmaf(P[1], X[1], P[0] * X[0])));
+    const float qy = fmaf(P[7], X[3], fmaf(P[6], X[2], fmaf(P[5], X[1], P[4] * X[0])));
+    const float qz = fmaf(P[11], X[3], fmaf(P[10], X[2], fmaf(P[9], X[1], P[8] * X[0])));
+    const float rz = 1.0f / (qz + eps);
+    const float u = qx * rz, v = qy * rz;
+    const float du = ggrid[((size_t)b * hw + p) * 2 + 0] * sx, dv = ggrid[((size_t)b * hw + p) * 2 + 1] * sy;
+    const float gq[3] = {du * rz, dv * rz, -(du * u + dv * v) * rz};
+    float* go = gpoints + (size_t)b * 4 * hw + p;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) go[c * hw] = gq[0] * P[c] + gq[1] * P[4 + c] + gq[2] * P[8 + c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gP[r * 4 + c] += gq[r] * X[c];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const float ws = wave_sum63(gP[k]);
+    if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6][k] = ws;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12)
+    gp_partial[((size_t)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] =
+        ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+}
+
+// SSIM: d out_c(p) / d x_c(q) = (A + B x(q) + C y(q))(p) / 9 for every window slot of p that lands on q
+// (ReflectionPad2d(1): border texels are hit by up to two slots per dimension).  One colour plane at a
+// time: coefficient planes of the (TH+2)x(TW+2) loss pixels around the tile, weighted by the upstream
+// gradient, then the 3x3 adjoint gather at the thread's own 4 texels.  The SSIM expression is symmetric
+// in (x, y), so the gradient w.r.t. the second argument is this kernel with the arguments swapped.
+__global__ __launch_bounds__(NT) void ssim_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ gout, float* __restrict__ gx,
+                                                      int H, int W, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float s_x[BPLANE + 8];
+  __shared__ __attribute__((aligned(16))) float s_y[BPLANE + 8];
+  __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE];
+  const int plane = blockIdx.x / ntiles;                       // one of n*3 colour planes
+  const TileCoord tc = decode_tile(blockIdx.x - plane * ntiles, W);
+  const size_t hw = (size_t)H * W;
+  const float* xp = x + (size_t)plane * hw;
+  const float* yp = y + (size_t)plane * hw;
+  const float* gp = gout + (size_t)plane * hw;
+  Cells<BH, BW, BS, 2> cl;
+  cl.init(H, W, tc.tx0, tc.ty0);
+#pragma unroll
+  for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
+    s_x[cl.lds[k]] = xp[cl.pix[k]];
+    s_y[cl.lds[k]] = yp[cl.pix[k]];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CH * CW; i += NT) {
+    const int r = i / CW, c = i - r * CW;
+    const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
+    float A = 0.0f, Bc = 0.0f, Cc = 0.0f;
+    if (py >= 0 && py < H && px >= 0 && px < W) {
+      float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
+#pragma unroll
+      for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) {
+          const float xv = s_x[(r + dr) * BS + c + dc], yv = s_y[(r + dr) * BS + c + dc];
+          sx_ += xv; sxx += xv * xv; sxy += xv * yv; sy_ += yv; syy += yv * yv;
+        }
+      float mu_y, sg_y;
+      bbd_ystats(sy_, syy, &mu_y, &sg_y);
+      bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
+      const float g = gp[(size_t)py * W + px];
+      A *= g; Bc *= g; Cc *= g;
+    }
+    s_cf[0][r * CS + c] = A;
+    s_cf[1][r * CS + c] = Bc;
+    s_cf[2][r * CS + c] = Cc;
+  }
+  __syncthreads();
+  int ly, lx0;
+  strip_of_thread(&ly, &lx0);
+  const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
+  if (qy >= H) return;
+  float wy[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int py = qy + d - 1;
+    wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int qx = qx0 + j;
+    if (qx >= W) continue;
+    float S[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int dc = 0; dc < 3; ++dc) {
+      const int px = qx + dc - 1;
+      const float wx = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx, px, W) : 0.0f;
+#pragma unroll
+      for (int dr = 0; dr < 3; ++dr) {
+        const float wgt = wx * wy[dr];
+        const int cell = (ly + dr) * CS + lx0 + j + dc;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) S[pl] = fmaf(wgt, s_cf[pl][cell], S[pl]);
+      }
+    }
+    const float xq = s_x[(ly + 2) * BS + lx0 + j + 2], yq = s_y[(ly + 2) * BS + lx0 + j + 2];
+    gx[(size_t)plane * hw + (size_t)qy * W + qx] = (S[0] + xq * S[1] + yq * S[2]) * (1.0f / 9.0f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Pose table [NP,40] (K[:3,:] | T | inv_K[:3,:3]) -> projection table [NP,24] (P = (K@T)[:3,:] | inv_K).
 // One thread per row; bbd_make_proj applies the reference CPU path's rounding order.
@@ -1511,6 +1669,35 @@ int bbd_ssim_fwd(const float* x, const float* y, float* out, int n, int H, int W
   const int ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(ssim_map_kernel, dim3((unsigned)(n * ntiles)), dim3(NT), 0, static_cast<hipStream_t>(stream),
                      x, y, out, H, W, ntiles);
+  return launch_status();
+}
+
+int bbd_backproject_bwd(const float* grad_points, const float* inv_K, float* grad_depth, int n, int H, int W,
+                        void* stream) {
+  if (!grad_points || !inv_K || !grad_depth || n <= 0 || H <= 0 || W <= 0) return BBD_E_BADARG;
+  const size_t tot = (size_t)n * H * W;
+  const unsigned grid = (unsigned)((tot + NT - 1) / NT < 4096 ? (tot + NT - 1) / NT : 4096);
+  hipLaunchKernelGGL(backproject_bwd_kernel, dim3(grid), dim3(NT), 0, static_cast<hipStream_t>(stream), grad_points,
+                     inv_K, grad_depth, n, H, W);
+  return launch_status();
+}
+
+int bbd_project3d_bwd_blocks(void) { return P3D_BLOCKS; }
+
+int bbd_project3d_bwd(const float* points, const float* K, const float* T, const float* grad_grid,
+                      float* grad_points, float* gp_partial, int n, int H, int W, double eps, void* stream) {
+  if (!points || !K || !T || !grad_grid || !grad_points || !gp_partial || n <= 0 || H < 2 || W < 2) return BBD_E_BADARG;
+  hipLaunchKernelGGL(project3d_bwd_kernel, dim3(P3D_BLOCKS, (unsigned)n), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), points, K, T, grad_grid, grad_points, gp_partial, H, W, (float)eps);
+  return launch_status();
+}
+
+int bbd_ssim_bwd(const float* x, const float* y, const float* grad_out, float* grad_x, int n, int H, int W,
+                 void* stream) {
+  if (!x || !y || !grad_out || !grad_x || n <= 0 || H < 3 || W < 3) return BBD_E_BADARG;
+  const int ntiles = bbd_num_tiles(H, W);
+  hipLaunchKernelGGL(ssim_bwd_kernel, dim3((unsigned)(n * 3 * ntiles)), dim3(NT), 0, static_cast<hipStream_t>(stream),
+                     x, y, grad_out, grad_x, H, W, ntiles);
   return launch_status();
 }
 

@@ -9,7 +9,6 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import ptr
 
 
 def disp_to_depth(disp, min_depth, max_depth):
@@ -112,15 +111,9 @@ def upsample(x):
     return torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
 
 
-def _forward_only(*tensors):
-    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        raise NotImplementedError(
-            "the stand-alone layer kernels are forward-only; gradients of the photometric path are "
-            "provided by the fused op (baseboostdepth_amd.ops.fused_reprojection_min) used by Trainer")
-
-
 class BackprojectDepth(nn.Module):
-    """depth [n,1,H,W], inv_K [n,4,4] -> camera points [n,4,H*W]  (layers.py:136-167).
+    """depth [n,1,H,W], inv_K [n,4,4] -> camera points [n,4,H*W]  (layers.py:136-167); differentiable
+    w.r.t. depth like the reference's module.
 
     The reference keeps [batch,3,H*W] pixel-grid and ones buffers; the kernel derives pixel
     coordinates from the thread index, so this module holds no tensors."""
@@ -130,49 +123,27 @@ class BackprojectDepth(nn.Module):
         self.batch_size, self.height, self.width = batch_size, height, width
 
     def forward(self, depth, inv_K, backend=None):
-        _forward_only(depth, inv_K)
-        backend = backend or ops.default_backend()
-        n = len(inv_K)
-        depth, inv_K = depth.contiguous(), inv_K.contiguous()
-        backend._check(depth, inv_K)
-        pts = torch.empty(n, 4, self.height * self.width, device=depth.device, dtype=torch.float32)
-        backend.run("bbd_backproject_fwd", depth, ptr(depth), ptr(inv_K), ptr(pts), n, self.height, self.width)
-        return pts
+        return ops.backproject(depth, inv_K, self.height, self.width, backend)
 
 
 class Project3D(nn.Module):
-    """points [n,4,H*W], K, T [n,4,4] -> sampling grid [n,H,W,2] in [-1,1]  (layers.py:170-195)."""
+    """points [n,4,H*W], K, T [n,4,4] -> sampling grid [n,H,W,2] in [-1,1]  (layers.py:170-195);
+    differentiable w.r.t. points, T and K."""
 
     def __init__(self, batch_size, height, width, eps=1e-7):
         super().__init__()
         self.batch_size, self.height, self.width, self.eps = batch_size, height, width, eps
 
     def forward(self, points, K, T, backend=None):
-        _forward_only(points, K, T)
-        backend = backend or ops.default_backend()
-        n = len(K)
-        points, K, T = points.contiguous(), K.contiguous(), T.contiguous()
-        backend._check(points, K, T)
-        grid = torch.empty(n, self.height, self.width, 2, device=points.device, dtype=torch.float32)
-        backend.run("bbd_project3d_fwd", points, ptr(points), ptr(K), ptr(T), ptr(grid), n, self.height,
-                    self.width, float(self.eps))
-        return grid
+        return ops.project3d(points, K, T, self.height, self.width, self.eps, backend)
 
 
 class SSIM(nn.Module):
-    """(1 - SSIM)/2 map between image pairs, [n,3,H,W] -> [n,3,H,W]  (layers.py:219-249)."""
+    """(1 - SSIM)/2 map between image pairs, [n,3,H,W] -> [n,3,H,W]  (layers.py:219-249); differentiable
+    w.r.t. both images."""
 
     def forward(self, x, y, backend=None):
-        _forward_only(x, y)
-        backend = backend or ops.default_backend()
-        x, y = x.contiguous(), y.contiguous()
-        backend._check(x, y)
-        n, c, H, W = x.shape
-        out = torch.empty_like(x)
-        # channels are independent: treat [n,c] as n*c/3 three-plane items
-        assert (n * c) % 3 == 0
-        backend.run("bbd_ssim_fwd", x, ptr(x), ptr(y), ptr(out), (n * c) // 3, H, W)
-        return out
+        return ops.ssim_map(x, y, backend)
 
 
 def get_smooth_loss(disp, img):

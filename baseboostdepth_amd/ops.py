@@ -322,6 +322,111 @@ def fused_reprojection_min(depth, proj, target, ident, noise, plan, frame_tensor
                                        bool(materialize), backend or default_backend())
 
 
+# ---------------------------------------------------------------------------- stand-alone layers (autograd)
+class _Backproject(torch.autograd.Function):
+    """layers.BackprojectDepth.forward (layers.py:160-167) with its closed-form backward."""
+
+    @staticmethod
+    def forward(ctx, depth, inv_K, H, W, backend):
+        n = len(inv_K)
+        depth, inv_K = depth.contiguous(), inv_K.contiguous()
+        backend._check(depth, inv_K)
+        pts = torch.empty(n, 4, H * W, device=depth.device, dtype=torch.float32)
+        backend.run("bbd_backproject_fwd", depth, ptr(depth), ptr(inv_K), ptr(pts), n, H, W)
+        ctx.save_for_backward(inv_K)
+        ctx.meta = (n, H, W, depth.shape, backend)
+        return pts
+
+    @staticmethod
+    def backward(ctx, grad_points):
+        (inv_K,) = ctx.saved_tensors
+        n, H, W, shape, backend = ctx.meta
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("BackprojectDepth: no gradient w.r.t. inv_K (camera intrinsics are constants "
+                                      "of the reference's training path)")
+        grad_points = grad_points.contiguous()
+        grad_depth = torch.empty(n, H, W, device=grad_points.device, dtype=torch.float32)
+        backend.run("bbd_backproject_bwd", grad_points, ptr(grad_points), ptr(inv_K), ptr(grad_depth), n, H, W)
+        return grad_depth.view(shape), None, None, None, None
+
+
+def backproject(depth, inv_K, H, W, backend=None):
+    return _Backproject.apply(depth, inv_K, H, W, backend or default_backend())
+
+
+class _Project3D(torch.autograd.Function):
+    """layers.Project3D.forward (layers.py:181-195); backward gives d points, d T and d K."""
+
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, eps, backend):
+        n = len(K)
+        points, K, T = points.contiguous(), K.contiguous(), T.contiguous()
+        backend._check(points, K, T)
+        grid = torch.empty(n, H, W, 2, device=points.device, dtype=torch.float32)
+        backend.run("bbd_project3d_fwd", points, ptr(points), ptr(K), ptr(T), ptr(grid), n, H, W, float(eps))
+        ctx.save_for_backward(points, K, T)
+        ctx.meta = (n, H, W, float(eps), backend)
+        return grid
+
+    @staticmethod
+    def backward(ctx, grad_grid):
+        points, K, T = ctx.saved_tensors
+        n, H, W, eps, backend = ctx.meta
+        grad_grid = grad_grid.contiguous()
+        grad_points = torch.empty_like(points)
+        blocks = backend.lib.project3d_bwd_blocks
+        gp_partial = torch.empty(n, blocks, 12, device=points.device, dtype=torch.float32)
+        backend.run("bbd_project3d_bwd", points, ptr(points), ptr(K), ptr(T), ptr(grad_grid), ptr(grad_points),
+                    ptr(gp_partial), n, H, W, eps)
+        gP = gp_partial.sum(dim=1).view(n, 3, 4)                    # dL/dP,  P = (K @ T)[:3, :]
+        grad_K = grad_T = None
+        if ctx.needs_input_grad[1]:
+            grad_K = torch.zeros_like(K)
+            grad_K[:, :3, :] = torch.matmul(gP, T.transpose(1, 2))
+        if ctx.needs_input_grad[2]:
+            grad_T = torch.matmul(K[:, :3, :].transpose(1, 2), gP)
+        return grad_points, grad_K, grad_T, None, None, None, None
+
+
+def project3d(points, K, T, H, W, eps=1e-7, backend=None):
+    return _Project3D.apply(points, K, T, H, W, eps, backend or default_backend())
+
+
+class _SSIMMap(torch.autograd.Function):
+    """layers.SSIM.forward (layers.py:235-249), [n,3k,H,W] x2 -> same shape; differentiable in both."""
+
+    @staticmethod
+    def forward(ctx, x, y, backend):
+        x, y = x.contiguous(), y.contiguous()
+        backend._check(x, y)
+        n, c, H, W = x.shape
+        assert (n * c) % 3 == 0, "SSIM kernels work on groups of three colour planes"
+        out = torch.empty_like(x)
+        backend.run("bbd_ssim_fwd", x, ptr(x), ptr(y), ptr(out), (n * c) // 3, H, W)
+        ctx.save_for_backward(x, y)
+        ctx.backend = backend
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, y = ctx.saved_tensors
+        backend = ctx.backend
+        n, c, H, W = x.shape
+        grad_out = grad_out.contiguous()
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            backend.run("bbd_ssim_bwd", x, ptr(x), ptr(y), ptr(grad_out), ptr(gx), (n * c) // 3, H, W)
+        if ctx.needs_input_grad[1]:       # the SSIM expression is symmetric in its two arguments
+            gy = torch.empty_like(y)
+            backend.run("bbd_ssim_bwd", x, ptr(y), ptr(x), ptr(grad_out), ptr(gy), (n * c) // 3, H, W)
+        return gx, gy, None
+
+
+def ssim_map(x, y, backend=None):
+    return _SSIMMap.apply(x, y, backend or default_backend())
+
+
 # ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)
 class _BatchNormAct(torch.autograd.Function):
     """Training-mode BatchNorm2d, optional residual add and ReLU in two launches each way

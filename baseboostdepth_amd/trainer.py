@@ -509,7 +509,8 @@ class Trainer:
         return new
 
     def compute_reprojection_loss(self, pred, target):
-        """0.85*SSIM + 0.15*L1 map, [n,3,H,W] x2 -> [n,1,H,W]  (trainer.py:477-486); forward-only."""
+        """0.85*SSIM + 0.15*L1 map, [n,3,H,W] x2 -> [n,1,H,W]  (trainer.py:477-486); differentiable (the
+        training step itself uses the fused launch, this is the reference's stand-alone method)."""
         l1 = torch.abs(target - pred).mean(1, True)
         if self.opt.no_ssim:
             return l1

@@ -149,8 +149,9 @@ int bbd_smooth_loss_bwd(const float* disp, const float* img, const float* mean_d
                         const float* gscale, float* grad_disp, float* dots,
                         int B, int h, int w, void* stream);
 
-/* Stand-alone forward kernels behind the reference's layer classes (API surface only; the
- * training step uses the fused entry points above and never materialises these tensors).
+/* Stand-alone kernels behind the reference's layer classes (the training step uses the fused entry
+ * points above and never materialises these tensors; callers written against the reference's
+ * `layers` module - including its own trainer - get differentiable modules through these).
  *   bbd_backproject_fwd : layers.BackprojectDepth.forward (layers.py:160-167)
  *                         depth [n,H,W], inv_K [n,4,4] -> points [n,4,H*W]
  *   bbd_project3d_fwd   : layers.Project3D.forward (layers.py:181-195)
@@ -161,6 +162,23 @@ int bbd_backproject_fwd(const float* depth, const float* inv_K, float* points, i
 int bbd_project3d_fwd(const float* points, const float* K, const float* T, float* grid,
                       int n, int H, int W, double eps, void* stream);
 int bbd_ssim_fwd(const float* x, const float* y, float* out, int n, int H, int W, void* stream);
+
+/* Their backward passes (the reference's layers are plain autograd nn.Modules, layers.py:136-249, and its
+ * trainer back-propagates through them, trainer.py:434-442, 477-486).  Closed forms of SURVEY Appendix A.
+ *   bbd_backproject_bwd : grad_points [n,4,H*W] -> grad_depth [n,H,W]          (inv_K carries no gradient)
+ *   bbd_project3d_bwd   : grad_grid [n,H,W,2] -> grad_points [n,4,H*W] and gp_partial
+ *                         [n, bbd_project3d_bwd_blocks(), 12]: per-workgroup partial sums of dL/dP,
+ *                         P = (K@T)[:3,:]; the caller sums them (fixed order => deterministic) and
+ *                         forms dL/dT = K[:3,:]^T dP, dL/dK[:3,:] = dP T^T
+ *   bbd_ssim_bwd        : grad_out [n,3,H,W] -> grad_x [n,3,H,W]; the SSIM expression is symmetric in
+ *                         its two arguments, so d/dy is the same call with x and y exchanged          */
+int bbd_backproject_bwd(const float* grad_points, const float* inv_K, float* grad_depth, int n, int H, int W,
+                        void* stream);
+int bbd_project3d_bwd_blocks(void);
+int bbd_project3d_bwd(const float* points, const float* K, const float* T, const float* grad_grid,
+                      float* grad_points, float* gp_partial, int n, int H, int W, double eps, void* stream);
+int bbd_ssim_bwd(const float* x, const float* y, const float* grad_out, float* grad_x, int n, int H, int W,
+                 void* stream);
 
 /* Validation metrics on the device: one workgroup per image.
  *   flags 0                       : Trainer.compute_depth_losses, KITTI branch (trainer.py:594-617):

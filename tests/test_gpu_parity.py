@@ -85,8 +85,7 @@ def test_standalone_layers(layers_z, backend):
     Mi = L.transformation_from_parameters(g(z, "tfp/aa"), g(z, "tfp/t"), invert=True)
     assert torch.allclose(M.cpu(), torch.from_numpy(z["tfp/M"]), atol=1e-6)
     assert torch.allclose(Mi.cpu(), torch.from_numpy(z["tfp/Minv"]), atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        L.SSIM()(x.clone().requires_grad_(True), y)
+    assert L.SSIM()(x.clone().requires_grad_(True), y).requires_grad    # differentiable: test_gpu_layers_autograd.py
 
 
 def test_disp_to_depth_kernel(layers_z, backend):
@@ -139,15 +138,25 @@ def _random_batch(B, H, W, ms, gen, trimin, decomp):
     return inputs
 
 
+def _note(text):
+    """Observed error levels, kept next to the bars they justify (BBD_TEST_REPORT=<file> to collect)."""
+    import os
+    path = os.environ.get("BBD_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(text + "\n")
+
+
 @pytest.mark.parametrize("ms,trimin,decomp,scales", [
     ([1, 1], False, False, [0, 1, 2, 3]),
     ([7, 3], True, True, [0]),
+    ([1] * 12, False, False, [0, 1, 2, 3]),          # BASELINE configs[1] at its real size: B=12, 4 scales
 ])
 def test_full_resolution_against_oracle(ms, trimin, decomp, scales, backend):
     """BASELINE sizes (192x640): HIP vs the oracle run live on this box's CPU.  PyTorch's CPU
     kernels round differently across host CPUs (oracle header), so this uses the tolerance
     protocol: maps to 1e-4, arg-min equal where the oracle's margin exceeds 2e-4, loss to 1e-5,
-    gradients to 1e-3 of their max outside the 3x3 footprint of flipped pixels."""
+    gradients to 1e-4 of their max outside the 3x3 footprint of flipped pixels."""
     import types
     from make_golden import synth_disp
     from oracle import hotpath_ref as O
@@ -207,14 +216,18 @@ def test_full_resolution_against_oracle(ms, trimin, decomp, scales, backend):
         rel = (gg - ge).abs() / float(ge.abs().max())
         # a flipped near-tie pixel re-routes gradient inside its 3x3 window and, at coarse scales,
         # through the 2x2 bilinear footprints of those nine texels
-        assert int((rel > 1e-3).sum()) <= 40 * flips, ("disp grad", s, flips, float(rel.max()))
+        n_bad = int((rel > 1e-4).sum())
+        _note("full_res ms=%s scale %d: flips %d, texels off (>1e-4 of max) %d, max rel %.3e, L2 rel %.3e" % (
+            ms, s, flips, n_bad, float(rel.max()), float((gg - ge).norm() / ge.norm())))
+        assert n_bad <= 40 * flips, ("disp grad", s, flips, n_bad, float(rel.max()))
         assert float((gg - ge).norm() / ge.norm()) < (1e-4 if flips == 0 else 5e-2), ("disp grad L2", s)
     assert abs(float(losses["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
     for f, T in poses.items():
         if T.grad is None:
             continue
         err = float((gpose[f].grad.cpu() - T.grad).abs().max()) / (float(T.grad.abs().max()) + 1e-12)
-        assert err < (2e-3 if total_flips == 0 else 1e-1), ("pose grad", f, err)
+        _note("full_res ms=%s pose %s: rel-to-max err %.3e (total flips %d)" % (ms, f, err, total_flips))
+        assert err < (1e-4 if total_flips == 0 else 1e-1), ("pose grad", f, err)
 
 
 def test_full_size_properties(backend):
@@ -281,7 +294,8 @@ def test_smoothness_kernel_against_oracle(backend):
         got.backward()
         assert abs(float(got) - float(ref)) < 2e-6 * max(1.0, abs(float(ref))), (float(got), float(ref))
         err = float((dg.grad.cpu() - dc.grad).abs().max()) / float(dc.grad.abs().max())
-        assert err < 1e-3, (s, err)
+        _note("smoothness scale %d: grad rel-to-max err %.3e" % (s, err))
+        assert err < 1e-4, (s, err)
 
 
 def test_pose_matrix_kernel(backend):
@@ -335,7 +349,8 @@ def test_no_ssim_option_on_gpu(name, backend):
         assert int((mism & (out["margin/%d" % s] > 2e-4)).sum()) == 0
         g, ge = case.disp[s].grad.cpu(), ref.disp[s].grad
         rel = (g - ge).abs() / float(ge.abs().max())
-        assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum())
+        _note("no_ssim/extreme scale %d: flips %d, texels off %d, max rel %.3e" % (s, int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
+        assert int((rel > 1e-4).sum()) <= 40 * int(mism.sum())
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
 
 
@@ -358,7 +373,8 @@ def test_edge_of_domain_poses_and_depths_on_gpu(backend):
         flips += int(mism.sum())
         g, ge = case.disp[s].grad.cpu(), ref.disp[s].grad
         rel = (g - ge).abs() / (float(ge.abs().max()) + 1e-12)
-        assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum()) + 4      # +4: clamp decisions at |ix - border| ~ ulp
+        _note("extreme scale %d: flips %d, texels off %d, max rel %.3e" % (s, int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
+        assert int((rel > 1e-4).sum()) <= 40 * int(mism.sum()) + 4      # +4: clamp decisions at |ix - border| ~ ulp
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
 
 
@@ -430,5 +446,6 @@ def test_sizes_off_the_tile_grid_on_gpu(H, W, backend):
     assert int((mism & (out["margin/0"] > 2e-4)).sum()) == 0
     g, ge = case.disp[0].grad.cpu(), ref.disp[0].grad
     rel = (g - ge).abs() / float(ge.abs().max())
-    assert int((rel > 2e-3).sum()) <= 40 * int(mism.sum()) + 4
+    _note("odd size: flips %d, texels off %d, max rel %.3e" % (int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
+    assert int((rel > 1e-4).sum()) <= 40 * int(mism.sum()) + 4
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5

@@ -10,6 +10,7 @@ from fake_nets import FakePoseEncoder, fill_deterministic
 from fused_runner import bare_trainer, make_opt, compare_with_golden
 from golden_io import Case, POSE_CASES, GOLDEN_DIR
 from host_port import HostPortBackend
+from pose_checks import check_pose_case
 from baseboostdepth_amd import networks
 
 
@@ -24,48 +25,7 @@ def _fkey(f):
 
 @pytest.mark.parametrize("name", POSE_CASES)
 def test_predict_poses_and_step(name, backend):
-    case = Case(name)
-    opt = make_opt(case, materialize_warps=False)
-    tr = bare_trainer(opt, backend, "cpu")
-    penc = fill_deterministic(FakePoseEncoder(), 0.1)
-    pdec = fill_deterministic(networks.PoseDecoder(penc.num_ch_enc, 1, 2), 0.2)
-    tr.models = {"pose_encoder": penc, "pose": pdec}
-    inputs = dict(case.inputs)
-    inputs["noise"] = case.noise
-    tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
-    tr.valid_frames_trimin(inputs)
-    outputs = tr.predict_poses(inputs)
-    # every pose tensor the reference produced, same key set, same values
-    want = {k for k in case.z.files if k.startswith("out/cam_T_cam")}
-    got = {"out/%s/%s/%s" % (k[0], _fkey(k[1]), _fkey(k[2])) for k in outputs}
-    assert got == want
-    for k in outputs:
-        e = case.expected("out/%s/%s/%s" % (k[0], _fkey(k[1]), _fkey(k[2])))
-        assert outputs[k].shape == e.shape, k
-        assert torch.allclose(outputs[k].detach(), e, atol=2e-6, rtol=1e-5), (k, float((outputs[k] - e).abs().max()))
-    for s in case.scales:
-        outputs[("disp", s)] = case.disp[s]
-    outputs.update(tr.generate_images_pred(inputs, outputs))
-    losses = tr.compute_losses(inputs, outputs)
-    # poses differ from the reference's by fp32 round-off of a different op graph, so use the
-    # tolerance protocol (loss 1e-5, arg-min equal off ties)
-    compare_with_golden(case, tr, outputs, losses, map_tol=1e-4, tie_margin=2e-4, check_warps=False)
-    losses["loss"].backward()
-    params = {"pose_encoder/" + k: p for k, p in penc.named_parameters()}
-    params.update({"pose/" + k: p for k, p in pdec.named_parameters()})
-    for k, p in params.items():
-        g = p.grad if p.grad is not None else torch.zeros_like(p)
-        if case.has("grad/w/" + k):
-            e = case.expected("grad/w/" + k)
-            scale = float(e.abs().max()) + 1e-12
-            assert float((g - e).abs().max()) / scale < 5e-3, k
-        else:
-            e = case.expected("gradsum/w/" + k)
-            assert abs(g.double().sum().item() - float(e[0])) <= 5e-3 * float(e[1]) + 1e-9, k
-    for s in case.scales:
-        ge = case.expected("grad/disp/%d" % s)
-        rel = (case.disp[s].grad - ge).abs() / float(ge.abs().max())
-        assert float(rel.max()) < 5e-3, (s, float(rel.max()))
+    check_pose_case(name, backend, "cpu")
 
 
 def test_decoders_match_reference_and_state_dict_keys():
