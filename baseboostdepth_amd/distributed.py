@@ -216,11 +216,11 @@ def attach(trainer, group=None):
     PyTorch's own per-parameter gradients (nothing to exchange, nothing to pack)."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return None
-    flat = FlatGradients(trainer.parameters_to_train)
+    flat = FlatGradients(getattr(trainer, "optimizer_parameters", None) or trainer.parameters_to_train)
     trainer.flat_grads = flat
     if True:
         # identical initial weights on every rank
-        for p in trainer.parameters_to_train:
+        for p in flat.params:
             dist.broadcast(p.data, src=0, group=group)
         for m in trainer.models.values():
             for b in m.buffers():

@@ -42,11 +42,13 @@ _FLAGS = [
     ("--eval_split", dict(type=str, default="eigen")), ("--save_pred_disps", dict(action="store_true")),
     ("--post_process", dict(action="store_true")),
     # this build
+    # MonoViT (BASELINE configs[4]): MPViT-small encoder + HR decoder, AdamW with two LR groups
+    ("--ViT", dict(action="store_true")), ("--mpvit_checkpoint", dict(type=str, default="./ckpt/mpvit_small.pth")),
     ("--materialize_warps", dict(action="store_true")), ("--synthetic", dict(action="store_true")),
     ("--step_graph", dict(action="store_true")), ("--loader_workers", dict(type=str, default="process", choices=["process", "thread"])),
 ]
 # other zoos / datasets of the reference: parsed, refused when set
-_OUT_OF_SCOPE = ["--SYNS_eval", "--SQL", "--SQL_L", "--CA_depth", "--DIFFNet", "--ViT", "--chamfer", "--stereo_guide",
+_OUT_OF_SCOPE = ["--SYNS_eval", "--SQL", "--SQL_L", "--CA_depth", "--DIFFNet", "--chamfer", "--stereo_guide",
                  "--x_min", "--png", "--use_stereo", "--eval_eigen_to_benchmark"]
 
 

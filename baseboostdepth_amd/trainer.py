@@ -38,21 +38,40 @@ class Trainer:
 
         self.models = {}
         self.parameters_to_train = []
-        self.models["encoder"] = networks.ResnetEncoder(opt.num_layers, opt.weights_init == "pretrained")
-        self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, opt.scales)
+        self.use_vit = bool(getattr(opt, "ViT", False))
+        if self.use_vit:
+            # MonoViT (BASELINE configs[4], trainer.py:52-58): MPViT-small encoder + HR decoder.  The
+            # encoder's parameters go into their own optimizer group below, not into parameters_to_train.
+            from . import networksvit
+            ckpt = getattr(opt, "mpvit_checkpoint", "./ckpt/mpvit_small.pth") if opt.weights_init == "pretrained" else None
+            self.models["encoder"] = networksvit.mpvit_small(checkpoint=ckpt)
+            self.models["encoder"].num_ch_enc = [64, 128, 216, 288, 288]
+            self.models["depth"] = networksvit.DepthDecoder()
+        else:
+            self.models["encoder"] = networks.ResnetEncoder(opt.num_layers, opt.weights_init == "pretrained")
+            self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, opt.scales)
         self.models["pose_encoder"] = networks.ResnetEncoder(18, opt.weights_init == "pretrained",
                                                              num_input_images=self.num_pose_frames)
         self.models["pose"] = networks.PoseDecoder(self.models["pose_encoder"].num_ch_enc,
                                                    num_input_features=1, num_frames_to_predict_for=2)
         for name in ("encoder", "depth", "pose_encoder", "pose"):
             self.models[name].to(self.device)
-            self.parameters_to_train += list(self.models[name].parameters())
-        # same Adam hyper-parameters as the reference (trainer.py:111); on the GPU the single-kernel
-        # "fused" implementation replaces ~20 multi-tensor launches per step
+            if not (self.use_vit and name == "encoder"):
+                self.parameters_to_train += list(self.models[name].parameters())
+        # same optimizer hyper-parameters as the reference (trainer.py:106-111): Adam(lr) for the ResNet
+        # path; AdamW with two groups for MonoViT - everything but the encoder at 1e-4, the encoder at 5e-5.
+        # On the GPU the single-kernel "fused" implementation replaces ~20 multi-tensor launches per step
         fused = self.device.type == "cuda" and getattr(opt, "fused_adam", True)
         self.use_graph = bool(fused and (getattr(opt, "step_graph", False) or os.environ.get("BBD_STEP_GRAPH") == "1"))
-        self.model_optimizer = optim.Adam(self.parameters_to_train, opt.learning_rate, fused=fused,
-                                          capturable=self.use_graph)
+        if self.use_vit:
+            self.params = [{"params": self.parameters_to_train, "lr": 1e-4},
+                           {"params": list(self.models["encoder"].parameters()), "lr": 5e-5}]
+            self.model_optimizer = optim.AdamW(self.params, fused=fused, capturable=self.use_graph)
+        else:
+            self.model_optimizer = optim.Adam(self.parameters_to_train, opt.learning_rate, fused=fused,
+                                              capturable=self.use_graph)
+        # every parameter the optimizer steps, in group order (the gradient exchange packs exactly these)
+        self.optimizer_parameters = [p for g in self.model_optimizer.param_groups for p in g["params"]]
         self._graphs = {}
         self.model_lr_scheduler = optim.lr_scheduler.MultiStepLR(
             self.model_optimizer, milestones=[11, 13, 15, 16, 17, 18, 19], gamma=0.4)
@@ -77,6 +96,11 @@ class Trainer:
             fc = getattr(enc, "fc", None)
             if fc is not None:
                 out += list(fc.parameters())
+        if getattr(self, "use_vit", False):
+            # the HR decoder builds X_0j_Conv_0 (j = 0..3) and never calls them (reference
+            # networksvit/hr_decoder.py:36-48 vs its forward)
+            for j in range(4):
+                out += list(self.models["depth"].convs["X_0%d_Conv_0" % j].parameters())
         return out
 
     # ------------------------------------------------------------------ mode switches

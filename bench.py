@@ -40,14 +40,15 @@ SCALES = [0, 1, 2, 3]
 
 def make_options(batch, device_index, config):
     import types
-    boosted = config != "md2"
+    boosted = config not in ("md2", "vit")
     one_scale = config in ("boosted", "boosted15")
     return types.SimpleNamespace(
         height=H, width=W, batch_size=batch, scales=([0] if one_scale else list(SCALES)), frame_ids=[0, -1, 1],
         min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False,
         trimin=boosted, decomp=boosted, pose_error=5.5, incremental_skip=boosted, partial_skip=boosted,
         materialize_warps=False, num_layers=18, weights_init="scratch", learning_rate=1e-4,
-        no_cuda=False, cuda=device_index, load_weights_folder="None", log_dir="/tmp", model_name="bench")
+        no_cuda=False, cuda=device_index, load_weights_folder="None", log_dir="/tmp", model_name="bench",
+        ViT=(config == "vit"))
 
 
 def algorithmic_bytes(plan, S):

@@ -40,7 +40,7 @@ def check_pose_case(name, backend, device):
     losses = tr.compute_losses(inputs, outputs)
     # poses differ from the reference's by fp32 round-off of a different op graph, so use the
     # tolerance protocol (loss 1e-5, arg-min equal off ties)
-    compare_with_golden(case, tr, outputs, losses, map_tol=1e-4, tie_margin=2e-4, check_warps=False)
+    report = compare_with_golden(case, tr, outputs, losses, map_tol=1e-4, tie_margin=2e-4, check_warps=False)
     losses["loss"].backward()
     params = {"pose_encoder/" + k: p for k, p in penc.named_parameters()}
     params.update({"pose/" + k: p for k, p in pdec.named_parameters()})
@@ -56,6 +56,9 @@ def check_pose_case(name, backend, device):
     for s in case.scales:
         ge = case.expected("grad/disp/%d" % s)
         rel = (case.disp[s].grad.cpu() - ge).abs() / float(ge.abs().max())
-        assert float(rel.max()) < 5e-3, (s, float(rel.max()))
+        # a near-tie pixel whose arg-min flipped (poses differ by round-off) re-routes gradient inside its
+        # 3x3 window and the 2x2 bilinear footprints below it: <= 25 texels per flip (observed <= 23)
+        flips = report.get("flips/%d" % s, 0)
+        assert int((rel > 5e-3).sum()) <= 25 * flips, (s, flips, int((rel > 5e-3).sum()), float(rel.max()))
 
 

@@ -219,7 +219,7 @@ def test_full_resolution_against_oracle(ms, trimin, decomp, scales, backend):
         n_bad = int((rel > 1e-4).sum())
         _note("full_res ms=%s scale %d: flips %d, texels off (>1e-4 of max) %d, max rel %.3e, L2 rel %.3e" % (
             ms, s, flips, n_bad, float(rel.max()), float((gg - ge).norm() / ge.norm())))
-        assert n_bad <= 40 * flips, ("disp grad", s, flips, n_bad, float(rel.max()))
+        assert n_bad <= 25 * flips, ("disp grad", s, flips, n_bad, float(rel.max()))
         assert float((gg - ge).norm() / ge.norm()) < (1e-4 if flips == 0 else 5e-2), ("disp grad L2", s)
     assert abs(float(losses["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
     for f, T in poses.items():
@@ -350,7 +350,7 @@ def test_no_ssim_option_on_gpu(name, backend):
         g, ge = case.disp[s].grad.cpu(), ref.disp[s].grad
         rel = (g - ge).abs() / float(ge.abs().max())
         _note("no_ssim/extreme scale %d: flips %d, texels off %d, max rel %.3e" % (s, int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
-        assert int((rel > 1e-4).sum()) <= 40 * int(mism.sum())
+        assert int((rel > 1e-4).sum()) <= 25 * int(mism.sum())
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
 
 
@@ -374,7 +374,7 @@ def test_edge_of_domain_poses_and_depths_on_gpu(backend):
         g, ge = case.disp[s].grad.cpu(), ref.disp[s].grad
         rel = (g - ge).abs() / (float(ge.abs().max()) + 1e-12)
         _note("extreme scale %d: flips %d, texels off %d, max rel %.3e" % (s, int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
-        assert int((rel > 1e-4).sum()) <= 40 * int(mism.sum()) + 4      # +4: clamp decisions at |ix - border| ~ ulp
+        assert int((rel > 1e-4).sum()) <= 25 * int(mism.sum()) + 4      # +4: clamp decisions at |ix - border| ~ ulp
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
 
 
@@ -447,5 +447,5 @@ def test_sizes_off_the_tile_grid_on_gpu(H, W, backend):
     g, ge = case.disp[0].grad.cpu(), ref.disp[0].grad
     rel = (g - ge).abs() / float(ge.abs().max())
     _note("odd size: flips %d, texels off %d, max rel %.3e" % (int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
-    assert int((rel > 1e-4).sum()) <= 40 * int(mism.sum()) + 4
+    assert int((rel > 1e-4).sum()) <= 25 * int(mism.sum()) + 4
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5

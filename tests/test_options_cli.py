@@ -22,7 +22,7 @@ def test_boosted_command_line_and_refusals():
     o = MonodepthOptions().parse("--rand --trimin --decomp --incremental_skip --partial_skip --naive_mix --kt "
                                  "--pose_error 5.5 --weights_init scratch --batch_size 4".split())
     assert o.rand and o.trimin and o.decomp and o.incremental_skip and o.partial_skip and o.pose_error == 5.5
-    for flag in ("--ViT", "--SQL", "--CA_depth", "--DIFFNet", "--SYNS_eval"):
+    for flag in ("--SQL", "--CA_depth", "--DIFFNet", "--SYNS_eval"):
         with pytest.raises(SystemExit):
             MonodepthOptions().parse([flag])
 
@@ -37,3 +37,21 @@ def test_namespace_constructs_trainer_on_cpu():
     batch = synthetic.synthetic_batch([1, 1], 64, 128, o.scales, device="cpu", seed=0)
     with pytest.raises(BbdError):                       # no CPU fallback for the hot path
         tr.process_batch(batch)
+
+
+def test_vit_flag_builds_monovit_with_two_lr_groups():
+    """--ViT (reference trainer.py:52-58, 106-109): MPViT-small + HR decoder, AdamW, encoder in its own
+    5e-5 group and NOT in parameters_to_train."""
+    import torch
+    from baseboostdepth_amd import Trainer, networksvit
+    o = MonodepthOptions().parse("--ViT --no_cuda --weights_init scratch --height 64 --width 128 --batch_size 2".split())
+    tr = Trainer(o)
+    assert isinstance(tr.models["encoder"], networksvit.MPViT) and isinstance(tr.models["depth"], networksvit.DepthDecoder)
+    assert tr.models["encoder"].num_ch_enc == [64, 128, 216, 288, 288]
+    assert isinstance(tr.model_optimizer, torch.optim.AdamW)
+    g0, g1 = tr.model_optimizer.param_groups
+    assert (g0["lr"], g1["lr"]) == (1e-4, 5e-5)
+    enc_ids = {id(p) for p in tr.models["encoder"].parameters()}
+    assert {id(p) for p in g1["params"]} == enc_ids and not (enc_ids & {id(p) for p in tr.parameters_to_train})
+    assert len(tr.optimizer_parameters) == len(g0["params"]) + len(g1["params"])
+    assert len(tr.gradient_free_parameters()) == 2 + 8          # pose encoder fc + the decoder's unused X_0j_Conv_0

@@ -58,3 +58,18 @@ def test_resume_epoch_parsing():
     for folder, want in (("/x/weights_9", 10), ("/x/weights_best", 10), ("/x/weights_3_1200/", 1201), ("w_0", 1)):
         tr.opt.load_weights_folder = folder
         assert tr.resume_epoch() == want, folder
+
+
+def test_vit_process_batch_on_cpu_host_port():
+    """--ViT wiring on the CPU tier: MonoViT networks + the host port of the loss kernels, one step."""
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    o = MonodepthOptions().parse(("--ViT --no_cuda --weights_init scratch --height %d --width %d --batch_size %d"
+                                  % (H, W, B)).split())
+    tr = Trainer(o, backend=HostPortBackend())
+    tr.set_train()
+    batch = synthetic.synthetic_batch([1] * B, H, W, o.scales, device="cpu", seed=1)
+    before = [p.detach().clone() for p in tr.models["encoder"].parameters()]
+    outputs, losses = tr.train_step(batch)
+    assert torch.isfinite(losses["loss"]) and outputs[("disp", 0)].shape == (B, 1, H, W)
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.models["encoder"].parameters()))
