@@ -106,9 +106,9 @@ __device__ __forceinline__ void strip_of_thread(int* ly, int* lx0) {
 // cells ONCE (no index math in the candidate loop) and keeps their depth in registers.  Threads
 // past the end of the region duplicate the last cell (same value to the same LDS word), which
 // keeps the loops branch-free so that all loads of a phase are in flight together.
-template <int ROWS, int COLS, int STRIDE, int HALO>
+template <int ROWS, int COLS, int STRIDE, int HALO, int NTH = NT>
 struct Cells {
-  static constexpr int N = (ROWS * COLS + NT - 1) / NT;
+  static constexpr int N = (ROWS * COLS + NTH - 1) / NTH;
   int lds[N];    // r * STRIDE + c
   int pix[N];    // yy * W + xx of the (reflected) image pixel
   int xy[N];     // yy << 16 | xx
@@ -118,7 +118,7 @@ struct Cells {
   __device__ __forceinline__ void init(int H, int W, int tx0, int ty0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      int i = k * NT + (int)threadIdx.x;
+      int i = k * NTH + (int)threadIdx.x;
       i = i < ROWS * COLS ? i : ROWS * COLS - 1;
       const int r = i / COLS, c = i - r * COLS;
       const int py = ty0 + r - HALO, px = tx0 + c - HALO;
@@ -158,11 +158,11 @@ __device__ __forceinline__ void load_depth(const float* __restrict__ depth, cons
 }
 
 // Warp one source image into the staged region for one pose-table row.
-template <int BATCH, typename CellsT, int PLANE>
+template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
-                                              float* __restrict__ warped_out, float (*dv)[TH * TW] = nullptr) {
+                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr) {
   // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
@@ -240,11 +240,23 @@ template <int STRIDE>
 __device__ __forceinline__ void load_window(const float* plane, int r0, int c0, float win[3][8]) {
   static_assert(STRIDE % 4 == 0, "rows must stay 16-byte aligned");
   // index in float4 units so the compiler keeps the 16-byte alignment and emits ds_read_b128
-  const float4* p4 = reinterpret_cast<const float4*>(plane) + (r0 * (STRIDE / 4) + (c0 >> 2));
+  // hipcc narrows these loads to the 6 columns that are used and re-pairs them (ds_read_b128 + ds_read2_b32 /
+  // ds_read_b64).  -DBBD_WINDOW_WHOLE forces both halves to stay whole 16-byte reads (volatile, explicit LDS
+  // address space); measured A/B (profiles/r02/lds_window_ab.txt): identical SQ_LDS_BANK_CONFLICT (7.4 % of
+  // the forward's LDS cycles either way) and SQ_LDS_IDX_ACTIVE, and the forced form is 8 % SLOWER (register
+  // pressure / load ordering) - so the compiler's pairing stays the default.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+#ifndef BBD_WINDOW_WHOLE
+  const v4f* p4 = reinterpret_cast<const v4f*>(plane) + (r0 * (STRIDE / 4) + (c0 >> 2));
+#else
+  // (explicit LDS address space: a volatile access through a generic pointer would become flat_load)
+  typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
+  lds_v4f_ptr p4 = (lds_v4f_ptr)(plane) + (r0 * (STRIDE / 4) + (c0 >> 2));
+#endif
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const float4 a = p4[r * (STRIDE / 4)];
-    const float4 b = p4[r * (STRIDE / 4) + 1];
+    const v4f a = p4[r * (STRIDE / 4)];
+    const v4f b = p4[r * (STRIDE / 4) + 1];
     win[r][0] = a.x; win[r][1] = a.y; win[r][2] = a.z; win[r][3] = a.w;
     win[r][4] = b.x; win[r][5] = b.y; win[r][6] = b.z; win[r][7] = b.w;
   }
@@ -824,6 +836,345 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
 
   if (q_row_ok)
     store_strip(a.grad_depth + sb * hw + qy * W + qx0, qx0, W, (qx0 + PPT <= W) && ((W & 3) == 0), gdepth);
+  BBD_STAMP(20);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused backward, narrow-tile form (the shipped one): the same LDS images and phases as above on a
+// 32x16-pixel tile, 256 threads = 4 waves, a 2-pixel strip per thread.  Per-thread state halves (3 staged
+// cells instead of 6, 2-pixel windows) -> 128 VGPRs, and the LDS images halve -> 38.5 KB per workgroup, so
+// FOUR independent workgroups = 16 waves per CU = 4 waves per SIMD are resident instead of two: the warp and
+// sample-gradient phases wait on gather latency, which only other resident waves can hide, and a barrier of
+// one workgroup (4 waves) no longer idles half the CU.  Measured (profiles/r02/bwd_variants.txt): 64-wide
+// tile / 4 waves / 2 per SIMD 0.378 ms; 64-wide / 8 waves / 4 per SIMD 0.401 ms (8-wave barriers eat the
+// occupancy gain); this form - see the table there.  The halo'd warp region grows from 1.33x to 1.41x of the
+// tile.  2-pixel windows are 8-byte aligned ds_read_b64.
+// ------------------------------------------------------------------------------------------
+constexpr int TW2 = 32;              // backward tile width (pixels); height stays TH
+constexpr int NT2 = 256;
+constexpr int PPT2 = 2;
+constexpr int SPR2 = TW2 / PPT2;     // 16 strips per tile row
+constexpr int BS2 = TW2 + 4;         // 36: row stride of the x / y regions (TH+4) x (TW2+4)
+constexpr int BW2 = TW2 + 4;
+constexpr int BPLANE2 = BH * BS2;
+constexpr int CS2 = TW2 + 4;         // 36: row stride of the coefficient region (TH+2) x (TW2+2)
+constexpr int CW2 = TW2 + 2;
+constexpr int CPLANE2 = CH * CS2;
+
+__device__ __forceinline__ TileCoord decode_tile2(int t, int W) {
+  const int tiles_x = (W + TW2 - 1) / TW2;
+  TileCoord c;
+  c.tile = t;
+  c.ty0 = (t / tiles_x) * TH;
+  c.tx0 = (t % tiles_x) * TW2;
+  return c;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void load_window4(const float* plane, int r0, int c0, float win[3][4]) {
+  static_assert(STRIDE % 2 == 0, "rows must stay 8-byte aligned");
+  typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef BBD_WINDOW_WHOLE
+  const v2f* p2 = reinterpret_cast<const v2f*>(plane) + (r0 * (STRIDE / 2) + (c0 >> 1));
+#else
+  typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;     // whole ds_read_b64, see load_window
+  lds_v2f_ptr p2 = (lds_v2f_ptr)(plane) + (r0 * (STRIDE / 2) + (c0 >> 1));
+#endif
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const v2f a = p2[r * (STRIDE / 2)];
+    const v2f b = p2[r * (STRIDE / 2) + 1];
+    win[r][0] = a.x; win[r][1] = a.y; win[r][2] = b.x; win[r][3] = b.y;
+  }
+}
+
+#ifndef BBD_BWD2_WGS
+#define BBD_BWD2_WGS 4   // waves per SIMD (HIP: second __launch_bounds__ argument): 2 workgroups per CU need <= 128 VGPRs
+#endif
+#ifndef BBD_BWD2_WARP_BATCH
+#define BBD_BWD2_WARP_BATCH 3
+#endif
+__global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_ybuf[3 * BPLANE2 + 8];
+  __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE2 + 8];
+  __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE2];
+  __shared__ uint16_t s_list[CH * CW2];
+  __shared__ __attribute__((aligned(16))) float s_dv[6][TH * TW2];
+  __shared__ float s_red[NT2 / 64][12];
+  __shared__ unsigned s_present;
+  __shared__ int s_count;
+  float (*s_y)[BPLANE2] = reinterpret_cast<float (*)[BPLANE2]>(s_ybuf);
+  float (*s_x)[BPLANE2] = reinterpret_cast<float (*)[BPLANE2]>(s_xbuf);
+  const BbdDims dm = a.dm;
+  const int H = dm.H, W = dm.W, hw = H * W;
+  int bid = blockIdx.x;
+  const int b = bid / (a.S * a.ntiles);
+  bid -= b * a.S * a.ntiles;
+  const int s = bid / a.ntiles;
+  const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
+  const size_t img = (size_t)3 * hw;
+  const size_t sb = (size_t)s * a.B + b;
+  const float* depth = a.depth + sb * hw;
+  const uint8_t* am = a.argmin + sb * hw;
+  const float g = a.gscale[s];
+  const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
+  const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
+
+  BBD_STAMP(0);
+  // setup: issue every global load first, then the LDS work that does not depend on them
+  constexpr int NP_CELLS = (CH * CW2 + NT2 - 1) / NT2;
+  int pcell[NP_CELLS];
+  unsigned parg[NP_CELLS];
+#pragma unroll
+  for (int k = 0; k < NP_CELLS; ++k) {
+    const int i = k * NT2 + (int)threadIdx.x;
+    const int r = i / CW2, c = i - r * CW2;
+    const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
+    const bool in = i < CH * CW2 && py >= 0 && py < H && px >= 0 && px < W;
+    pcell[k] = r * CS2 + c;
+    parg[k] = in ? (unsigned)am[py * W + px] : 255u;
+  }
+  typedef Cells<BH, BW2, BS2, 2, NT2> CellsB;
+  CellsB cl;
+  cl.init(H, W, tc.tx0, tc.ty0);
+  float tcell[CellsB::N][3];
+  {
+    const float* tg = a.target + (size_t)b * img;
+#pragma unroll
+    for (int k = 0; k < CellsB::N; ++k) {
+      tcell[k][0] = tg[cl.pix[k]];
+      tcell[k][1] = tg[cl.pix[k] + hw];
+      tcell[k][2] = tg[cl.pix[k] + 2 * hw];
+    }
+  }
+  float dcell[CellsB::N];
+  load_depth(depth, cl, dcell);
+
+  const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
+  const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
+  const bool q_row_ok = qy < H;
+  const bool q_vec_ok = (qx0 + PPT2 <= W) && ((W & 1) == 0);
+  unsigned qarg[PPT2];
+#pragma unroll
+  for (int j = 0; j < PPT2; ++j) qarg[j] = (q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u;
+  const bool interior = tc.tx0 >= 2 && tc.tx0 + TW2 + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
+  float gdepth[PPT2] = {0.0f, 0.0f};
+  float qdepth[PPT2] = {1.0f, 1.0f};
+  if (q_row_ok) {
+    if (q_vec_ok) {
+      const float2 t = *reinterpret_cast<const float2*>(depth + qy * W + qx0);
+      qdepth[0] = t.x; qdepth[1] = t.y;
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j)
+        if (qx0 + j < W) qdepth[j] = depth[qy * W + qx0 + j];
+    }
+  }
+
+  if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
+  for (int i = threadIdx.x; i < 3 * CPLANE2 / 4; i += NT2)
+    reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  {
+    unsigned mine = 0u;
+#pragma unroll
+    for (int k = 0; k < NP_CELLS; ++k)
+      if (parg[k] != 255u) mine |= 1u << parg[k];
+    if (mine) atomicOr(&s_present, mine);
+  }
+#pragma unroll
+  for (int k = 0; k < CellsB::N; ++k) {
+    s_y[0][cl.lds[k]] = tcell[k][0];
+    s_y[1][cl.lds[k]] = tcell[k][1];
+    s_y[2][cl.lds[k]] = tcell[k][2];
+  }
+  BBD_STAMP(1);
+  __syncthreads();
+  BBD_STAMP(2);
+  const unsigned present = s_present;
+
+  const int nc = a.ncand[b];
+  int prev = -1;
+  for (int c = 0; c < nc; ++c) {
+    const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
+    if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
+    float* gp_out = a.grad_proj + (((size_t)s * a.NP + cd.pose) * a.ntiles + tc.tile) * 12;
+    if (!((present >> c) & 1u)) {
+      if (threadIdx.x < 12) gp_out[threadIdx.x] = 0.0f;
+      continue;
+    }
+    const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
+    const float* pose_row = a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE;
+
+    // ---- phase W
+    if (!a.no_ssim) {
+#pragma unroll
+      for (int k = 0; k < NP_CELLS; ++k) {
+        if ((int)parg[k] == prev) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
+        }
+        if (parg[k] == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
+      }
+    }
+    prev = c;
+    BBD_STAMP(4 + 8 * (c & 1));
+    warp_into_lds<BBD_BWD2_WARP_BATCH>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
+    BBD_STAMP(5 + 8 * (c & 1));
+    __syncthreads();
+    BBD_STAMP(6 + 8 * (c & 1));
+
+    // ---- phases C/G, one colour channel at a time
+    const int nwin = a.no_ssim ? 0 : s_count;
+    float gx[3][PPT2];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      for (int idx = threadIdx.x; idx < nwin; idx += NT2) {
+        const int cell = s_list[idx];
+        const int pr = cell / CS2, pc = cell - pr * CS2;
+        float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+          for (int dc = 0; dc < 3; ++dc) {
+            const float xv = s_x[ch][(pr + dr) * BS2 + pc + dc], yv = s_y[ch][(pr + dr) * BS2 + pc + dc];
+            sx_ += xv; sxx += xv * xv; sxy += xv * yv; sy_ += yv; syy += yv * yv;
+          }
+        float mu_y, sg_y, A, Bc, Cc;
+        bbd_ystats(sy_, syy, &mu_y, &sg_y);
+        bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
+        s_cf[0][cell] = A * w_ssim;
+        s_cf[1][cell] = Bc * w_ssim;
+        s_cf[2][cell] = Cc * w_ssim;
+      }
+      if (ch == 0) BBD_STAMP(7 + 8 * (c & 1));
+      __syncthreads();
+      if (ch == 0) BBD_STAMP(8 + 8 * (c & 1));
+      if (ch == 0 && threadIdx.x == 0) s_count = 0;
+
+      // G: adjoint of reflect-pad + 3x3 mean at this thread's 2 texels
+      const float2 xq2 = *reinterpret_cast<const float2*>(&s_x[ch][(ly + 2) * BS2 + lx0 + 2]);
+      const float2 yq2 = *reinterpret_cast<const float2*>(&s_y[ch][(ly + 2) * BS2 + lx0 + 2]);
+      const float xqv[PPT2] = {xq2.x, xq2.y}, yqv[PPT2] = {yq2.x, yq2.y};
+      float S3[3][PPT2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < PPT2; ++j) S3[pl][j] = 0.0f;
+      if (!a.no_ssim) {
+        if (interior) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            float cw[3][4];
+            load_window4<CS2>(s_cf[pl], ly, lx0, cw);
+            float col[PPT2 + 2];
+#pragma unroll
+            for (int i = 0; i < PPT2 + 2; ++i) col[i] = (cw[0][i] + cw[1][i]) + cw[2][i];
+#pragma unroll
+            for (int j = 0; j < PPT2; ++j) S3[pl][j] = (col[j] + col[j + 1]) + col[j + 2];
+          }
+        } else {
+          float wy[3], wx[PPT2][3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int py = qy + d - 1;
+            wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < PPT2; ++j) {
+              const int px = qx0 + j + d - 1;
+              wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
+            }
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            float cw[3][4];
+            load_window4<CS2>(s_cf[pl], ly, lx0, cw);
+#pragma unroll
+            for (int j = 0; j < PPT2; ++j)
+#pragma unroll
+              for (int dr = 0; dr < 3; ++dr) {
+                float r = 0.0f;
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc) r = fmaf(wx[j][dc], cw[dr][j + dc], r);
+                S3[pl][j] = fmaf(wy[dr], r, S3[pl][j]);
+              }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j) {
+        const float xq = xqv[j], yq = yqv[j];
+        float acc = (S3[0][j] + xq * S3[1][j] + yq * S3[2][j]) * (1.0f / 9.0f);
+        if (qarg[j] == (unsigned)c) {
+          const float df = xq - yq;
+          acc += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+        }
+        gx[ch][j] = (q_row_ok && qx0 + j < W) ? acc : 0.0f;
+      }
+      if (ch < 2 && !a.no_ssim) __syncthreads();
+    }
+
+    BBD_STAMP(9 + 8 * (c & 1));
+    // texel gradient -> sampling coordinates -> depth and P
+    float gP[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
+    if (q_row_ok) {
+      float pj[21];
+#pragma unroll
+      for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
+      float dxy[6][PPT2];
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) {
+        const float2 q = *reinterpret_cast<const float2*>(&s_dv[pl][ly * TW2 + lx0]);
+        dxy[pl][0] = q.x; dxy[pl][1] = q.y;
+      }
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j) {
+        const int qx = qx0 + j;
+        if (qx >= W) continue;
+        if (gx[0][j] == 0.0f && gx[1][j] == 0.0f && gx[2][j] == 0.0f) continue;
+        const float gix = gx[0][j] * dxy[0][j] + gx[1][j] * dxy[1][j] + gx[2][j] * dxy[2][j];
+        const float giy = gx[0][j] * dxy[3][j] + gx[1][j] * dxy[4][j] + gx[2][j] * dxy[5][j];
+        BbdSample sm;
+        bbd_sample_smooth(pj, qx, qy, qdepth[j], &sm);
+        float gd, gp1[12];
+        bbd_project_grad(pj, &sm, gix, giy, &gd, gp1);
+        gdepth[j] += gd;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gP[k] += gp1[k];
+      }
+    }
+    if (cd.kind & FLAG_NO_POSE_GRAD) {
+      if (threadIdx.x < 12) gp_out[threadIdx.x] = 0.0f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const float ws = wave_sum63(gP[k]);
+        if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6][k] = ws;
+      }
+    }
+    BBD_STAMP(10 + 8 * (c & 1));
+    __syncthreads();
+    BBD_STAMP(11 + 8 * (c & 1));
+    if (!(cd.kind & FLAG_NO_POSE_GRAD) && threadIdx.x < 12) {
+      float t = s_red[0][threadIdx.x];
+#pragma unroll
+      for (int w8 = 1; w8 < NT2 / 64; ++w8) t += s_red[w8][threadIdx.x];
+      gp_out[threadIdx.x] = t;
+    }
+  }
+
+  if (q_row_ok) {
+    float* o = a.grad_depth + sb * hw + qy * W + qx0;
+    if (q_vec_ok) {
+      *reinterpret_cast<float2*>(o) = make_float2(gdepth[0], gdepth[1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j)
+        if (qx0 + j < W) o[j] = gdepth[j];
+    }
+  }
   BBD_STAMP(20);
 }
 
@@ -1494,6 +1845,13 @@ int bbd_abi_version(void) { return BBD_ABI_VERSION; }
 int bbd_tile_w(void) { return TW; }
 int bbd_tile_h(void) { return TH; }
 int bbd_num_tiles(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
+int bbd_num_tiles_bwd(int H, int W) {
+#if defined(BBD_BWD_256)
+  return bbd_num_tiles(H, W);
+#else
+  return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2);
+#endif
+}
 
 int bbd_identity_loss_fwd(const void* const* frames, const float* target, const int32_t* items, int NI,
                           float* ident, int H, int W, int no_ssim, void* stream) {
@@ -1545,9 +1903,14 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
   a.target = target; a.depth = depth; a.pose = proj; a.cand = cand; a.ncand = ncand; a.argmin = argmin;
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
-  a.ntiles = bbd_num_tiles(H, W);
+  a.ntiles = bbd_num_tiles_bwd(H, W);
+#if defined(BBD_BWD_256)        // the round-1 form (4 waves, 4-pixel strips): kept for A/B timing builds
   hipLaunchKernelGGL(warp_ssim_min_bwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
+#else
+  hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                     static_cast<hipStream_t>(stream), a);
+#endif
   return launch_status();
 }
 

@@ -62,6 +62,9 @@ class HipBackend:
     def num_tiles(self, H, W):
         return self.lib.num_tiles(H, W)
 
+    def num_tiles_bwd(self, H, W):
+        return self.lib.num_tiles_bwd(H, W)
+
     def smooth_chunks(self):
         return self.lib.smooth_chunks
 
@@ -286,7 +289,7 @@ class _FusedReprojectionMin(torch.autograd.Function):
                     ptr(noise), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial),
                     ptr(warped), S, B, plan.NP, H, W, int(no_ssim))
         ctx.save_for_backward(depth, proj, target, argmin, ptab)
-        ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, ntiles)
+        ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, backend.num_tiles_bwd(H, W))
         ctx.mark_non_differentiable(min_loss, argmin)
         outs = (partial.view(S, -1).sum(dim=1), min_loss, argmin)
         if materialize:

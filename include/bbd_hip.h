@@ -66,6 +66,8 @@ int bbd_abi_version(void);
 int bbd_tile_w(void);
 int bbd_tile_h(void);
 int bbd_num_tiles(int H, int W);
+/* tiles of the BACKWARD launch (narrower tile): sizes grad_proj [S, NP, bbd_num_tiles_bwd(H,W), 12] */
+int bbd_num_tiles_bwd(int H, int W);
 
 /* Pose table [NP,40] -> projection table [NP,24]: P = (K@T)[:3,:] formed with the rounding order of
  * the reference's CPU torch.matmul (layers.py:182), inv_K[:3,:3] copied. */

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 out = "/tmp/bbdvar/libbbd_stamps.so"
 os.makedirs("/tmp/bbdvar", exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17",
-                "-fPIC", "-shared", "-DBBD_STAMPS", "-o", out] +
+                "-fPIC", "-shared", "-DBBD_STAMPS"] + os.environ.get("BBD_STAMPS_FLAGS", "").split() + ["-o", out] +
                [os.path.join(ROOT, "baseboostdepth_amd/csrc", f) for f in ("bbd_kernels.hip", "bbd_eval.hip", "bbd_image.hip", "bbd_nn.hip")],
                check=True)
 os.environ["BBD_HIP_LIB"] = out
@@ -27,7 +27,8 @@ plan = tr.valid_frames_trimin(inputs)
 disp = synthetic_disp(B, H, W, scales, device=dev, seed=1)
 outputs = {("disp", s): disp[s] for s in scales}
 outputs.update(synthetic_poses(plan, device=dev, seed=2))
-nblocks = 4 * B * be.num_tiles(H, W)
+nblocks_f = 4 * B * be.num_tiles(H, W)
+nblocks = 4 * B * max(be.num_tiles(H, W), be.num_tiles_bwd(H, W))     # the backward tile is narrower
 stamps = torch.zeros(nblocks * 32, dtype=torch.int64, device=dev)
 dll = be.lib._dll
 dll.bbd_debug_set_stamps.argtypes = [ctypes.c_void_p]
@@ -36,7 +37,7 @@ for _ in range(3):
 dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 tr.generate_images_pred(inputs, dict(outputs))
 torch.cuda.synchronize()
-st = stamps.view(nblocks, 32).cpu().double()
+st = stamps.view(nblocks, 32)[:nblocks_f].cpu().double()
 names = {(0, 1): "cells+stage target+depth issue", (1, 2): "wait loads + barrier", (2, 3): "ystats",
          (4, 5): "cand0 project+gather+blend", (5, 6): "cand0 barrier wait", (6, 7): "cand0 SSIM",
          (8, 9): "cand1 project+gather+blend", (9, 10): "cand1 barrier wait", (10, 11): "cand1 SSIM",
@@ -54,7 +55,7 @@ ls = o[("bbd", "loss_sum")]
 dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 ls.sum().backward()
 torch.cuda.synchronize()
-st = stamps.view(nblocks, 32).cpu().double()
+st = stamps.view(nblocks, 32)[:4 * B * be.num_tiles_bwd(H, W)].cpu().double()
 bn = {(0, 1): "setup: clear planes, arg ids, cells, stage", (1, 2): "barrier", (4, 5): "cand0 W: list + warp recompute",
       (5, 6): "cand0 barrier", (6, 7): "cand0 C: winners' SSIM partials", (7, 8): "cand0 barrier",
       (8, 9): "cand0 G: adjoint gather", (9, 10): "cand0 sample-grad + dP reduce", (10, 11): "cand0 barrier",
