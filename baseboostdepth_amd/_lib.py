@@ -65,6 +65,8 @@ SIGNATURES = {
     "bbd_dispconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_dispconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
+    "bbd_dwconv_tokens_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "bbd_dwconv_tokens_wgrad": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4
 EVAL_DESC, EVAL_OUT = 8, 12

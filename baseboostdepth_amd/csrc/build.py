@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, "bbd_kernels.hip"), os.path.join(HERE, "bbd_eval.hip"),
-        os.path.join(HERE, "bbd_image.hip"), os.path.join(HERE, "bbd_nn.hip")]
+        os.path.join(HERE, "bbd_image.hip"), os.path.join(HERE, "bbd_nn.hip"), os.path.join(HERE, "bbd_vit.hip")]
 OUT = os.path.join(HERE, "libbbd_hip.so")
 DEPS = SRCS + [os.path.join(HERE, "bbd_math.h"), os.path.join(HERE, "bbd_image_math.h"), os.path.join(HERE, "..", "..", "include", "bbd_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17"]

@@ -21,6 +21,8 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 __all__ = ["MPViT", "mpvit_tiny", "mpvit_xsmall", "mpvit_small", "mpvit_base"]
 
 _BN = dict(type="BN")
@@ -139,6 +141,11 @@ class Patch_Embed_stage(nn.Module):
         return outs
 
 
+def _hip_tokens(t):
+    """fp32 GPU tokens take the HIP depth-wise kernels (BBD_FUSED_NN=0 keeps the MIOpen path for A/B runs)."""
+    return t.is_cuda and t.dtype == torch.float32 and ops.FUSED_NN
+
+
 def _as_image(tokens, size):
     """[B, N, C] tokens -> [B, C, H, W] view in channels-last memory format (no copy)."""
     B, N, C = tokens.shape
@@ -159,6 +166,8 @@ class ConvPosEnc(nn.Module):
         self.proj = nn.Conv2d(dim, dim, k, 1, k // 2, groups=dim)
 
     def forward(self, x, size):
+        if _hip_tokens(x):           # one HIP launch, residual folded in (csrc/bbd_vit.hip)
+            return ops.dwconv_tokens(x, size, [self.proj], add_input=True)
         img = _as_image(x, size)
         return _as_tokens(self.proj(img) + img)
 
@@ -184,6 +193,8 @@ class ConvRelPosEnc(nn.Module):
 
     def conv_v(self, v_tokens, size):
         """v as `[B, N, h*Ch]` tokens (head-major channels) -> conv(v) in the same layout."""
+        if _hip_tokens(v_tokens):    # the three window sizes write their channel groups of one output
+            return ops.dwconv_tokens(v_tokens, size, list(self.conv_list))
         img = _as_image(v_tokens, size)
         parts = torch.split(img, self.channel_splits, dim=1)
         return _as_tokens(torch.cat([conv(p) for conv, p in zip(self.conv_list, parts)], dim=1))

@@ -430,6 +430,68 @@ def ssim_map(x, y, backend=None):
     return _SSIMMap.apply(x, y, backend or default_backend())
 
 
+# ---------------------------------------------------------------------------- MonoViT: depth-wise conv on tokens
+def _slice_ptr(t, c0):
+    return ctypes.c_void_p(t.data_ptr() + 4 * c0)
+
+
+class _DepthwiseTokens(torch.autograd.Function):
+    """Depth-wise k x k convolutions over token-layout activations [B, H*W, C] (csrc/bbd_vit.hip): channel
+    groups `splits` use their own (weight [n,1,k,k], bias [n]) - MPViT's ConvRelPosEnc gives head groups
+    windows 3 / 5 / 7, ConvPosEnc is one group with the residual folded in (`add_input`).  `x` may be a
+    channel-slice view of wider rows (v inside the packed qkv activation)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, add_input, backend, splits, *params):
+        B, N, C = x.shape
+        assert N == H * W and sum(splits) == C and x.dtype == torch.float32
+        if x.stride(2) != 1 or x.stride(0) != N * x.stride(1):
+            x = x.contiguous()
+        backend._check(x, *params)
+        y = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        c0 = 0
+        for i, n in enumerate(splits):
+            w, b = params[2 * i].contiguous(), params[2 * i + 1]
+            backend.run("bbd_dwconv_tokens_fwd", x, _slice_ptr(x, c0), x.stride(1), ptr(w), ptr(b), _slice_ptr(y, c0), C,
+                        B, H, W, n, w.shape[-1], int(add_input), 0)
+            c0 += n
+        ctx.save_for_backward(x, *params)
+        ctx.meta = (H, W, bool(add_input), backend, tuple(splits))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        H, W, add_input, backend, splits = ctx.meta
+        B, N, C = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty(B, N, C, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        grads, c0 = [], 0
+        for i, n in enumerate(splits):
+            w, b = params[2 * i].contiguous(), params[2 * i + 1]
+            k = w.shape[-1]
+            if gx is not None:
+                backend.run("bbd_dwconv_tokens_fwd", gy, _slice_ptr(gy, c0), C, ptr(w), ptr(None), _slice_ptr(gx, c0), C,
+                            B, H, W, n, k, int(add_input), 1)
+            gw = torch.empty_like(w)
+            gb = torch.empty_like(b) if b is not None else None
+            scratch = torch.empty(B * H * n * (k * k + 1), device=x.device, dtype=torch.float32)
+            backend.run("bbd_dwconv_tokens_wgrad", x, _slice_ptr(x, c0), x.stride(1), _slice_ptr(gy, c0), C, ptr(scratch),
+                        ptr(gw), ptr(gb), B, H, W, n, k)
+            grads += [gw, gb]
+            c0 += n
+        return (gx, None, None, None, None, None) + tuple(grads)
+
+
+def dwconv_tokens(x, size, convs, add_input=False, backend=None):
+    """`convs`: list of nn.Conv2d (depth-wise, stride 1, padding k//2) covering consecutive channel groups."""
+    params, splits = [], []
+    for conv in convs:
+        params += [conv.weight, conv.bias]
+        splits.append(conv.weight.shape[0])
+    return _DepthwiseTokens.apply(x, size[0], size[1], add_input, backend or default_backend(), tuple(splits), *params)
+
+
 # ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)
 class _BatchNormAct(torch.autograd.Function):
     """Training-mode BatchNorm2d, optional residual add and ReLU in two launches each way

@@ -283,6 +283,22 @@ int bbd_dispconv_bwd(const float* x, const float* weight, const float* grad_y, f
  * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */
 int bbd_selftest_div(int blocks, int iters, unsigned seed, int32_t* mismatches, void* stream);
 
+/* ---- MonoViT encoder (BASELINE configs[4]): depth-wise convolution on token-layout activations ----------
+ * The position encodings of the reference's MPViT (networksvit/mpvit.py:240-330: ConvPosEnc, ConvRelPosEnc)
+ * are depth-wise k x k convolutions (k in {3,5,7}, stride 1, zero padding k/2) over the token matrix viewed
+ * as an image.  Tokens are [B, H*W, C] row-major (= NHWC); x / y / grad_y may be channel slices of wider
+ * rows: `*_row` is the number of floats between consecutive tokens and the pointer addresses the slice's
+ * first channel, C is the number of channels of the slice.  weight [C,k,k] (nn.Conv2d's [C,1,k,k]), bias [C]
+ * or NULL.
+ *   fwd   : y = bias + conv(x) (+ x when add_input).  flip = 1 mirrors the taps: with x := grad_y, bias NULL
+ *           this is the data gradient (add_input carries the residual's gradient).
+ *   wgrad : grad_weight [C,k,k], grad_bias [C] (or NULL); partial = scratch [B*H, C, k*k+1] floats.
+ *           Deterministic (per-row partial sums, fixed-order fp64 combine).                              */
+int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const float* bias, float* y, int y_row,
+                          int B, int H, int W, int C, int k, int add_input, int flip, void* stream);
+int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
+                            float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,3 +74,37 @@ def test_vit_train_steps_reduce_the_loss():
         hist.append(float(l["loss"].detach()))
     assert all(h == h for h in hist)
     assert sum(hist[-5:]) / 5 < sum(hist[:5]) / 5, (hist[:5], hist[-5:])
+
+
+@pytest.mark.parametrize("B,H,W,C,splits,add", [
+    (2, 12, 40, 216, (54, 81, 81), False),       # stage-2 ConvRelPosEnc: 27-channel heads, windows 3/5/7
+    (3, 6, 20, 64, (16, 24, 24), False),
+    (2, 9, 13, 64, (64,), True),                 # ConvPosEnc (residual folded in), odd sizes
+    (1, 5, 3, 8, (2, 3, 3), False),              # image smaller than the 7x7 window
+])
+def test_depthwise_token_convolution_matches_torch(B, H, W, C, splits, add):
+    """HIP depth-wise convolution on token-layout activations (forward, data / weight / bias gradients)
+    against nn.Conv2d on the NCHW view, reading its input in place from a wider (qkv-like) row."""
+    import torch.nn as nn
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + C)
+    wide = torch.randn(B, H * W, 3 * C, generator=g).to(DEV).requires_grad_(True)
+    convs = [nn.Conv2d(n, n, k, 1, k // 2, groups=n).to(DEV) for n, k in zip(splits, (3, 5, 7))]
+    w = torch.randn(B, H * W, C, generator=g).to(DEV)
+    x = wide[:, :, 2 * C:]                                                    # the "v" third, row stride 3C
+    y = ops.dwconv_tokens(x, (H, W), convs, add_input=add)
+    (y * w).sum().backward()
+    got = [y.detach(), wide.grad.clone()] + [p.grad.clone() for c in convs for p in c.parameters()]
+    wide.grad = None
+    for c in convs:
+        c.zero_grad()
+    img = x.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    ref = torch.cat([c(p) for c, p in zip(convs, torch.split(img, list(splits), dim=1))], 1)
+    if add:
+        ref = ref + img
+    ref = ref.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    (ref * w).sum().backward()
+    want = [ref.detach(), wide.grad] + [p.grad for c in convs for p in c.parameters()]
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-6) + 1e-6, (a.shape, float((a - b).abs().max()))
