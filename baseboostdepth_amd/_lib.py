@@ -66,6 +66,12 @@ SIGNATURES = {
     "bbd_dispconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
     "bbd_dwconv_tokens_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "bbd_factor_att_supported": [_i, _i],
+    "bbd_factor_att_segments": [_i, _i],
+    "bbd_factor_att_scratch_floats": [_i, _i, _i, _i],
+    "bbd_factor_att_fwd": [_p] * 7 + [_i, _i, _i, _i, _d, _p],
+    "bbd_factor_att_bwd": [_p] * 10 + [_i, _i, _i, _i, _d, _p],
+    "bbd_dwconv_tokens_wgrad_scratch_floats": [_i, _i, _i, _i, _i],
     "bbd_dwconv_tokens_wgrad": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4
@@ -90,7 +96,7 @@ class HipLibrary:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(self._dll, name)   # AttributeError here = header/library mismatch
             fn.argtypes = argtypes
-            fn.restype = _i
+            fn.restype = ctypes.c_long if name.endswith("_scratch_floats") else _i
         if self._dll.bbd_abi_version() != ABI_VERSION:
             raise BbdError("libbbd_hip.so ABI version mismatch")
         self.smooth_chunks = self._dll.bbd_smooth_chunks()
@@ -106,6 +112,15 @@ class HipLibrary:
 
     def bn_scratch_doubles(self, N, C, HW):
         return self._dll.bbd_bn_scratch_doubles(N, C, HW)
+
+    def dwconv_wgrad_scratch_floats(self, B, H, W, C, k):
+        return self._dll.bbd_dwconv_tokens_wgrad_scratch_floats(B, H, W, C, k)
+
+    def factor_att_supported(self, C, Ch):
+        return bool(self._dll.bbd_factor_att_supported(C, Ch))
+
+    def factor_att_scratch_floats(self, B, N, C, Ch):
+        return self._dll.bbd_factor_att_scratch_floats(B, N, C, Ch)
 
     def dispconv_scratch_doubles(self, C):
         return self._dll.bbd_dispconv_scratch_doubles(C)

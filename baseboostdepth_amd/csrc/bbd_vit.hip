@@ -74,53 +74,298 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restri
     if (w0 + q < W) yo[(long)q * y_row] = acc[q];
 }
 
-// Weight / bias gradient, stage 1: one thread per (image row (b,h), channel) accumulates its k*k + 1 partial
-// sums over the W pixels of that row; stage 2 adds the B*H partials of every (channel, tap) in fixed order.
+// Weight / bias gradient.  Stage 1: one thread per (row segment of WCH pixels, channel) accumulates its
+// k*k + 1 partial sums, sliding the k-wide window of x through registers; stage 2 / 3: column sums of the
+// partial matrix [segments, C*(k*k+1)] in two fixed-order passes (fp64 in the last) - deterministic.
+constexpr int WCH = 8;
 template <int K>
 __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __restrict__ x, int x_row,
                                                                  const float* __restrict__ dy, int dy_row,
                                                                  float* __restrict__ partial, int B, int H, int W, int C) {
   constexpr int P = K / 2;
+  const int wseg = (W + WCH - 1) / WCH;
   const long id = (long)blockIdx.x * NT + threadIdx.x;
-  if (id >= (long)B * H * C) return;
+  if (id >= (long)B * H * wseg * C) return;
   const int c = (int)(id % C);
-  const int bh = (int)(id / C);
+  const long seg = id / C;
+  const int w0 = (int)(seg % wseg) * WCH;
+  const int bh = (int)(seg / wseg);
   const int h = bh % H, b = bh / H;
   float acc[K * K + 1];
 #pragma unroll
   for (int i = 0; i <= K * K; ++i) acc[i] = 0.0f;
-  const float* xb = x + (long)b * H * W * x_row + c;
-  const float* dr = dy + (long)bh * W * dy_row + c;
-  for (int w = 0; w < W; ++w) {
-    const float g = dr[(long)w * dy_row];
-    acc[K * K] += g;
+  float g[WCH];
+  const float* dr = dy + ((long)bh * W + w0) * dy_row + c;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-      const int hy = h + i - P;
-      if (hy < 0 || hy >= H) continue;
-      const float* xr = xb + (long)hy * W * x_row;
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const int wx = w + j - P;
-        if (wx >= 0 && wx < W) acc[i * K + j] = fmaf(g, xr[(long)wx * x_row], acc[i * K + j]);
-      }
-    }
+  for (int q = 0; q < WCH; ++q) {
+    g[q] = (w0 + q < W) ? dr[(long)q * dy_row] : 0.0f;
+    acc[K * K] += g[q];
   }
-  float* po = partial + ((long)bh * C + c) * (K * K + 1);
+  const float* xb = x + (long)b * H * W * x_row + c;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int hy = h + i - P;
+    if (hy < 0 || hy >= H) continue;
+    const float* xr = xb + (long)hy * W * x_row;
+    float win[WCH + K - 1];
+#pragma unroll
+    for (int j = 0; j < WCH + K - 1; ++j) {
+      const int wx = w0 + j - P;
+      win[j] = (wx >= 0 && wx < W) ? xr[(long)wx * x_row] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+      for (int q = 0; q < WCH; ++q) acc[i * K + j] = fmaf(g[q], win[q + j], acc[i * K + j]);
+  }
+  float* po = partial + (seg * C + c) * (K * K + 1);
 #pragma unroll
   for (int i = 0; i <= K * K; ++i) po[i] = acc[i];
 }
 
-__global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_reduce_kernel(const float* __restrict__ partial,
-                                                                        float* __restrict__ dw, float* __restrict__ dbias,
-                                                                        int rows, int C, int kk) {
+// out[r, col] = sum over rows r, r + R, r + 2R ... of in[row, col]   (R = gridDim.y; coalesced along col)
+__global__ __launch_bounds__(NT) void colsum_stage_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long rows, int cols) {
+  const int col = blockIdx.x * NT + threadIdx.x;
+  if (col >= cols) return;
+  float s = 0.0f;
+  for (long r = blockIdx.y; r < rows; r += gridDim.y) s += in[r * cols + col];
+  out[(long)blockIdx.y * cols + col] = s;
+}
+
+__global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
+                                                                       float* __restrict__ dw, float* __restrict__ dbias,
+                                                                       int rows, int C, int kk) {
   const int id = blockIdx.x * NT + threadIdx.x;
   if (id >= C * (kk + 1)) return;
   const int c = id / (kk + 1), t = id - c * (kk + 1);
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partial[((long)r * C + c) * (kk + 1) + t];
+  for (int r = 0; r < rows; ++r) s += (double)partial[(long)r * C * (kk + 1) + id];
   if (t < kk) dw[c * kk + t] = (float)s;
   else if (dbias) dbias[c] = (float)s;
+}
+
+constexpr int WGRAD_STAGE_ROWS = 64;
+
+// ------------------------------------------------------------------------------------------------------
+// Factorised attention of MPViT (reference networksvit/mpvit.py:333-394), token layout.
+//   qkv [B, N, 3, h, Ch] (the Linear's output, read in place: row = 3C floats, q | k | v thirds)
+//   ctxs[b,h,kc,vc] = scale * sum_n softmax_N(k)[b,n,h,kc] * v[b,n,h,vc]                (h * Ch * Ch per image)
+//   out[b,n,h,vc]   = sum_kc q[b,n,h,kc] * ctxs[b,h,kc,vc]  +  q[b,n,h,vc] * convv[b,n,h,vc]
+// The reference evaluates this as softmax (a [B,h,N,Ch] kernel over the strided N axis: 0.9 ms per call on
+// MI355X), two einsum GEMMs with Ch = 8..36, and three element-wise launches; here: column statistics of k
+// (online max / sum per token segment), the [Ch x Ch] contexts as per-segment partial sums combined in fixed
+// order, and one token-parallel kernel for the output - all reading the packed qkv rows coalesced along C.
+// ------------------------------------------------------------------------------------------------------
+constexpr int FA_TOK = 16;      // tokens staged per iteration of the context kernel
+constexpr int FA_MAXO = 48;     // context entries per thread (C * Ch <= 256 * 48); instantiated for 2 / 8 / 24 / 48
+
+// per-(image, token segment) online softmax statistics of k over the tokens of the segment
+__global__ __launch_bounds__(NT) void fa_kstats_kernel(const float* __restrict__ qkv, float* __restrict__ pm,
+                                                       float* __restrict__ ps, int N, int C, int seg_tokens) {
+  const int seg = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
+  const int n0 = seg * seg_tokens, n1 = min(N, n0 + seg_tokens);
+  const float* kb = qkv + ((long)b * N) * 3 * C + C;
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float m = -INFINITY, sum = 0.0f;
+    for (int n = n0; n < n1; ++n) {
+      const float v = kb[(long)n * 3 * C + c];
+      const float mn = fmaxf(m, v);
+      sum = sum * __expf(m - mn) + __expf(v - mn);
+      m = mn;
+    }
+    pm[((long)b * nseg + seg) * C + c] = m;
+    ps[((long)b * nseg + seg) * C + c] = sum;
+  }
+}
+
+__global__ __launch_bounds__(NT) void fa_kstats_combine_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                               float* __restrict__ kmax, float* __restrict__ krsum,
+                                                               int nseg, int C, int total) {
+  const int id = blockIdx.x * NT + threadIdx.x;
+  if (id >= total) return;
+  const int b = id / C, c = id - b * C;
+  float m = -INFINITY;
+  for (int s = 0; s < nseg; ++s) m = fmaxf(m, pm[((long)b * nseg + s) * C + c]);
+  float sum = 0.0f;
+  for (int s = 0; s < nseg; ++s) {
+    const float sm = ps[((long)b * nseg + s) * C + c];
+    if (sm > 0.0f) sum += sm * __expf(pm[((long)b * nseg + s) * C + c] - m);
+  }
+  kmax[id] = m;
+  krsum[id] = 1.0f / sum;
+}
+
+// partial[b, seg, o] = sum over the segment's tokens of A[n, hk(o)] * Bm[n, hv(o)],  o = (h, kc, vc) flattened.
+// SOFTMAX: A = exp(k - kmax) * krsum (the softmax over tokens), Bm = v      -> forward contexts
+// else   : A = q,                                               Bm = dout   -> their gradient
+template <bool SOFTMAX, int MAXO>
+__global__ __launch_bounds__(NT) void fa_context_kernel(const float* __restrict__ qkv, const float* __restrict__ bm_src,
+                                                        int bm_row, const float* __restrict__ kmax,
+                                                        const float* __restrict__ krsum, float* __restrict__ partial,
+                                                        int N, int C, int Ch, int seg_tokens) {
+  extern __shared__ float fa_lds[];
+  float* s_a = fa_lds;                  // [FA_TOK][C]
+  float* s_b = fa_lds + FA_TOK * C;     // [FA_TOK][C]
+  const int seg = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
+  const int n0 = seg * seg_tokens, n1 = min(N, n0 + seg_tokens);
+  const int nout = C * Ch;
+  float acc[MAXO];
+  int ia[MAXO], ib[MAXO];
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = threadIdx.x + i * NT;
+    const int oo = o < nout ? o : 0;
+    const int hk = oo / Ch, vc = oo - hk * Ch;
+    ia[i] = hk;
+    ib[i] = (hk / Ch) * Ch + vc;
+    acc[i] = 0.0f;
+  }
+  const float* row0 = qkv + ((long)b * N) * 3 * C;
+  const float* bsrc = bm_src + ((long)b * N) * bm_row;
+  for (int t0 = n0; t0 < n1; t0 += FA_TOK) {
+    const int tn = min(FA_TOK, n1 - t0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < tn * C; e += NT) {
+      const int tt = e / C, c = e - tt * C;
+      const long n = t0 + tt;
+      float av;
+      if (SOFTMAX) av = __expf(row0[n * 3 * C + C + c] - kmax[b * C + c]) * krsum[b * C + c];
+      else av = row0[n * 3 * C + c];
+      s_a[tt * C + c] = av;
+      s_b[tt * C + c] = bsrc[n * bm_row + c];
+    }
+    __syncthreads();
+    for (int tt = 0; tt < tn; ++tt) {
+#pragma unroll
+      for (int i = 0; i < MAXO; ++i) acc[i] = fmaf(s_a[tt * C + ia[i]], s_b[tt * C + ib[i]], acc[i]);
+    }
+  }
+  float* po = partial + ((long)b * nseg + seg) * nout;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = threadIdx.x + i * NT;
+    if (o < nout) po[o] = acc[i];
+  }
+}
+
+// ctx[b, o] = scale * sum_seg partial[b, seg, o]   (fixed order)
+__global__ __launch_bounds__(NT) void fa_context_reduce_kernel(const float* __restrict__ partial, float* __restrict__ ctx,
+                                                               int nseg, int nout, int total, float scale) {
+  const int id = blockIdx.x * NT + threadIdx.x;
+  if (id >= total) return;
+  const int b = id / nout, o = id - b * nout;
+  float s = 0.0f;
+  for (int g = 0; g < nseg; ++g) s += partial[((long)b * nseg + g) * nout + o];
+  ctx[id] = s * scale;
+}
+
+// out[b,n,c=(h,vc)] = sum_kc q[b,n,h,kc] * ctxs[b,h,kc,vc] + q[b,n,c] * convv[b,n,c]
+__global__ __launch_bounds__(NT) void fa_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctxs,
+                                                      const float* __restrict__ convv, float* __restrict__ out, int N,
+                                                      int C, int Ch, int tok_per_block) {
+  extern __shared__ float fa_lds[];
+  float* s_ctx = fa_lds;                           // [C][Ch]  (entry (h,kc,vc) at (h*Ch+kc)*Ch + vc)
+  float* s_q = fa_lds + C * Ch;                    // [tok_per_block][C]
+  const int b = blockIdx.y, n0 = blockIdx.x * tok_per_block, tn = min(tok_per_block, N - n0);
+  for (int e = threadIdx.x; e < C * Ch; e += NT) s_ctx[e] = ctxs[(long)b * C * Ch + e];
+  const float* row0 = qkv + ((long)b * N + n0) * 3 * C;
+  for (int e = threadIdx.x; e < tn * C; e += NT) {
+    const int tt = e / C, c = e - tt * C;
+    s_q[e] = row0[(long)tt * 3 * C + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < tn * C; e += NT) {
+    const int tt = e / C, c = e - tt * C;
+    const int h = c / Ch, vc = c - h * Ch;
+    const float* qh = s_q + tt * C + h * Ch;
+    const float* cx = s_ctx + (h * Ch) * Ch + vc;
+    float acc = 0.0f;
+    for (int kc = 0; kc < Ch; ++kc) acc = fmaf(qh[kc], cx[kc * Ch], acc);
+    const long o = ((long)b * N + n0 + tt) * C + c;
+    out[o] = acc + s_q[e] * convv[o];
+  }
+}
+
+// Token-parallel backward: dq | dk | dv into dqkv [B,N,3C] and dconvv [B,N,C].
+//   dq[n,h,x] = sum_vc dout[n,h,vc] ctxs[h,x,vc] + dout[n,h,x] convv[n,h,x]
+//   dv[n,h,x] = sum_kc p[n,h,kc] D[h,kc,x]              D = scale * sum_n q (x) dout  (d loss / d context)
+//   dk[n,h,x] = p[n,h,x] (sum_vc v[n,h,vc] D[h,x,vc] - r[h,x]),   r[h,x] = sum_vc ctxs[h,x,vc] D[h,x,vc] / scale
+__global__ __launch_bounds__(NT) void fa_bwd_token_kernel(const float* __restrict__ qkv, const float* __restrict__ ctxs,
+                                                          const float* __restrict__ dctx, const float* __restrict__ convv,
+                                                          const float* __restrict__ dout, const float* __restrict__ kmax,
+                                                          const float* __restrict__ krsum, float* __restrict__ dqkv,
+                                                          float* __restrict__ dconvv, int N, int C, int Ch,
+                                                          int tok_per_block, float inv_scale) {
+  extern __shared__ float fa_lds[];
+  const int Chp = Ch | 1;                          // odd row stride: row- and column-wise reads both conflict-free
+  float* s_ctx = fa_lds;                           // [C][Chp]
+  float* s_d = s_ctx + C * Chp;                    // [C][Chp]
+  float* s_r = s_d + C * Chp;                      // [C]
+  float* s_p = s_r + C;                            // [tok][C] softmax(k)
+  float* s_v = s_p + tok_per_block * C;            // [tok][C]
+  float* s_g = s_v + tok_per_block * C;            // [tok][C] dout
+  const int b = blockIdx.y, n0 = blockIdx.x * tok_per_block, tn = min(tok_per_block, N - n0);
+  for (int e = threadIdx.x; e < C * Ch; e += NT) {
+    const int hk = e / Ch, vc = e - hk * Ch;
+    s_ctx[hk * Chp + vc] = ctxs[(long)b * C * Ch + e];
+    s_d[hk * Chp + vc] = dctx[(long)b * C * Ch + e];
+  }
+  const float* row0 = qkv + ((long)b * N + n0) * 3 * C;
+  for (int e = threadIdx.x; e < tn * C; e += NT) {
+    const int tt = e / C, c = e - tt * C;
+    s_p[e] = __expf(row0[(long)tt * 3 * C + C + c] - kmax[b * C + c]) * krsum[b * C + c];
+    s_v[e] = row0[(long)tt * 3 * C + 2 * C + c];
+    s_g[e] = dout[((long)b * N + n0 + tt) * C + c];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float r = 0.0f;
+    for (int vc = 0; vc < Ch; ++vc) r = fmaf(s_ctx[c * Chp + vc], s_d[c * Chp + vc], r);
+    s_r[c] = r * inv_scale;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < tn * C; e += NT) {
+    const int tt = e / C, c = e - tt * C;
+    const int h = c / Ch, x = c - h * Ch;
+    const float* gh = s_g + tt * C + h * Ch;
+    const float* ph = s_p + tt * C + h * Ch;
+    const float* vh = s_v + tt * C + h * Ch;
+    float aq = 0.0f, av = 0.0f, ap = 0.0f;
+    for (int j = 0; j < Ch; ++j) {
+      aq = fmaf(gh[j], s_ctx[c * Chp + j], aq);               // row x of ctxs
+      ap = fmaf(vh[j], s_d[c * Chp + j], ap);                 // row x of D
+      av = fmaf(ph[j], s_d[(h * Ch + j) * Chp + x], av);      // column x of D
+    }
+    const long tok = (long)b * N + n0 + tt;
+    const float q = row0[(long)tt * 3 * C + c];
+    const float cv = convv[tok * C + c];
+    float* o = dqkv + tok * 3 * C + c;
+    o[0] = aq + s_g[e] * cv;
+    o[C] = s_p[e] * (ap - s_r[c]);
+    o[2 * C] = av;
+    dconvv[tok * C + c] = s_g[e] * q;
+  }
+}
+
+template <bool SOFTMAX>
+void fa_launch_context(dim3 grid, size_t lds, hipStream_t st, const float* qkv, const float* bsrc, int brow,
+                              const float* kmax, const float* krsum, float* part, int N, int C, int Ch, int seg_tokens) {
+  const int nacc = (C * Ch + NT - 1) / NT;
+#define BBD_FA(M) hipLaunchKernelGGL((fa_context_kernel<SOFTMAX, M>), grid, dim3(NT), lds, st, qkv, bsrc, brow, kmax, krsum, part, N, C, Ch, seg_tokens)
+  if (nacc <= 2) BBD_FA(2);
+  else if (nacc <= 8) BBD_FA(8);
+  else if (nacc <= 24) BBD_FA(24);
+  else BBD_FA(48);
+#undef BBD_FA
+}
+
+/* segments of tokens: enough workgroups to fill the chip, at least FA_TOK tokens each */
+int fa_segments(int B, int N) {
+  int nseg = (1024 + B - 1) / B;
+  const int max_seg = (N + FA_TOK - 1) / FA_TOK;
+  if (nseg > max_seg) nseg = max_seg;
+  return nseg < 1 ? 1 : nseg;
 }
 
 int launch_status() {
@@ -147,19 +392,89 @@ int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const 
   return launch_status();
 }
 
+long bbd_dwconv_tokens_wgrad_scratch_floats(int B, int H, int W, int C, int k) {
+  const long segs = (long)B * H * ((W + WCH - 1) / WCH);
+  return (segs + WGRAD_STAGE_ROWS) * C * (k * k + 1);
+}
+
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
                             float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, void* stream) {
   if (!x || !grad_y || !partial || !grad_weight || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BBD_E_BADARG;
   if (k != 3 && k != 5 && k != 7) return BBD_E_BADARG;
-  const long total = (long)B * H * C;
+  const long segs = (long)B * H * ((W + WCH - 1) / WCH);
+  const long total = segs * C;
   const dim3 grid((unsigned)((total + NT - 1) / NT));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (k == 3) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<3>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
   else if (k == 5) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<5>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
   else hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<7>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
-  const int n = C * (k * k + 1);
-  hipLaunchKernelGGL(dwconv_tokens_wgrad_reduce_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, partial,
-                     grad_weight, grad_bias, B * H, C, k * k);
+  const int cols = C * (k * k + 1);
+  float* stage = partial + segs * cols;
+  const int srows = segs < WGRAD_STAGE_ROWS ? (int)segs : WGRAD_STAGE_ROWS;
+  hipLaunchKernelGGL(colsum_stage_kernel, dim3((unsigned)((cols + NT - 1) / NT), (unsigned)srows), dim3(NT), 0, st, partial,
+                     stage, segs, cols);
+  hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + NT - 1) / NT)), dim3(NT), 0, st, stage,
+                     grad_weight, grad_bias, srows, C, k * k);
+  return launch_status();
+}
+
+int bbd_factor_att_segments(int B, int N) { return fa_segments(B, N); }
+int bbd_factor_att_supported(int C, int Ch) {
+  return C > 0 && Ch > 0 && C % Ch == 0 && (long)C * Ch <= (long)NT * FA_MAXO && C <= 1024;
+}
+
+int bbd_factor_att_fwd(const float* qkv, const float* convv, float* kmax, float* krsum, float* ctxs, float* scratch,
+                       float* out, int B, int N, int C, int Ch, double scale, void* stream) {
+  if (!qkv || !convv || !kmax || !krsum || !ctxs || !scratch || !out || B <= 0 || N <= 0) return BBD_E_BADARG;
+  if (!bbd_factor_att_supported(C, Ch)) return BBD_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nseg = fa_segments(B, N), seg_tokens = (N + nseg - 1) / nseg, nout = C * Ch;
+  float* pm = scratch;                            // [B, nseg, C]
+  float* ps = pm + (long)B * nseg * C;            // [B, nseg, C]
+  float* part = ps + (long)B * nseg * C;          // [B, nseg, C*Ch]
+  hipLaunchKernelGGL(fa_kstats_kernel, dim3(nseg, B), dim3(NT), 0, st, qkv, pm, ps, N, C, seg_tokens);
+  hipLaunchKernelGGL(fa_kstats_combine_kernel, dim3((unsigned)((B * C + NT - 1) / NT)), dim3(NT), 0, st, pm, ps, kmax,
+                     krsum, nseg, C, B * C);
+  fa_launch_context<true>(dim3(nseg, B), (size_t)2 * FA_TOK * C * sizeof(float), st, qkv, qkv + 2 * C, 3 * C, kmax, krsum,
+                          part, N, C, Ch, seg_tokens);
+  hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + NT - 1) / NT)), dim3(NT), 0, st, part,
+                     ctxs, nseg, nout, B * nout, (float)scale);
+  const int tpb = 8;
+  hipLaunchKernelGGL(fa_apply_kernel, dim3((unsigned)((N + tpb - 1) / tpb), B), dim3(NT),
+                     (size_t)(nout + tpb * C) * sizeof(float), st, qkv, ctxs, convv, out, N, C, Ch, tpb);
+  return launch_status();
+}
+
+long bbd_factor_att_scratch_floats(int B, int N, int C, int Ch) {
+  const long nseg = fa_segments(B, N);
+  return (long)B * nseg * (2L * C + (long)C * Ch);
+}
+
+int bbd_factor_att_bwd(const float* qkv, const float* convv, const float* kmax, const float* krsum, const float* ctxs,
+                       const float* grad_out, float* dctx, float* scratch, float* grad_qkv, float* grad_convv, int B,
+                       int N, int C, int Ch, double scale, void* stream) {
+  if (!qkv || !convv || !kmax || !krsum || !ctxs || !grad_out || !dctx || !scratch || !grad_qkv || !grad_convv)
+    return BBD_E_BADARG;
+  if (B <= 0 || N <= 0 || !bbd_factor_att_supported(C, Ch)) return BBD_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nseg = fa_segments(B, N), seg_tokens = (N + nseg - 1) / nseg, nout = C * Ch;
+  float* part = scratch + 2L * B * nseg * C;
+  fa_launch_context<false>(dim3(nseg, B), (size_t)2 * FA_TOK * C * sizeof(float), st, qkv, grad_out, C, kmax, krsum, part,
+                           N, C, Ch, seg_tokens);
+  hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + NT - 1) / NT)), dim3(NT), 0, st, part,
+                     dctx, nseg, nout, B * nout, (float)scale);
+  const int tpb = 8, Chp = Ch | 1;
+  const size_t lds = (size_t)(2 * C * Chp + C + 3 * tpb * C) * sizeof(float);
+  if (lds > 64 * 1024) {      // up to 114 KB for C = 288, Ch = 36: above the default dynamic-LDS limit
+    static size_t granted = 0;
+    if (lds > granted) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fa_bwd_token_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BBD_E_BADARG;
+      granted = lds;
+    }
+  }
+  hipLaunchKernelGGL(fa_bwd_token_kernel, dim3((unsigned)((N + tpb - 1) / tpb), B), dim3(NT), lds, st, qkv, ctxs, dctx,
+                     convv, grad_out, kmax, krsum, grad_qkv, grad_convv, N, C, Ch, tpb, (float)(1.0 / scale));
   return launch_status();
 }
 

@@ -223,7 +223,14 @@ class FactorAtt_ConvRelPosEnc(nn.Module):
     def forward(self, x, size):
         B, N, C = x.shape
         h = self.num_heads
-        qkv = self.qkv(x).view(B, N, 3, h, C // h)
+        qkv = self.qkv(x)                                              # [B, N, 3C] = q | k | v, head-major channels
+        if _hip_tokens(qkv) and ops.factor_attention_supported(C, h):
+            # two HIP ops on the packed activation: conv(v) read in place from the v third, then column
+            # statistics of k + [Ch x Ch] contexts + the token-parallel output (csrc/bbd_vit.hip)
+            convv = self.crpe.conv_v(qkv[:, :, 2 * C:], size)
+            out = ops.factor_attention(qkv, convv, h, self.scale)
+            return self.proj_drop(self.proj(out))
+        qkv = qkv.view(B, N, 3, h, C // h)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]             # [B, N, h, Ch] strided views
         # softmax over the N tokens, then the [Ch, Ch] context of every head: (k^T v) is tiny, so the
         # scale goes there instead of onto the [N, Ch] product

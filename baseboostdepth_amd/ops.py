@@ -475,7 +475,7 @@ class _DepthwiseTokens(torch.autograd.Function):
                             B, H, W, n, k, int(add_input), 1)
             gw = torch.empty_like(w)
             gb = torch.empty_like(b) if b is not None else None
-            scratch = torch.empty(B * H * n * (k * k + 1), device=x.device, dtype=torch.float32)
+            scratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, n, k), device=x.device, dtype=torch.float32)
             backend.run("bbd_dwconv_tokens_wgrad", x, _slice_ptr(x, c0), x.stride(1), _slice_ptr(gy, c0), C, ptr(scratch),
                         ptr(gw), ptr(gb), B, H, W, n, k)
             grads += [gw, gb]
@@ -490,6 +490,56 @@ def dwconv_tokens(x, size, convs, add_input=False, backend=None):
         params += [conv.weight, conv.bias]
         splits.append(conv.weight.shape[0])
     return _DepthwiseTokens.apply(x, size[0], size[1], add_input, backend or default_backend(), tuple(splits), *params)
+
+
+class _FactorAttention(torch.autograd.Function):
+    """MPViT's factorised attention on the packed qkv activation (csrc/bbd_vit.hip):
+    out = q (scale * softmax_N(k)^T v) + q * convv, per head.  qkv [B,N,3C] is the qkv Linear's output,
+    convv [B,N,C] the ConvRelPosEnc convolution of v."""
+
+    @staticmethod
+    def forward(ctx, qkv, convv, heads, scale, backend):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        Ch = C // heads
+        qkv, convv = qkv.contiguous(), convv.contiguous()
+        backend._check(qkv, convv)
+        dev = qkv.device
+        kmax = torch.empty(B, C, device=dev, dtype=torch.float32)
+        krsum = torch.empty(B, C, device=dev, dtype=torch.float32)
+        ctxs = torch.empty(B, C * Ch, device=dev, dtype=torch.float32)
+        scratch = torch.empty(backend.lib.factor_att_scratch_floats(B, N, C, Ch), device=dev, dtype=torch.float32)
+        out = torch.empty(B, N, C, device=dev, dtype=torch.float32)
+        backend.run("bbd_factor_att_fwd", qkv, ptr(qkv), ptr(convv), ptr(kmax), ptr(krsum), ptr(ctxs), ptr(scratch),
+                    ptr(out), B, N, C, Ch, float(scale))
+        ctx.save_for_backward(qkv, convv, kmax, krsum, ctxs)
+        ctx.meta = (heads, float(scale), backend)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, convv, kmax, krsum, ctxs = ctx.saved_tensors
+        heads, scale, backend = ctx.meta
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        Ch = C // heads
+        gout = gout.contiguous()
+        dev = qkv.device
+        dctx = torch.empty_like(ctxs)
+        scratch = torch.empty(backend.lib.factor_att_scratch_floats(B, N, C, Ch), device=dev, dtype=torch.float32)
+        gqkv = torch.empty_like(qkv)
+        gconvv = torch.empty_like(convv)
+        backend.run("bbd_factor_att_bwd", qkv, ptr(qkv), ptr(convv), ptr(kmax), ptr(krsum), ptr(ctxs), ptr(gout),
+                    ptr(dctx), ptr(scratch), ptr(gqkv), ptr(gconvv), B, N, C, Ch, scale)
+        return gqkv, gconvv, None, None, None
+
+
+def factor_attention(qkv, convv, heads, scale, backend=None):
+    return _FactorAttention.apply(qkv, convv, heads, scale, backend or default_backend())
+
+
+def factor_attention_supported(C, heads, backend=None):
+    return (backend or default_backend()).lib.factor_att_supported(C, C // heads)
 
 
 # ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)

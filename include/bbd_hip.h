@@ -292,12 +292,32 @@ int bbd_selftest_div(int blocks, int iters, unsigned seed, int32_t* mismatches, 
  * or NULL.
  *   fwd   : y = bias + conv(x) (+ x when add_input).  flip = 1 mirrors the taps: with x := grad_y, bias NULL
  *           this is the data gradient (add_input carries the residual's gradient).
- *   wgrad : grad_weight [C,k,k], grad_bias [C] (or NULL); partial = scratch [B*H, C, k*k+1] floats.
- *           Deterministic (per-row partial sums, fixed-order fp64 combine).                              */
+ *   wgrad : grad_weight [C,k,k], grad_bias [C] (or NULL); partial = scratch of
+ *           bbd_dwconv_tokens_wgrad_scratch_floats(B,H,W,C,k) floats.  Deterministic (per-segment partial
+ *           sums, two fixed-order column-sum passes, the last in fp64).                                  */
+long bbd_dwconv_tokens_wgrad_scratch_floats(int B, int H, int W, int C, int k);
 int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const float* bias, float* y, int y_row,
                           int B, int H, int W, int C, int k, int add_input, int flip, void* stream);
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
                             float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, void* stream);
+
+/* Factorised attention of MPViT (networksvit/mpvit.py:333-394) on the packed qkv activation.
+ *   qkv [B, N, 3, h, Ch] = the qkv Linear's output (C = h*Ch); convv [B,N,C] = ConvRelPosEnc's conv(v)
+ *   fwd : out[b,n,h,vc] = sum_kc q[b,n,h,kc] ctxs[b,h,kc,vc] + q[b,n,h,vc] convv[b,n,h,vc],
+ *         ctxs = scale * softmax_N(k)^T v per head; also returns kmax / krsum [B,C] (softmax statistics of
+ *         k over the tokens) and ctxs [B, h, Ch, Ch] for the backward.
+ *   bwd : grad_out [B,N,C] -> grad_qkv [B,N,3C] (dq | dk | dv), grad_convv [B,N,C]; dctx = work buffer
+ *         [B, h, Ch, Ch].  scratch: bbd_factor_att_scratch_floats(B,N,C,Ch) floats for both calls.
+ *   Deterministic (per-token-segment partial sums combined in fixed order).  Supported shapes:
+ *   bbd_factor_att_supported(C, Ch) != 0 (C*Ch <= 12288: MPViT tiny / xsmall / small).                    */
+int bbd_factor_att_supported(int C, int Ch);
+int bbd_factor_att_segments(int B, int N);
+long bbd_factor_att_scratch_floats(int B, int N, int C, int Ch);
+int bbd_factor_att_fwd(const float* qkv, const float* convv, float* kmax, float* krsum, float* ctxs, float* scratch,
+                       float* out, int B, int N, int C, int Ch, double scale, void* stream);
+int bbd_factor_att_bwd(const float* qkv, const float* convv, const float* kmax, const float* krsum, const float* ctxs,
+                       const float* grad_out, float* dctx, float* scratch, float* grad_qkv, float* grad_convv, int B,
+                       int N, int C, int Ch, double scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ HEADER = os.path.join(ROOT, "include", "bbd_hip.h")
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(bbd_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(bbd_[a-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")

@@ -108,3 +108,43 @@ def test_depthwise_token_convolution_matches_torch(B, H, W, C, splits, add):
     for a, b in zip(got, want):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-6) + 1e-6, (a.shape, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,C,heads", [
+    (2, 12, 40, 216, 8),        # stage 2 of mpvit_small: Ch = 27
+    (3, 6, 20, 288, 8),         # stage 3: Ch = 36 (114 KB of LDS in the backward)
+    (2, 24, 80, 128, 8),        # stage 1: Ch = 16
+    (1, 48, 160, 64, 8),        # stage 0 at full size: 7680 tokens, Ch = 8
+    (2, 3, 5, 64, 8),           # fewer tokens than one staging step
+])
+def test_factorised_attention_matches_torch(B, H, W, C, heads):
+    """Fused factorised attention (column softmax of k over the tokens, [Ch x Ch] contexts, output) and its
+    backward against the reference's formulation in torch ops (mpvit.py:354-386) on the same packed qkv."""
+    from baseboostdepth_amd import ops
+    assert ops.factor_attention_supported(C, heads)
+    N, Ch = H * W, C // heads
+    scale = Ch ** -0.5
+    g = torch.Generator().manual_seed(C + N)
+    qkv = (1.5 * torch.randn(B, N, 3 * C, generator=g)).to(DEV).requires_grad_(True)
+    convv = torch.randn(B, N, C, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(B, N, C, generator=g).to(DEV)
+    out = ops.factor_attention(qkv, convv, heads, scale)
+    (out * w).sum().backward()
+    got = [out.detach(), qkv.grad.clone(), convv.grad.clone()]
+    qkv.grad = convv.grad = None
+    r = qkv.view(B, N, 3, heads, Ch).permute(2, 0, 3, 1, 4)            # [3, B, h, N, Ch] like the reference
+    q, k, v = r[0], r[1], r[2]
+    kv = torch.einsum("bhnk,bhnv->bhkv", k.softmax(dim=2), v)
+    att = torch.einsum("bhnk,bhkv->bhnv", q, kv)
+    ref = scale * att + q * convv.view(B, N, heads, Ch).transpose(1, 2)
+    ref = ref.transpose(1, 2).reshape(B, N, C)
+    (ref * w).sum().backward()
+    want = [ref.detach(), qkv.grad, convv.grad]
+    for name, a, b in zip(("out", "grad qkv", "grad convv"), got, want):
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err < 2e-5, (name, err)
+    # the three thirds separately: dk is the smallest and would hide behind dq / dv in a joint maximum
+    for t, name in enumerate(("dq", "dk", "dv")):
+        a, b = got[1][:, :, t * C:(t + 1) * C], want[1][:, :, t * C:(t + 1) * C]
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err < 1e-4, (name, err)
