@@ -150,11 +150,52 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ img, int h
   }
 }
 
+// Where a (scale, sample)'s depth comes from: a full-resolution depth plane (bbd_disp_to_depth_fwd's output), or
+// - SURVEY 8f-1 - the decoder's low-resolution disparity itself: F.interpolate(bilinear, align_corners=False)
+// + layers.disp_to_depth (trainer.py:455-461, layers.py:13-22) evaluated per staged cell with the same
+// functions (bbd_up_src / bbd_up_blend, IEEE reciprocal) as the stand-alone kernel, so depth is bit-identical.
+constexpr int MAX_SCALES = 4;
+struct DispSrc {
+  const float* disp[MAX_SCALES];   // per scale [B,1,h,w]; all NULL = depth-plane mode
+  int h[MAX_SCALES], w[MAX_SCALES];
+  float lo, span;                  // 1/max_depth, 1/min_depth - 1/max_depth
+};
+struct DepthSrc {
+  const float* depth;              // [H,W] plane of this (scale, sample), or nullptr
+  const float* disp;               // [h,w] plane of this (scale, sample)
+  int h, w, small;
+  float lo, span;
+};
+__device__ __forceinline__ DepthSrc depth_source(const float* depth_planes, const DispSrc& ds, int s, int b, size_t sb,
+                                                 int H, int W) {
+  DepthSrc d;
+  d.depth = depth_planes ? depth_planes + sb * (size_t)H * W : nullptr;
+  d.h = ds.h[s]; d.w = ds.w[s];
+  d.disp = depth_planes ? nullptr : ds.disp[s] + (size_t)b * d.h * d.w;
+  d.small = (H + W) <= 128;
+  d.lo = ds.lo; d.span = ds.span;
+  return d;
+}
+__device__ __forceinline__ float depth_at(const DepthSrc& d, int yy, int xx, int H, int W) {
+  if (d.depth != nullptr) return d.depth[yy * W + xx];
+  float v;
+  if (d.h == H && d.w == W) {
+    v = d.disp[yy * W + xx];
+  } else {
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bbd_up_src(yy, d.h, H, &y0, &y1, &ly0, &ly1);
+    bbd_up_src(xx, d.w, W, &x0, &x1, &lx0, &lx1);
+    v = bbd_up_blend(d.disp[y0 * d.w + x0], d.disp[y0 * d.w + x1], d.disp[y1 * d.w + x0], d.disp[y1 * d.w + x1], ly0, ly1,
+                     lx0, lx1, d.small);
+  }
+  return 1.0f / (d.lo + d.span * v);
+}
+
 template <typename CellsT>
-__device__ __forceinline__ void load_depth(const float* __restrict__ depth, const CellsT& cl,
-                                           float (&d)[CellsT::N]) {
+__device__ __forceinline__ void load_depth(const DepthSrc& src, int H, int W, const CellsT& cl, float (&d)[CellsT::N]) {
 #pragma unroll
-  for (int k = 0; k < CellsT::N; ++k) d[k] = depth[cl.pix[k]];
+  for (int k = 0; k < CellsT::N; ++k) d[k] = depth_at(src, cl.xy[k] >> 16, cl.xy[k] & 0xffff, H, W);
 }
 
 // Warp one source image into the staged region for one pose-table row.
@@ -396,6 +437,8 @@ struct FwdArgs {
   uint8_t* argmin;
   float* partial;
   float* warped;
+  float* depth_out;     // optional [S,B,H,W]: the depth this launch used (outputs[("depth",0,s)] of the reference)
+  DispSrc ds;
   BbdDims dm;
   int S, B, NP, ntiles, no_ssim;
 };
@@ -435,7 +478,13 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   cl.init(H, W, tc.tx0, tc.ty0);
   stage_image(a.target + (size_t)b * img, hw, cl, s_y);
   float dcell[Cells<LH, LW, LS, 1>::N];
-  load_depth(a.depth + sb * hw, cl, dcell);
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  load_depth(dsrc, H, W, cl, dcell);
+  if (a.depth_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < Cells<LH, LW, LS, 1>::N; ++k)
+      if (cl.own[k]) a.depth_out[sb * hw + cl.pix[k]] = dcell[k];
+  }
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
@@ -528,8 +577,9 @@ struct BwdArgs {
   const int32_t* ncand;
   const uint8_t* argmin;
   const float* gscale;
-  float* grad_depth;
+  float* grad_depth;    // depth-plane mode: d loss / d depth; disparity mode: d loss / d up-sampled disparity
   float* grad_proj;
+  DispSrc ds;
   BbdDims dm;
   int S, B, NP, ntiles, no_ssim;
 };
@@ -562,7 +612,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
   const size_t img = (size_t)3 * hw;
   const size_t sb = (size_t)s * a.B + b;
-  const float* depth = a.depth + sb * hw;
+  const float* depth = a.depth + sb * hw;      // (this timing-only form supports depth planes only)
   const uint8_t* am = a.argmin + sb * hw;
   const float g = a.gscale[s];
   const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
@@ -600,7 +650,8 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
     }
   }
   float dcell[Cells<BH, BW, BS, 2>::N];
-  load_depth(depth, cl, dcell);
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  load_depth(dsrc, H, W, cl, dcell);
 
   int ly, lx0;
   strip_of_thread(&ly, &lx0);
@@ -914,7 +965,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
   const size_t img = (size_t)3 * hw;
   const size_t sb = (size_t)s * a.B + b;
-  const float* depth = a.depth + sb * hw;
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
   const uint8_t* am = a.argmin + sb * hw;
   const float g = a.gscale[s];
   const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
@@ -948,7 +999,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
   float dcell[CellsB::N];
-  load_depth(depth, cl, dcell);
+  load_depth(dsrc, H, W, cl, dcell);
 
   const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
   const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
@@ -961,14 +1012,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   float gdepth[PPT2] = {0.0f, 0.0f};
   float qdepth[PPT2] = {1.0f, 1.0f};
   if (q_row_ok) {
-    if (q_vec_ok) {
-      const float2 t = *reinterpret_cast<const float2*>(depth + qy * W + qx0);
-      qdepth[0] = t.x; qdepth[1] = t.y;
-    } else {
 #pragma unroll
-      for (int j = 0; j < PPT2; ++j)
-        if (qx0 + j < W) qdepth[j] = depth[qy * W + qx0 + j];
-    }
+    for (int j = 0; j < PPT2; ++j)
+      if (qx0 + j < W) qdepth[j] = depth_at(dsrc, qy, qx0 + j, H, W);
   }
 
   if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
@@ -1165,6 +1211,12 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
 
+  if (dsrc.depth == nullptr) {
+    // disparity mode: hand back d loss / d (up-sampled disparity) = d loss / d depth * (-span * depth^2); the
+    // bilinear adjoint onto the low-resolution map is bbd_disp_upsample_adjoint (one launch for all scales)
+#pragma unroll
+    for (int j = 0; j < PPT2; ++j) gdepth[j] *= -dsrc.span * qdepth[j] * qdepth[j];
+  }
   if (q_row_ok) {
     float* o = a.grad_depth + sb * hw + qy * W + qx0;
     if (q_vec_ok) {
@@ -1263,6 +1315,55 @@ __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __re
 #pragma unroll
   for (int off = Q / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (live && sub == 0) gdisp[i] = acc;
+}
+
+// Bilinear up-sampling adjoint for ALL reduced scales of a step in one launch (disparity mode of the fused
+// backward): grad_up [S,B,H,W] = d loss / d (up-sampled disparity)  ->  grad_disp_s [B,h_s,w_s].  Gather form,
+// Q lanes (4 / 16 / 64 by up-sampling factor) per low-resolution pixel, fixed xor-butterfly: deterministic.
+struct AdjointArgs {
+  const float* gup[MAX_SCALES];     // [B,H,W] plane stack of the scale
+  float* gdisp[MAX_SCALES];
+  int h[MAX_SCALES], w[MAX_SCALES], q[MAX_SCALES];
+  int block0[MAX_SCALES + 1];       // first workgroup of each scale
+  int n, B, H, W;
+};
+__global__ __launch_bounds__(NT) void upsample_adjoint_kernel(AdjointArgs a) {
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.block0[k + 1]) ++k;
+  const int h = a.h[k], w = a.w[k], Q = a.q[k], H = a.H, W = a.W;
+  const size_t n = (size_t)a.B * h * w;
+  const size_t gid = ((size_t)(blockIdx.x - a.block0[k]) * NT + threadIdx.x) / Q;
+  const int sub = threadIdx.x % Q;
+  const bool live = gid < n;
+  const size_t i = live ? gid : n - 1;
+  const int x = (int)(i % w);
+  const int y = (int)((i / w) % h);
+  const int b = (int)(i / ((size_t)w * h));
+  const float* g = a.gup[k] + (size_t)b * H * W;
+  const float sy_ = (float)H / (float)h, sx_ = (float)W / (float)w;
+  const int oy_lo = max(0, (int)floorf(((float)y - 0.5f) * sy_ - 0.5f) - 1);
+  const int oy_hi = min(H - 1, (int)ceilf(((float)y + 1.5f) * sy_ - 0.5f) + 1);
+  const int ox_lo = max(0, (int)floorf(((float)x - 0.5f) * sx_ - 0.5f) - 1);
+  const int ox_hi = min(W - 1, (int)ceilf(((float)x + 1.5f) * sx_ - 0.5f) + 1);
+  const int nx = ox_hi - ox_lo + 1, ncand = (oy_hi - oy_lo + 1) * nx;
+  float acc = 0.0f;
+  for (int c = sub; c < ncand; c += Q) {
+    const int oy = oy_lo + c / nx, ox = ox_lo + c % nx;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bbd_up_src(oy, h, H, &y0, &y1, &ly0, &ly1);
+    bbd_up_src(ox, w, W, &x0, &x1, &lx0, &lx1);
+    const float wy = (y0 == y ? ly0 : 0.0f) + (y1 == y ? ly1 : 0.0f);
+    const float wx = (x0 == x ? lx0 : 0.0f) + (x1 == x ? lx1 : 0.0f);
+    if (wy == 0.0f || wx == 0.0f) continue;
+    acc += g[(size_t)oy * W + ox] * wy * wx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(acc, off, 64);
+    if (off < Q) acc += o;
+  }
+  if (live && sub == 0) a.gdisp[k][i] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1865,11 +1966,29 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   return launch_status();
 }
 
-int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const float* depth, const float* proj,
-                          const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
-                          float* min_loss, uint8_t* argmin, float* partial, float* warped, int S, int B, int NP,
-                          int H, int W, int no_ssim, void* stream) {
-  if (!target || !depth || !cand || !ncand || !min_loss || !argmin || !partial) return BBD_E_BADARG;
+static int fill_disp(const void* const* disp, const int32_t* disp_hw, double min_depth, double max_depth, int S, int H,
+                     int W, DispSrc* ds) {
+  for (int i = 0; i < MAX_SCALES; ++i) { ds->disp[i] = nullptr; ds->h[i] = H; ds->w[i] = W; }
+  ds->lo = 0.0f; ds->span = 0.0f;
+  if (disp == nullptr) return 0;
+  if (disp_hw == nullptr || S > MAX_SCALES || min_depth <= 0.0 || max_depth <= min_depth) return BBD_E_BADARG;
+  for (int i = 0; i < S; ++i) {
+    ds->disp[i] = static_cast<const float*>(disp[i]);
+    ds->h[i] = disp_hw[2 * i]; ds->w[i] = disp_hw[2 * i + 1];
+    if (!ds->disp[i] || ds->h[i] <= 0 || ds->w[i] <= 0 || ds->h[i] > H || ds->w[i] > W) return BBD_E_BADARG;
+  }
+  // layers.py:18-20 evaluates these in Python doubles before they meet the fp32 tensor
+  ds->lo = (float)(1.0 / max_depth);
+  ds->span = (float)(1.0 / min_depth - 1.0 / max_depth);
+  return 0;
+}
+
+static int launch_fused_fwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
+                            const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
+                            const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
+                            float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out, int S, int B,
+                            int NP, int H, int W, int no_ssim, void* stream) {
+  if (!target || (!depth && !disp) || !cand || !ncand || !min_loss || !argmin || !partial) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   FwdArgs a;
 #ifdef BBD_STAMPS
@@ -1878,20 +1997,22 @@ int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const 
   a.stamps = nullptr;
 #endif
   if (fill_frames(frames, &a.frames)) return BBD_E_BADARG;
+  if (fill_disp(depth ? nullptr : disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.ident = ident; a.noise = noise;
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
-  a.warped = warped; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
+  a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 
-int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth, const float* proj,
-                          const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
-                          float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
-                          void* stream) {
-  if (!target || !depth || !cand || !ncand || !argmin || !gscale || !grad_depth || !grad_proj) return BBD_E_BADARG;
+static int launch_fused_bwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
+                            const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
+                            const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
+                            float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
+                            void* stream) {
+  if (!target || (!depth && !disp) || !cand || !ncand || !argmin || !gscale || !grad_depth || !grad_proj) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   BwdArgs a;
 #ifdef BBD_STAMPS
@@ -1900,17 +2021,79 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
   a.stamps = nullptr;
 #endif
   if (fill_frames(frames, &a.frames)) return BBD_E_BADARG;
+  if (fill_disp(depth ? nullptr : disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.cand = cand; a.ncand = ncand; a.argmin = argmin;
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
-#if defined(BBD_BWD_256)        // the round-1 form (4 waves, 4-pixel strips): kept for A/B timing builds
+#if defined(BBD_BWD_256)        // the round-1 form (4 waves, 4-pixel strips, depth planes only): A/B timing builds
+  if (!depth) return BBD_E_BADARG;
   hipLaunchKernelGGL(warp_ssim_min_bwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
 #else
   hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                      static_cast<hipStream_t>(stream), a);
 #endif
+  return launch_status();
+}
+
+int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const float* depth, const float* proj,
+                          const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
+                          float* min_loss, uint8_t* argmin, float* partial, float* warped, int S, int B, int NP,
+                          int H, int W, int no_ssim, void* stream) {
+  if (!depth) return BBD_E_BADARG;
+  return launch_fused_fwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, ident, noise, cand, ncand, min_loss,
+                          argmin, partial, warped, nullptr, S, B, NP, H, W, no_ssim, stream);
+}
+
+int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth, const float* proj,
+                          const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
+                          float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
+                          void* stream) {
+  if (!depth) return BBD_E_BADARG;
+  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, argmin, gscale,
+                          grad_depth, grad_proj, S, B, NP, H, W, no_ssim, stream);
+}
+
+int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, const void* const* disp,
+                               const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
+                               const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
+                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out, int S,
+                               int B, int NP, int H, int W, int no_ssim, void* stream) {
+  if (!disp) return BBD_E_BADARG;
+  return launch_fused_fwd(frames, target, nullptr, disp, disp_hw, min_depth, max_depth, proj, ident, noise, cand, ncand,
+                          min_loss, argmin, partial, warped, depth_out, S, B, NP, H, W, no_ssim, stream);
+}
+
+int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
+                               const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
+                               const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
+                               float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
+                               void* stream) {
+  if (!disp) return BBD_E_BADARG;
+  return launch_fused_bwd(frames, target, nullptr, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
+                          grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
+}
+
+int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B,
+                              int H, int W, void* stream) {
+  if (!grad_up || !disp_hw || !grad_disp || n < 0 || n > MAX_SCALES || B <= 0 || H <= 0 || W <= 0) return BBD_E_BADARG;
+  if (n == 0) return 0;
+  AdjointArgs a;
+  a.n = n; a.B = B; a.H = H; a.W = W;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    a.gup[i] = static_cast<const float*>(grad_up[i]);
+    a.gdisp[i] = static_cast<float*>(grad_disp[i]);
+    a.h[i] = disp_hw[2 * i]; a.w[i] = disp_hw[2 * i + 1];
+    if (!a.gup[i] || !a.gdisp[i] || a.h[i] <= 0 || a.w[i] <= 0 || a.h[i] > H || a.w[i] > W) return BBD_E_BADARG;
+    const int f = (H + a.h[i] - 1) / a.h[i];
+    a.q[i] = f <= 1 ? 1 : (f <= 2 ? 4 : (f <= 4 ? 16 : 64));
+    a.block0[i] = blocks;
+    blocks += (int)(((size_t)B * a.h[i] * a.w[i] * a.q[i] + NT - 1) / NT);
+  }
+  a.block0[n] = blocks;
+  hipLaunchKernelGGL(upsample_adjoint_kernel, dim3((unsigned)blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 

@@ -318,6 +318,103 @@ class _FusedReprojectionMin(torch.autograd.Function):
         return grad_depth, grad_pose, None, None, None, None, None, None, None, None
 
 
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        assert t.is_contiguous() and t.dtype == torch.float32
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _hw_array(tensors):
+    arr = (ctypes.c_int32 * (2 * len(tensors)))()
+    for i, t in enumerate(tensors):
+        arr[2 * i], arr[2 * i + 1] = t.shape[-2], t.shape[-1]
+    return arr
+
+
+class _FusedReprojectionMinDisp(torch.autograd.Function):
+    """The fused launch fed with the decoder's disparity maps themselves: bilinear up-sampling +
+    disp_to_depth happen per staged pixel inside the kernels, no depth buffer is read, and the backward folds
+    d depth / d disparity in; only the bilinear adjoint of the reduced scales is a second (single) launch.
+    Returns (loss_sum [S], min_loss, argmin, warped | None, depth [S,B,H,W] | None)."""
+
+    @staticmethod
+    def forward(ctx, proj, target, ident, noise, plan, frame_tensors, no_ssim, materialize, want_depth, min_depth,
+                max_depth, backend, *disps):
+        disps = [d.contiguous() for d in disps]
+        S, B = len(disps), disps[0].shape[0]
+        H, W = target.shape[-2:]
+        dev = target.device
+        tb = plan.tables(dev)
+        ntiles = backend.num_tiles(H, W)
+        proj = proj.contiguous()
+        min_loss = torch.empty(S, B, H, W, device=dev, dtype=torch.float32)
+        argmin = torch.empty(S, B, H, W, device=dev, dtype=torch.uint8)
+        partial = torch.empty(S, B, ntiles, device=dev, dtype=torch.float32)
+        warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
+        depth = torch.empty(S, B, H, W, device=dev, dtype=torch.float32) if want_depth else None
+        backend._check(proj, target, ident, noise, *disps, *frame_tensors.values())
+        frames = frame_pointer_array(frame_tensors)
+        ptab = torch.empty(plan.NP, PROJ_STRIDE, device=dev, dtype=torch.float32)
+        backend.run("bbd_pose_expand", proj, ptr(proj), ptr(ptab), plan.NP)
+        backend.run("bbd_warp_ssim_min_disp_fwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps),
+                    float(min_depth), float(max_depth), ptr(ptab), ptr(ident), ptr(noise), ptr(tb["cand"]),
+                    ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), S, B, plan.NP,
+                    H, W, int(no_ssim))
+        ctx.save_for_backward(proj, target, argmin, ptab, *disps)
+        ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, float(min_depth), float(max_depth))
+        ctx.mark_non_differentiable(min_loss, argmin)
+        if materialize:
+            ctx.mark_non_differentiable(warped)
+        if want_depth:
+            ctx.mark_non_differentiable(depth)
+        return partial.view(S, -1).sum(dim=1), min_loss, argmin, warped, depth
+
+    @staticmethod
+    def backward(ctx, g_sum, *_unused):
+        proj, target, argmin, ptab = ctx.saved_tensors[:4]
+        disps = ctx.saved_tensors[4:]
+        plan, frame_tensors, frames, no_ssim, backend, lo, hi = ctx.meta
+        S, B = len(disps), disps[0].shape[0]
+        H, W = target.shape[-2:]
+        dev = target.device
+        tb = plan.tables(dev)
+        gscale = g_sum.contiguous().to(torch.float32)
+        grad_up = torch.empty(S, B, H, W, device=dev, dtype=torch.float32)
+        ntb = backend.num_tiles_bwd(H, W)
+        gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
+        backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
+                    ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
+                    S, B, plan.NP, H, W, no_ssim)
+        # a scale at full resolution: grad_up IS its disparity gradient; the reduced ones share one adjoint launch
+        grads, small, small_g, small_up = [None] * S, [], [], []
+        for i, d in enumerate(disps):
+            if tuple(d.shape[-2:]) == (H, W):
+                grads[i] = grad_up[i].unsqueeze(1)
+            else:
+                grads[i] = torch.empty_like(d)
+                small.append(d)
+                small_g.append(grads[i])
+                small_up.append(grad_up[i])
+        if small:
+            backend.run("bbd_disp_upsample_adjoint", grad_up, _ptr_array(small_up), _hw_array(small), _ptr_array(small_g),
+                        len(small), B, H, W)
+        gP = gp_partial.sum(dim=(0, 2)).view(plan.NP, 3, 4)
+        gT = torch.matmul(proj[:, :12].view(plan.NP, 3, 4).transpose(1, 2), gP)
+        grad_pose = torch.zeros_like(proj)
+        grad_pose[:, 12:28] = gT.reshape(plan.NP, 16)
+        return (grad_pose,) + (None,) * 11 + tuple(grads)
+
+
+def fused_reprojection_min_disp(disps, proj, target, ident, noise, plan, frame_tensors, min_depth, max_depth,
+                                no_ssim=False, materialize=False, want_depth=True, backend=None):
+    """[("disp", s)] maps in, (loss_sum [S], min_loss, argmin, warped | None, depth [S,B,H,W] | None) out."""
+    return _FusedReprojectionMinDisp.apply(proj, target, ident, noise, plan, frame_tensors, bool(no_ssim),
+                                           bool(materialize), bool(want_depth), min_depth, max_depth,
+                                           backend or default_backend(), *disps)
+
+
 def fused_reprojection_min(depth, proj, target, ident, noise, plan, frame_tensors, no_ssim=False,
                            materialize=False, backend=None):
     """Returns (loss_sum [S], min_loss [S,B,H,W], argmin u8 [S,B,H,W], warped [S,NP,3,H,W] | None)."""

@@ -508,10 +508,6 @@ class Trainer:
         scales = list(opt.scales)
         target = inputs[("color", 0, 0)]
         new = {}
-        depth = ops.disp_pyramid_to_depth([outputs[("disp", s)] for s in scales], H, W,
-                                          opt.min_depth, opt.max_depth, be)          # [S,B,H,W]
-        for i, s in enumerate(scales):
-            new[("depth", 0, s)] = depth[i].unsqueeze(1)
         proj = ops.pose_table(plan, inputs[("K", 0)], inputs[("inv_K", 0)], self._job_poses(inputs, outputs))
         frame_tensors = {f: inputs[("color", f, 0)] for f in plan.frames}
         noise = inputs.get("noise")
@@ -519,8 +515,20 @@ class Trainer:
             noise = torch.randn(plan.B, H, W, device=target.device) * 0.00001
         ident = ops.identity_losses(plan, frame_tensors, target, opt.no_ssim, be)
         materialize = bool(getattr(opt, "materialize_warps", False))
-        loss_sum, min_loss, argmin, warped = ops.fused_reprojection_min(
-            depth, proj, target, ident, noise, plan, frame_tensors, opt.no_ssim, materialize, be)
+        disps = [outputs[("disp", s)] for s in scales]
+        if getattr(opt, "fused_disp", True) and len(scales) <= 4:
+            # the kernels read the low-resolution disparities themselves (up-sampling + disp_to_depth
+            # per staged pixel); outputs[("depth",0,s)] is a by-product of the forward launch
+            loss_sum, min_loss, argmin, warped, depth = ops.fused_reprojection_min_disp(
+                disps, proj, target, ident, noise, plan, frame_tensors, opt.min_depth, opt.max_depth, opt.no_ssim,
+                materialize, bool(getattr(opt, "materialize_depth", True)), be)
+        else:
+            depth = ops.disp_pyramid_to_depth(disps, H, W, opt.min_depth, opt.max_depth, be)          # [S,B,H,W]
+            loss_sum, min_loss, argmin, warped = ops.fused_reprojection_min(
+                depth, proj, target, ident, noise, plan, frame_tensors, opt.no_ssim, materialize, be)
+        if depth is not None:
+            for i, s in enumerate(scales):
+                new[("depth", 0, s)] = depth[i].unsqueeze(1)
         new[("bbd", "loss_sum")] = loss_sum
         new[("bbd", "to_optimise")] = min_loss
         new[("bbd", "argmin")] = argmin

@@ -246,6 +246,67 @@ int hp_disp_to_depth_bwd(const float* disp, const float* /*depth*/, const float*
   return 0;
 }
 
+// ---- disparity-mode forms: composed from the pieces above -------------------------------
+static void hp_depth_planes(const void* const* disp, const int32_t* disp_hw, double min_depth, double max_depth, int S,
+                            int B, int H, int W, float* depth) {
+  for (int s = 0; s < S; ++s)
+    hp_disp_to_depth_fwd(static_cast<const float*>(disp[s]), depth + (size_t)s * B * H * W, B, disp_hw[2 * s],
+                         disp_hw[2 * s + 1], H, W, min_depth, max_depth);
+}
+
+int hp_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, const void* const* disp,
+                              const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
+                              const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
+                              float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out, int S,
+                              int B, int NP, int H, int W, int no_ssim) {
+  std::vector<float> tmp;
+  float* depth = depth_out;
+  if (!depth) { tmp.resize((size_t)S * B * H * W); depth = tmp.data(); }
+  hp_depth_planes(disp, disp_hw, min_depth, max_depth, S, B, H, W, depth);
+  return hp_warp_ssim_min_fwd(frames, target, depth, proj, ident, noise, cand, ncand, min_loss, argmin, partial, warped,
+                              S, B, NP, H, W, no_ssim);
+}
+
+int hp_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
+                              const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
+                              const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
+                              float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim) {
+  std::vector<float> depth((size_t)S * B * H * W);
+  hp_depth_planes(disp, disp_hw, min_depth, max_depth, S, B, H, W, depth.data());
+  const int rc = hp_warp_ssim_min_bwd(frames, target, depth.data(), proj, cand, ncand, argmin, gscale, grad_up, grad_proj,
+                                      S, B, NP, H, W, no_ssim);
+  const float span = (float)(1.0 / min_depth - 1.0 / max_depth);
+  for (size_t i = 0; i < depth.size(); ++i) grad_up[i] *= -span * depth[i] * depth[i];
+  return rc;
+}
+
+int hp_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B, int H,
+                             int W) {
+  for (int k = 0; k < n; ++k) {
+    const int h = disp_hw[2 * k], w = disp_hw[2 * k + 1];
+    const float* g = static_cast<const float*>(grad_up[k]);
+    float* gd = static_cast<float*>(grad_disp[k]);
+    memset(gd, 0, sizeof(float) * B * h * w);
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+          int y0 = y, y1 = y, x0 = x, x1 = x;
+          float ly0 = 1, ly1 = 0, lx0 = 1, lx1 = 0;
+          if (!(h == H && w == W)) {
+            bbd_up_src(y, h, H, &y0, &y1, &ly0, &ly1);
+            bbd_up_src(x, w, W, &x0, &x1, &lx0, &lx1);
+          }
+          const float gv = g[((size_t)b * H + y) * W + x];
+          float* o = gd + (size_t)b * h * w;
+          o[(size_t)y0 * w + x0] += gv * ly0 * lx0;
+          o[(size_t)y0 * w + x1] += gv * ly0 * lx1;
+          o[(size_t)y1 * w + x0] += gv * ly1 * lx0;
+          o[(size_t)y1 * w + x1] += gv * ly1 * lx1;
+        }
+  }
+  return 0;
+}
+
 // smoothness (plain loops; single "chunk" layout: sums [B,1,2], dots [B,1])
 static float hp_edge(const float* im, int hw, int i0, int i1) {
   const float g = fabsf(im[i0] - im[i1]) + fabsf(im[i0 + hw] - im[i1 + hw]) + fabsf(im[i0 + 2 * hw] - im[i1 + 2 * hw]);

@@ -449,3 +449,48 @@ def test_sizes_off_the_tile_grid_on_gpu(H, W, backend):
     _note("odd size: flips %d, texels off %d, max rel %.3e" % (int(mism.sum()), int((rel > 1e-4).sum()), float(rel.max())))
     assert int((rel > 1e-4).sum()) <= 25 * int(mism.sum()) + 4
     assert abs(float(losses["loss"].detach()) - float(out["loss"].detach())) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["md2_b2_32x64", "tri_3105_32x64", "md2_b1_192x640"])
+def test_disparity_mode_equals_depth_plane_mode(name, backend):
+    """the fused launches fed with the low-resolution disparities (up-sampling + disp_to_depth per
+    staged pixel, no depth buffer) give bit-identical maps / arg-min ids / depth to the two-kernel form, and
+    the same disparity and pose gradients (the adjoint is regrouped: 1e-6 of max)."""
+    res = {}
+    for mode in (True, False):
+        case = Case(name, device=DEV)
+        from fused_runner import make_opt, bare_trainer
+        opt = make_opt(case, materialize_warps=False)
+        opt.fused_disp = mode
+        tr = bare_trainer(opt, backend, DEV)
+        inputs = dict(case.inputs)
+        inputs["noise"] = case.noise
+        tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+        tr.valid_frames_trimin(inputs)
+        outputs = {}
+        perr = case.poses_error()
+        for f, T in case.poses.items():
+            outputs[("cam_T_cam", 0, f)] = T
+            if case.decomp:
+                outputs[("cam_T_cam_error", 0, f)] = perr[f]
+        for s in case.scales:
+            outputs[("disp", s)] = case.disp[s]
+        outputs.update(tr.generate_images_pred(inputs, outputs))
+        losses = tr.compute_losses(inputs, outputs)
+        losses["loss"].backward()
+        res[mode] = (outputs, losses, case)
+    (oa, la, ca), (ob, lb, cb) = res[True], res[False]
+    assert torch.equal(oa[("bbd", "to_optimise")], ob[("bbd", "to_optimise")])
+    assert torch.equal(oa[("bbd", "argmin")], ob[("bbd", "argmin")])
+    assert float(la["loss"].detach()) == float(lb["loss"].detach())
+    for s in ca.scales:
+        assert torch.equal(oa[("depth", 0, s)], ob[("depth", 0, s)]), s
+        ga, gb = ca.disp[s].grad, cb.disp[s].grad
+        assert float((ga - gb).abs().max()) <= 1e-6 * float(gb.abs().max()), s
+    for f in ca.poses:
+        if cb.poses[f].grad is not None:
+            assert float((ca.poses[f].grad - cb.poses[f].grad).abs().max()) <= 1e-6 * float(cb.poses[f].grad.abs().max()) + 1e-12
+    # golden check of the by-product depth
+    for s in ca.scales:
+        if ca.has("out/depth/%d" % s):
+            assert torch.equal(oa[("depth", 0, s)].cpu(), ca.expected("out/depth/%d" % s))
