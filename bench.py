@@ -60,7 +60,10 @@ def algorithmic_bytes(plan, S):
         c_id = sum(1 for k, _ in names if k == "I")
         fwd += P * (25 + 12 * c_src + 4 * c_id)
         bwd += P * (21 + 12 * c_src)
+    # the disparity-mode launches are the same kernels fed with the low-resolution disparities:
+    # they are priced with the SAME 8d figure (which still counts 4 B/px of depth they no longer read)
     return {"bbd_warp_ssim_min_fwd": fwd * S, "bbd_warp_ssim_min_bwd": bwd * S,
+            "bbd_warp_ssim_min_disp_fwd": fwd * S, "bbd_warp_ssim_min_disp_bwd": bwd * S,
             "bbd_identity_loss_fwd": 28 * P * plan.NI}
 
 
@@ -362,8 +365,11 @@ def main(argv=None):
                 break
         if args.batch == 12 and tpath is not None:
             tj = json.load(open(tpath))
-            traffic = tj.get(dom, {}).get("traffic_bytes")
+            alias = lambda k: k.replace("_disp_", "_")           # PMC files name the kernels, not the entry points
+            traffic = tj.get(alias(dom), {}).get("traffic_bytes")
             for k in kernels:
+                if alias(k) in tj:
+                    tj[k] = tj[alias(k)]
                 if k in tj:
                     kernels[k]["pmc_traffic_MB_per_launch"] = round(tj[k]["traffic_bytes"] / 1e6, 1)
                     if "valu_wave_instructions" in tj[k]:
