@@ -110,12 +110,13 @@ template <int ROWS, int COLS, int STRIDE, int HALO, int NTH = NT>
 struct Cells {
   static constexpr int N = (ROWS * COLS + NTH - 1) / NTH;
   int lds[N];    // r * STRIDE + c
-  int pix[N];    // yy * W + xx of the (reflected) image pixel
-  int xy[N];     // yy << 16 | xx
-  int own[N];    // 0, or 1 + (r-HALO)*(COLS-2*HALO) + (c-HALO) if the cell is an un-reflected interior pixel
-                 // this tile owns (warped output, sample-derivative planes)
+  int xy[N];     // yy << 16 | xx of the (reflected) image pixel
+  int ownbits;   // bit k: cell k is an un-reflected interior pixel this tile owns (warped / depth output,
+                 // sample-derivative planes).  Two words per cell live across the candidate loop, not four:
+                 // the pixel offset and the own-pixel index are re-derived where they are needed (rarely).
 
   __device__ __forceinline__ void init(int H, int W, int tx0, int ty0) {
+    ownbits = 0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       int i = k * NTH + (int)threadIdx.x;
@@ -124,23 +125,29 @@ struct Cells {
       const int py = ty0 + r - HALO, px = tx0 + c - HALO;
       const int yy = bbd_reflect(py, H), xx = bbd_reflect(px, W);
       lds[k] = r * STRIDE + c;
-      pix[k] = yy * W + xx;
       xy[k] = (yy << 16) | xx;
-      own[k] = (py == yy && px == xx && r >= HALO && r < ROWS - HALO && c >= HALO && c < COLS - HALO)
-                   ? 1 + (r - HALO) * (COLS - 2 * HALO) + (c - HALO) : 0;
+      if (py == yy && px == xx && r >= HALO && r < ROWS - HALO && c >= HALO && c < COLS - HALO) ownbits |= 1 << k;
     }
+  }
+  __device__ __forceinline__ int pix(int k, int W) const { return (xy[k] >> 16) * W + (xy[k] & 0xffff); }
+  __device__ __forceinline__ bool own(int k) const { return (ownbits >> k) & 1; }
+  // index of an owned cell inside the tile's (ROWS-2*HALO) x (COLS-2*HALO) pixel block
+  __device__ __forceinline__ int own_index(int k) const {
+    const int r = lds[k] / STRIDE, c = lds[k] - r * STRIDE;
+    return (r - HALO) * (COLS - 2 * HALO) + (c - HALO);
   }
 };
 
 template <typename CellsT, int PLANE>
-__device__ __forceinline__ void stage_image(const float* __restrict__ img, int hw, const CellsT& cl,
+__device__ __forceinline__ void stage_image(const float* __restrict__ img, int hw, int hw_w, const CellsT& cl,
                                             float (*s)[PLANE]) {
   float v[CellsT::N][3];
 #pragma unroll
   for (int k = 0; k < CellsT::N; ++k) {
-    v[k][0] = img[cl.pix[k]];
-    v[k][1] = img[cl.pix[k] + hw];
-    v[k][2] = img[cl.pix[k] + 2 * hw];
+    const int px = cl.pix(k, hw_w);
+    v[k][0] = img[px];
+    v[k][1] = img[px + hw];
+    v[k][2] = img[px + 2 * hw];
   }
 #pragma unroll
   for (int k = 0; k < CellsT::N; ++k) {
@@ -240,7 +247,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
       for (int ch = 0; ch < 3; ++ch) {
 #if defined(BBD_ABLATE_GATHER)        // timing experiment only: coalesced loads instead of gathers
         const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-        v[kk][ch][0] = v[kk][ch][1] = v[kk][ch][2] = v[kk][ch][3] = src[ch * hw + cl.pix[k]];
+        v[kk][ch][0] = v[kk][ch][1] = v[kk][ch][2] = v[kk][ch][3] = src[ch * hw + cl.pix(k, dm.W)];
 #else
         bbd_fetch4(src + ch * hw, &t[kk], v[kk][ch]);
 #endif
@@ -255,16 +262,16 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
         val[ch] = bbd_bilerp(v[kk][ch], &t[kk]);
         s[ch][cl.lds[k]] = val[ch];
       }
-      if (warped_out != nullptr && cl.own[k]) {
-        float* o = warped_out + cl.pix[k];
+      if (warped_out != nullptr && cl.own(k)) {
+        float* o = warped_out + cl.pix(k, dm.W);
         o[0] = val[0];
         o[hw] = val[1];
         o[2 * hw] = val[2];
       }
-      if (dv != nullptr && cl.own[k]) {
+      if (dv != nullptr && cl.own(k)) {
         // backward: d warped / d (ix, iy) of the tile's own pixels from the taps already in registers
         // (zero where the border clamp is active), so the sample-gradient phase needs no gathers
-        const int ci = cl.own[k] - 1;
+        const int ci = cl.own_index(k);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
           const float* vv = v[kk][ch];
@@ -396,8 +403,8 @@ __global__ __launch_bounds__(NT) void identity_loss_kernel(FramePtrs frames, con
   const size_t img = (size_t)3 * hw;
   Cells<LH, LW, LS, 1> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(target + (size_t)b * img, hw, cl, s_y);
-  stage_image(frames.base[slot] + (size_t)row * img, hw, cl, s_x);
+  stage_image(target + (size_t)b * img, hw, W, cl, s_y);
+  stage_image(frames.base[slot] + (size_t)row * img, hw, W, cl, s_x);
   __syncthreads();
   int ly, lx0;
   strip_of_thread(&ly, &lx0);
@@ -476,14 +483,14 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   BBD_STAMP(0);
   Cells<LH, LW, LS, 1> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(a.target + (size_t)b * img, hw, cl, s_y);
+  stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
   float dcell[Cells<LH, LW, LS, 1>::N];
   const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
   load_depth(dsrc, H, W, cl, dcell);
   if (a.depth_out != nullptr) {
 #pragma unroll
     for (int k = 0; k < Cells<LH, LW, LS, 1>::N; ++k)
-      if (cl.own[k]) a.depth_out[sb * hw + cl.pix[k]] = dcell[k];
+      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
   }
   BBD_STAMP(1);
   __syncthreads();
@@ -498,13 +505,12 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   float mu_y[3][PPT], sg_y[3][PPT];
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
 
-  float nz[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (a.noise != nullptr && row_ok) load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
-
+  // (register budget: this kernel sits on the 168-VGPR line of 3 waves per SIMD - the four arg-min ids share one
+  // word and the identity noise is fetched where an identity candidate needs it, not held across the loop)
   float best[PPT];
-  int arg[PPT];
+  unsigned argw = 0u;
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) { best[j] = INFINITY; arg[j] = 0; }
+  for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
   const int nc = a.ncand[b];
@@ -531,12 +537,20 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
       for (int j = 0; j < PPT; ++j) loss[j] = 0.0f;
       if (row_ok) {
         load_strip(a.ident + (size_t)cd.row * hw + pix, xx, W, vec_ok, loss);
+        if (a.noise != nullptr) {
+          float nz[PPT];
+          load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) loss[j] += nz[j];
+          for (int j = 0; j < PPT; ++j) loss[j] += nz[j];
+        }
       }
     }
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) bbd_min_update(loss[j], c, &best[j], &arg[j]);
+    for (int j = 0; j < PPT; ++j) {
+      int aj = (int)((argw >> (8 * j)) & 0xffu);
+      bbd_min_update(loss[j], c, &best[j], &aj);
+      argw = (argw & ~(0xffu << (8 * j))) | ((unsigned)aj << (8 * j));
+    }
   }
 
   float tsum = 0.0f;
@@ -544,14 +558,13 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
     store_strip(a.min_loss + sb * hw + pix, xx, W, vec_ok, best);
     uint8_t* ao = a.argmin + sb * hw + pix;
     if (vec_ok) {
-      *reinterpret_cast<uint32_t*>(ao) =
-          (uint32_t)arg[0] | ((uint32_t)arg[1] << 8) | ((uint32_t)arg[2] << 16) | ((uint32_t)arg[3] << 24);
+      *reinterpret_cast<uint32_t*>(ao) = argw;
       tsum = ((best[0] + best[1]) + best[2]) + best[3];
     } else {
 #pragma unroll
       for (int j = 0; j < PPT; ++j)
         if (xx + j < W) {
-          ao[j] = (uint8_t)arg[j];
+          ao[j] = (uint8_t)(argw >> (8 * j));
           tsum += best[j];
         }
     }
@@ -644,9 +657,10 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
     const float* tg = a.target + (size_t)b * img;
 #pragma unroll
     for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
-      tcell[k][0] = tg[cl.pix[k]];
-      tcell[k][1] = tg[cl.pix[k] + hw];
-      tcell[k][2] = tg[cl.pix[k] + 2 * hw];
+      const int px = cl.pix(k, W);
+      tcell[k][0] = tg[px];
+      tcell[k][1] = tg[px + hw];
+      tcell[k][2] = tg[px + 2 * hw];
     }
   }
   float dcell[Cells<BH, BW, BS, 2>::N];
@@ -940,7 +954,10 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 }
 
 #ifndef BBD_BWD2_WGS
-#define BBD_BWD2_WGS 4   // waves per SIMD (HIP: second __launch_bounds__ argument): 2 workgroups per CU need <= 128 VGPRs
+#define BBD_BWD2_WGS 3   // waves per SIMD (HIP: second __launch_bounds__ argument).  3 = up to 168 VGPRs, no spills.
+                         // Measured: 3, 4 and 5 waves per SIMD run within 1 % of each other (the kernel is issue-bound,
+                         // profiles/r02/bwd_variants_narrow_tile.txt), but at 4 (128 VGPRs) hipcc spills 15 registers and
+                         // the scratch traffic doubles the launch's HBM bytes (PMC: 549 MB vs 265 MB algorithmic)
 #endif
 #ifndef BBD_BWD2_WARP_BATCH
 #define BBD_BWD2_WARP_BATCH 3
@@ -993,9 +1010,10 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     const float* tg = a.target + (size_t)b * img;
 #pragma unroll
     for (int k = 0; k < CellsB::N; ++k) {
-      tcell[k][0] = tg[cl.pix[k]];
-      tcell[k][1] = tg[cl.pix[k] + hw];
-      tcell[k][2] = tg[cl.pix[k] + 2 * hw];
+      const int px = cl.pix(k, W);
+      tcell[k][0] = tg[px];
+      tcell[k][1] = tg[px + hw];
+      tcell[k][2] = tg[px + 2 * hw];
     }
   }
   float dcell[CellsB::N];
@@ -1435,8 +1453,8 @@ __global__ __launch_bounds__(NT) void ssim_map_kernel(const float* __restrict__ 
   const size_t hw = (size_t)H * W, img = 3 * hw;
   Cells<LH, LW, LS, 1> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(y + (size_t)item * img, (int)hw, cl, s_y);
-  stage_image(x + (size_t)item * img, (int)hw, cl, s_x);
+  stage_image(y + (size_t)item * img, (int)hw, W, cl, s_y);
+  stage_image(x + (size_t)item * img, (int)hw, W, cl, s_x);
   __syncthreads();
   int ly, lx0;
   strip_of_thread(&ly, &lx0);
@@ -1562,8 +1580,8 @@ __global__ __launch_bounds__(NT) void ssim_bwd_kernel(const float* __restrict__ 
   cl.init(H, W, tc.tx0, tc.ty0);
 #pragma unroll
   for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
-    s_x[cl.lds[k]] = xp[cl.pix[k]];
-    s_y[cl.lds[k]] = yp[cl.pix[k]];
+    s_x[cl.lds[k]] = xp[cl.pix(k, W)];
+    s_y[cl.lds[k]] = yp[cl.pix(k, W)];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < CH * CW; i += NT) {
