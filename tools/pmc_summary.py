@@ -25,13 +25,16 @@ if len(sys.argv) > 2:
     names = {"warp_ssim_min_fwd": "bbd_warp_ssim_min_fwd", "warp_ssim_min_bwd": "bbd_warp_ssim_min_bwd",
              "identity_loss": "bbd_identity_loss_fwd"}
     out = {"_note": "rocprofv3 PMC, separate passes for FETCH_SIZE and WRITE_SIZE (tools/pmc_passes.sh); KB -> bytes "
-                    "x1024; FETCH_SIZE NOT doubled: these kernels issue 4/8-byte loads, and the dword-load "
-                    "disp_to_depth kernel calibrates FETCH_SIZE at 1.00x of its known bytes (the x2 correction of "
-                    "MI355X_MICROARCH.md applies to 16-byte-per-lane streams)",
-           "workload": "MD2 batch 12, 4 scales, 640x192 (tools/kernel_bench.py --config md2)"}
+                    "x1024; FETCH_SIZE DOUBLED (MI355X_MICROARCH.md, HBM: gfx950 tallies 128-B requests at 64 B). "
+                    "Calibrated on this build's own access widths by tools/microbench/fetch_calib.hip over a 1 GiB "
+                    "buffer: 4-, 8- and 16-byte-per-lane streams and the warp kernels' 8-byte texel-pair gather all "
+                    "report exactly 0.5000 of their known bytes (profiles/r02/fetch_size_calibration.txt); round 1's "
+                    "'not doubled' reading came from a buffer that fitted the Infinity Cache. WRITE_SIZE as reported. "
+                    "Fabric-side requests: Infinity-Cache hits are counted.",
+           "workload": sys.argv[3] if len(sys.argv) > 3 else "tools/kernel_bench.py"}
     for k, cs in vals.items():
         if k in names and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024
+            f = 2.0 * sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024
             w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
             out[names[k]] = {"fetch_bytes": round(f), "write_bytes": round(w), "traffic_bytes": round(f + w)}
             if "SQ_INSTS_VALU" in cs:
