@@ -67,6 +67,11 @@ SIGNATURES = {
     "bbd_dispconv_scratch_doubles": [_i],
     "bbd_dispconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_dispconv_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "bbd_upcat_pad1_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "bbd_upcat_pad1_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "bbd_bias_elu_scratch_doubles": [_i, _i, _i],
+    "bbd_bias_elu_fwd": [_p, _p, _i, _i, _i, _p],
+    "bbd_bias_elu_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
     "bbd_dwconv_tokens_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "bbd_factor_att_supported": [_i, _i],
@@ -124,6 +129,9 @@ class HipLibrary:
 
     def factor_att_scratch_floats(self, B, N, C, Ch):
         return self._dll.bbd_factor_att_scratch_floats(B, N, C, Ch)
+
+    def bias_elu_scratch_doubles(self, N, C, HW):
+        return self._dll.bbd_bias_elu_scratch_doubles(N, C, HW)
 
     def dispconv_scratch_doubles(self, C):
         return self._dll.bbd_dispconv_scratch_doubles(C)

@@ -307,6 +307,115 @@ __global__ __launch_bounds__(RW * RR) void reflect_pad1_bwd_kernel(const float* 
   }
 }
 
+// ---- decoder glue: nearest x2 up-sampling + skip concatenation + ReflectionPad2d(1) as ONE pass -------------
+// (reference networks/depth_decoder.py:44-50: `upsample(x)`, `torch.cat([x, skip], 1)`, then the next ConvBlock's
+// ReflectionPad2d(1), layers.py:118-133 - three full-tensor round trips in eager mode).  out[n, c, py, px] for the
+// padded (H+2)x(W+2) image of the concatenation; H = 2h, W = 2w.
+__global__ __launch_bounds__(RW * RR) void upcat_pad_fwd_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                                float* __restrict__ out, int C1, int C2, int h, int w) {
+  const int H = 2 * h, W = 2 * w, PH = H + 2, PW = W + 2;
+  const int py = blockIdx.x * RR + threadIdx.y;
+  if (py >= PH) return;
+  const int pl = blockIdx.y, n = pl / (C1 + C2), c = pl - n * (C1 + C2);
+  const int yy = reflect1(py, H);
+  float* dst = out + ((size_t)pl * PH + py) * PW;
+  if (c < C1) {
+    const float* src = x + (((size_t)n * C1 + c) * h + (yy >> 1)) * w;
+    for (int px = threadIdx.x; px < PW; px += RW) dst[px] = src[reflect1(px, W) >> 1];
+  } else {
+    const float* src = skip + (((size_t)n * C2 + (c - C1)) * H + yy) * W;
+    for (int px = threadIdx.x; px < PW; px += RW) dst[px] = src[reflect1(px, W)];
+  }
+}
+
+// sum of grad_out over every padded position that reads image position (y, x)  (1, 2, 3, 4, 6 or 9 terms)
+__device__ __forceinline__ float pad1_adjoint(const float* __restrict__ g, int y, int x, int H, int W) {
+  const int PW = W + 2;
+  int rows[3], nr = 0;
+  rows[nr++] = y + 1;
+  if (y == 1) rows[nr++] = 0;
+  if (y == H - 2) rows[nr++] = H + 1;
+  float acc = 0.0f;
+  for (int a = 0; a < nr; ++a) {
+    const float* row = g + (size_t)rows[a] * PW;
+    acc += row[x + 1];
+    if (x == 1) acc += row[0];
+    if (x == W - 2) acc += row[PW - 1];
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(RW * RR) void upcat_pad_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gx,
+                                                                float* __restrict__ gskip, int C1, int C2, int h, int w) {
+  const int H = 2 * h, W = 2 * w, PH = H + 2, PW = W + 2;
+  const int pl = blockIdx.y, n = pl / (C1 + C2), c = pl - n * (C1 + C2);
+  const float* g = gout + (size_t)pl * PH * PW;
+  if (c < C1) {                                  // low-resolution rows: each output sums its 2x2 up-sampled block
+    const int i = blockIdx.x * RR + threadIdx.y;
+    if (i >= h) return;
+    float* dst = gx + (((size_t)n * C1 + c) * h + i) * w;
+    for (int j = threadIdx.x; j < w; j += RW)
+      dst[j] = (pad1_adjoint(g, 2 * i, 2 * j, H, W) + pad1_adjoint(g, 2 * i, 2 * j + 1, H, W)) +
+               (pad1_adjoint(g, 2 * i + 1, 2 * j, H, W) + pad1_adjoint(g, 2 * i + 1, 2 * j + 1, H, W));
+  } else {
+    for (int y = blockIdx.x * RR + threadIdx.y; y < H; y += gridDim.x * RR) {
+      float* dst = gskip + (((size_t)n * C2 + (c - C1)) * H + y) * W;
+      for (int xx = threadIdx.x; xx < W; xx += RW) dst[xx] = pad1_adjoint(g, y, xx, H, W);
+    }
+  }
+}
+
+// ---- decoder glue: bias + ELU in place on the convolution's output, and its backward with the bias gradient ------
+// (layers.ConvBlock = Conv3x3 + ELU, layers.py:103-115; eager PyTorch-ROCm launches conv, a bias add and ELU forward,
+// and ELU-backward plus a bias reduction backward).  ELU(alpha = 1): y = v > 0 ? v : expm1(v); dy/dv = y > 0 ? 1 : y + 1.
+__global__ __launch_bounds__(NT) void bias_elu_fwd_kernel(float* __restrict__ y, const float* __restrict__ bias, int C, int HW,
+                                                          size_t total) {
+  for (size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * NT * 4) {
+    const int c = (int)((i / HW) % C);            // HW % 4 == 0: the four elements share a channel
+    const float b = bias[c];
+    float4 v = *reinterpret_cast<float4*>(y + i);
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    v.x = v.x > 0.0f ? v.x : expm1f(v.x); v.y = v.y > 0.0f ? v.y : expm1f(v.y);
+    v.z = v.z > 0.0f ? v.z : expm1f(v.z); v.w = v.w > 0.0f ? v.w : expm1f(v.w);
+    *reinterpret_cast<float4*>(y + i) = v;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bias_elu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                          float* __restrict__ gx, double* __restrict__ part, int N, int C,
+                                                          int HW, int split) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y;
+  int len = (HW + split - 1) / split;
+  len = (len + 3) & ~3;
+  const int lo = blockIdx.x * len, hi = min(HW, lo + len);
+  double acc = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * HW;
+    float s = 0.0f;
+    for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+      const float4 o = *reinterpret_cast<const float4*>(y + base + i);
+      float4 g = *reinterpret_cast<const float4*>(gy + base + i);
+      g.x = o.x > 0.0f ? g.x : g.x * (o.x + 1.0f); g.y = o.y > 0.0f ? g.y : g.y * (o.y + 1.0f);
+      g.z = o.z > 0.0f ? g.z : g.z * (o.z + 1.0f); g.w = o.w > 0.0f ? g.w : g.w * (o.w + 1.0f);
+      *reinterpret_cast<float4*>(gx + base + i) = g;
+      s += (g.x + g.y) + (g.z + g.w);
+    }
+    acc += (double)s;
+  }
+  const double t = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(size_t)c * split + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(64) void bias_grad_final_kernel(const double* __restrict__ part, float* __restrict__ gbias, int C,
+                                                             int split) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < split; ++k) s += part[(size_t)c * split + k];
+  gbias[c] = (float)s;
+}
+
 // MaxPool2d(kernel 3, stride 2, padding 1): ATen's scan order and tie / NaN rule (first maximum in
 // row-major window order; a NaN replaces the running maximum).  `code` = window position 0..8.
 __global__ __launch_bounds__(RW * RR) void maxpool3s2_fwd_kernel(const float* __restrict__ in,
@@ -630,6 +739,45 @@ int bbd_reflect_pad1_bwd(const float* grad_out, float* grad_in, int planes, int 
   if (!grad_out || !grad_in || planes <= 0 || planes > 65535 || H < 2 || W < 2) return BBD_E_BADARG;
   hipLaunchKernelGGL(reflect_pad1_bwd_kernel, dim3((unsigned)((H + RR - 1) / RR), (unsigned)planes), dim3(RW, RR), 0,
                      static_cast<hipStream_t>(stream), grad_out, grad_in, H, W);
+  return status();
+}
+
+int bbd_upcat_pad1_fwd(const float* x, const float* skip, float* out, int N, int C1, int C2, int h, int w, void* stream) {
+  if (!x || !out || N <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !skip) || h < 1 || w < 1) return BBD_E_BADARG;
+  if ((long)N * (C1 + C2) > 65535) return BBD_E_BADARG;
+  hipLaunchKernelGGL(upcat_pad_fwd_kernel, dim3((unsigned)((2 * h + 2 + RR - 1) / RR), (unsigned)(N * (C1 + C2))), dim3(RW, RR),
+                     0, static_cast<hipStream_t>(stream), x, skip, out, C1, C2, h, w);
+  return status();
+}
+
+int bbd_upcat_pad1_bwd(const float* grad_out, float* grad_x, float* grad_skip, int N, int C1, int C2, int h, int w,
+                       void* stream) {
+  if (!grad_out || !grad_x || N <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !grad_skip) || h < 1 || w < 1) return BBD_E_BADARG;
+  if ((long)N * (C1 + C2) > 65535) return BBD_E_BADARG;
+  hipLaunchKernelGGL(upcat_pad_bwd_kernel, dim3((unsigned)((2 * h + RR - 1) / RR), (unsigned)(N * (C1 + C2))), dim3(RW, RR), 0,
+                     static_cast<hipStream_t>(stream), grad_out, grad_x, grad_skip, C1, C2, h, w);
+  return status();
+}
+
+int bbd_bias_elu_scratch_doubles(int N, int C, int HW) { return C * pick_split(N, HW); }
+
+int bbd_bias_elu_fwd(float* y, const float* bias, int N, int C, int HW, void* stream) {
+  if (!y || !bias || N <= 0 || C <= 0 || HW <= 0 || (HW & 3)) return BBD_E_BADARG;
+  const size_t total = (size_t)N * C * HW;
+  const size_t blocks = (total / 4 + NT - 1) / NT;
+  hipLaunchKernelGGL(bias_elu_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), y, bias, C, HW, total);
+  return status();
+}
+
+int bbd_bias_elu_bwd(const float* y, const float* grad_y, float* grad_x, float* grad_bias, double* scratch, int N, int C,
+                     int HW, void* stream) {
+  if (!y || !grad_y || !grad_x || !grad_bias || !scratch || N <= 0 || C <= 0 || HW <= 0 || (HW & 3)) return BBD_E_BADARG;
+  const int split = pick_split(N, HW);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bias_elu_bwd_kernel, dim3((unsigned)split, (unsigned)C), dim3(NT), 0, st, y, grad_y, grad_x, scratch, N, C,
+                     HW, split);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, scratch, grad_bias, C, split);
   return status();
 }
 

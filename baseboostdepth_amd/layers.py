@@ -96,15 +96,31 @@ class Conv3x3(nn.Module):
 
 
 class ConvBlock(nn.Module):
-    """Conv3x3 + ELU (layers.py:103-115)."""
+    """Conv3x3 + ELU (layers.py:103-115).  fp32 GPU tensors: bias-free MIOpen convolution, then bias + ELU as
+    one in-place HIP pass (and ELU' + bias gradient as one pass backward) instead of conv / add / ELU."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.conv = Conv3x3(in_channels, out_channels)
         self.nonlin = nn.ELU(inplace=True)
 
+    def _fused(self, x):
+        return (x.is_cuda and x.dtype == torch.float32 and ops.FUSED_NN and self.conv.conv.out_channels > 1
+                and self.conv.conv.bias is not None and (x.shape[2] * x.shape[3]) % 4 == 0)
+
     def forward(self, x):
+        if self._fused(x):
+            return self.forward_padded(self.conv.pad(x))
         return self.nonlin(self.conv(x))
+
+    def forward_padded(self, xp):
+        """`xp` already carries the 1-pixel reflection border (e.g. from `ops.upcat_pad`)."""
+        conv = self.conv.conv
+        out_hw = (xp.shape[2] - 2) * (xp.shape[3] - 2)
+        if xp.is_cuda and xp.dtype == torch.float32 and ops.FUSED_NN and conv.bias is not None and out_hw % 4 == 0:
+            y = torch.nn.functional.conv2d(xp, conv.weight, None)
+            return ops.bias_elu_(y, conv.bias)
+        return self.nonlin(conv(xp))
 
 
 def upsample(x):

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..layers import ConvBlock, Conv3x3
 
 _DECODER_WIDTHS = (16, 32, 64, 128, 256)
@@ -45,10 +46,16 @@ class DepthDecoder(nn.Module):
         self.outputs = {}
         x = input_features[-1]
         for level in reversed(range(5)):
-            x = F.interpolate(self._stage("upconv", level, 0)(x), scale_factor=2, mode="nearest")
-            if self.use_skips and level > 0:
-                x = torch.cat([x, input_features[level - 1]], 1)
-            x = self._stage("upconv", level, 1)(x)
+            x = self._stage("upconv", level, 0)(x)
+            skip = input_features[level - 1] if (self.use_skips and level > 0) else None
+            if ops.upcat_pad_supported(x, skip):
+                # nearest x2 + skip concatenation + the next block's reflection border in ONE HIP pass
+                x = self._stage("upconv", level, 1).forward_padded(ops.upcat_pad(x, skip))
+            else:
+                x = F.interpolate(x, scale_factor=2, mode="nearest")
+                if skip is not None:
+                    x = torch.cat([x, skip], 1)
+                x = self._stage("upconv", level, 1)(x)
             if level in self.scales:
                 self.outputs[("disp", level)] = torch.sigmoid(self._stage("dispconv", level)(x))
         return self.outputs

@@ -740,6 +740,77 @@ def maxpool3s2(x, backend=None):
     return _MaxPool3s2.apply(x, backend or default_backend())
 
 
+# ---------------------------------------------------------------------------- decoder glue
+class _UpCatPad(torch.autograd.Function):
+    """ReflectionPad2d(1)(cat(nearest_x2(x), skip)) in one pass each way (decoder glue, csrc/bbd_nn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, backend):
+        x = x.contiguous()
+        N, C1, h, w = x.shape
+        C2 = 0
+        if skip is not None:
+            skip = skip.contiguous()
+            C2 = skip.shape[1]
+            assert skip.shape == (N, C2, 2 * h, 2 * w)
+        backend._check(x, skip)
+        out = torch.empty(N, C1 + C2, 2 * h + 2, 2 * w + 2, device=x.device, dtype=torch.float32)
+        backend.run("bbd_upcat_pad1_fwd", x, ptr(x), ptr(skip), ptr(out), N, C1, C2, h, w)
+        ctx.meta = (N, C1, C2, h, w, backend)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        N, C1, C2, h, w, backend = ctx.meta
+        gout = gout.contiguous()
+        gx = torch.empty(N, C1, h, w, device=gout.device, dtype=torch.float32)
+        gs = torch.empty(N, C2, 2 * h, 2 * w, device=gout.device, dtype=torch.float32) if C2 else None
+        backend.run("bbd_upcat_pad1_bwd", gout, ptr(gout), ptr(gx), ptr(gs), N, C1, C2, h, w)
+        return gx, gs, None
+
+
+def upcat_pad(x, skip=None, backend=None):
+    return _UpCatPad.apply(x, skip, backend or default_backend())
+
+
+def upcat_pad_supported(x, skip):
+    n_planes = x.shape[0] * (x.shape[1] + (skip.shape[1] if skip is not None else 0))
+    return (FUSED_NN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and n_planes <= 65535
+            and (skip is None or (skip.is_cuda and skip.dtype == torch.float32)))
+
+
+class _BiasELU(torch.autograd.Function):
+    """ELU(conv_out + bias) in place on the bias-free convolution's output; backward from the saved OUTPUT
+    (ELU' = y > 0 ? 1 : y + 1) with the bias gradient in the same pass."""
+
+    @staticmethod
+    def forward(ctx, y, bias, backend):
+        assert y.is_contiguous()
+        N, C, H, W = y.shape
+        backend._check(y, bias)
+        backend.run("bbd_bias_elu_fwd", y, ptr(y), ptr(bias), N, C, H * W)
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(y)
+        ctx.backend = backend
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        backend = ctx.backend
+        N, C, H, W = y.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        gb = torch.empty(C, device=y.device, dtype=torch.float32)
+        scratch = torch.empty(backend.lib.bias_elu_scratch_doubles(N, C, H * W), device=y.device, dtype=torch.float64)
+        backend.run("bbd_bias_elu_bwd", y, ptr(y), ptr(gy), ptr(gx), ptr(gb), ptr(scratch), N, C, H * W)
+        return gx, gb, None
+
+
+def bias_elu_(conv_out, bias, backend=None):
+    return _BiasELU.apply(conv_out, bias, backend or default_backend())
+
+
 # ---------------------------------------------------------------------------- disparity head Conv3x3(C -> 1)
 class _DispConv(torch.autograd.Function):
     @staticmethod

@@ -304,6 +304,21 @@ int bbd_dispconv_bwd(const float* x, const float* weight, const float* grad_y, f
  * both and adds the number of bit mismatches to *mismatches (device int32, caller zeroes it). */
 int bbd_selftest_div(int blocks, int iters, unsigned seed, int32_t* mismatches, void* stream);
 
+/* Decoder glue (reference networks/depth_decoder.py:44-50, layers.py:103-133), fp32 NCHW:
+ *   bbd_upcat_pad1_fwd : out [N, C1+C2, 2h+2, 2w+2] = ReflectionPad2d(1)(cat(nearest_x2(x [N,C1,h,w]), skip [N,C2,2h,2w]))
+ *                        in one pass (skip may be NULL with C2 = 0); _bwd: grad_out -> grad_x, grad_skip (gather form,
+ *                        no atomics, deterministic).  N*(C1+C2) <= 65535.
+ *   bbd_bias_elu_fwd   : y <- ELU(y + bias[c]) in place on a convolution's output [N,C,HW] (HW % 4 == 0)
+ *   bbd_bias_elu_bwd   : grad_x = grad_y * ELU'(from the saved output y), grad_bias[c] = sum grad_x (fp64 partial sums,
+ *                        fixed order); scratch = bbd_bias_elu_scratch_doubles(N,C,HW) doubles.                       */
+int bbd_upcat_pad1_fwd(const float* x, const float* skip, float* out, int N, int C1, int C2, int h, int w, void* stream);
+int bbd_upcat_pad1_bwd(const float* grad_out, float* grad_x, float* grad_skip, int N, int C1, int C2, int h, int w,
+                       void* stream);
+int bbd_bias_elu_scratch_doubles(int N, int C, int HW);
+int bbd_bias_elu_fwd(float* y, const float* bias, int N, int C, int HW, void* stream);
+int bbd_bias_elu_bwd(const float* y, const float* grad_y, float* grad_x, float* grad_bias, double* scratch, int N, int C,
+                     int HW, void* stream);
+
 /* ---- MonoViT encoder (BASELINE configs[4]): depth-wise convolution on token-layout activations ----------
  * The position encodings of the reference's MPViT (networksvit/mpvit.py:240-330: ConvPosEnc, ConvRelPosEnc)
  * are depth-wise k x k convolutions (k in {3,5,7}, stride 1, zero padding k/2) over the token matrix viewed

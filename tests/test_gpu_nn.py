@@ -186,3 +186,47 @@ def test_depth_decoder_fused_vs_stock():
         assert _rel(a, b) < 1e-5
     for n in g0:
         assert _rel(g1[n], g0[n]) < 2e-3, n
+
+
+@pytest.mark.parametrize("N,C1,C2,h,w", [(2, 16, 8, 6, 10), (1, 5, 0, 3, 5), (3, 32, 64, 24, 80), (2, 4, 4, 1, 2)])
+def test_upsample_concat_pad_in_one_pass(N, C1, C2, h, w):
+    """ReflectionPad2d(1)(cat(nearest_x2(x), skip)) against the three torch ops, forward and both gradients."""
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(N * 10 + C1)
+    x0 = torch.randn(N, C1, h, w, generator=g).to(DEV)
+    s0 = torch.randn(N, C2, 2 * h, 2 * w, generator=g).to(DEV) if C2 else None
+    go = torch.randn(N, C1 + C2, 2 * h + 2, 2 * w + 2, generator=g).to(DEV)
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        s = s0.clone().requires_grad_(True) if s0 is not None else None
+        if fused:
+            y = ops.upcat_pad(x, s)
+        else:
+            u = F.interpolate(x, scale_factor=2, mode="nearest")
+            y = F.pad(torch.cat([u, s], 1) if s is not None else u, (1, 1, 1, 1), mode="reflect")
+        y.backward(go)
+        return [y.detach(), x.grad] + ([s.grad] if s is not None else [])
+
+    for a, b in zip(run(True), run(False)):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-6 * (1 + float(b.abs().max())), float((a - b).abs().max())
+
+
+def test_bias_elu_in_place_and_its_backward():
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for (N, C, H, W) in ((2, 16, 12, 20), (1, 3, 6, 10), (3, 64, 48, 160)):
+        v0 = (2 * torch.randn(N, C, H, W, generator=g)).to(DEV)
+        b0 = torch.randn(C, generator=g).to(DEV)
+        gy = torch.randn(N, C, H, W, generator=g).to(DEV)
+
+        def run(fused):
+            v, b = v0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = ops.bias_elu_(v * 1.0, b) if fused else F.elu(v + b.view(1, C, 1, 1))
+            y.backward(gy)
+            return y.detach(), v.grad, b.grad
+
+        got, want = run(True), run(False)
+        for name, a, b_, tol in zip(("y", "grad_x", "grad_bias"), got, want, (1e-6, 1e-6, 2e-5)):
+            assert _rel(a, b_) < tol, (name, _rel(a, b_))
+        assert all(torch.equal(p, q) for p, q in zip(got, run(True)))       # deterministic
