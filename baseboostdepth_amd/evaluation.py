@@ -73,7 +73,7 @@ STEREO_SCALE_FACTOR = 5.4          # evaluate_depth.py:45
 
 
 def evaluate(opt, dataloader=None, gt_depths=None, models=None, batch_size=16):
-    """KITTI branch of the reference's `evaluate(opt)` (evaluate_depth.py:104-317) for the ResNet models:
+    """KITTI branch of the reference's `evaluate(opt)` (evaluate_depth.py:104-317) for the ResNet and MonoViT (`--ViT`) models:
     predicts disparities for a split, scores them against `gt_depths.npz` with median (mono) or 5.4x
     (stereo) scaling, returns (mean_errors[7], ratios).  Differences by design: images are prepared by the
     device loader and each batch is scored by one `bbd_depth_metrics` launch while it is still in HBM
@@ -94,8 +94,14 @@ def evaluate(opt, dataloader=None, gt_depths=None, models=None, batch_size=16):
         assert os.path.isdir(folder), "Cannot find a folder at {}".format(folder)
         enc_dict = torch.load(os.path.join(folder, "encoder.pth"), map_location=device)
         height, width = enc_dict["height"], enc_dict["width"]
-        encoder = networks.ResnetEncoder(opt.num_layers, False)
-        decoder = networks.DepthDecoder(encoder.num_ch_enc)
+        if getattr(opt, "ViT", False):                  # MonoViT checkpoints (evaluate_depth.py:141-149)
+            from . import networksvit
+            encoder = networksvit.mpvit_small(checkpoint=None)
+            encoder.num_ch_enc = [64, 128, 216, 288, 288]
+            decoder = networksvit.DepthDecoder()
+        else:
+            encoder = networks.ResnetEncoder(opt.num_layers, False)
+            decoder = networks.DepthDecoder(encoder.num_ch_enc)
         own = encoder.state_dict()
         encoder.load_state_dict({k: v for k, v in enc_dict.items() if k in own})
         decoder.load_state_dict(torch.load(os.path.join(folder, "depth.pth"), map_location=device), strict=False)

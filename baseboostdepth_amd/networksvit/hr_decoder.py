@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..layers import ConvBlock, Conv3x3, upsample
 
 _GRID = ["01", "11", "21", "31", "02", "12", "22", "03", "13", "04"]     # evaluation order
@@ -123,11 +124,18 @@ class DepthDecoder(nn.Module):
             halved = c["X_%s_Conv_0" % below](X[below])
             if node in _DIAGONAL:
                 X[node] = c["X_%s_attention" % node](halved, same_row)
+            elif col == 1 and ops.upcat_pad_supported(halved, same_row[0]):
+                # up-sampling + concatenation + the block's reflection border in one HIP pass (csrc/bbd_nn.hip)
+                X[node] = c["X_%s_Conv_1" % below].forward_padded(ops.upcat_pad(halved, same_row[0]))
             else:
                 x = torch.cat([upsample(halved)] + same_row, 1)
                 if col != 1:
                     x = c["X_%s_downsample" % node](x)
                 X[node] = c["X_%s_Conv_1" % below](x)
-        top = c["X_04_Conv_1"](upsample(c["X_04_Conv_0"](X["04"])))
+        last = c["X_04_Conv_0"](X["04"])
+        if ops.upcat_pad_supported(last, None):
+            top = c["X_04_Conv_1"].forward_padded(ops.upcat_pad(last, None))
+        else:
+            top = c["X_04_Conv_1"](upsample(last))
         heads = {0: top, 1: X["04"], 2: X["13"], 3: X["22"]}
         return {("disp", s): torch.sigmoid(c["dispconv%d" % s](heads[s])) for s in range(4)}
