@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch_size", type=int, default=12)
     ap.add_argument("--boosted", action="store_true")
+    ap.add_argument("--ViT", action="store_true", help="MonoViT: MPViT-small encoder + HR decoder (BASELINE configs[4])")
     a = ap.parse_args()
     rank, local, world = distributed.init_from_env()
     torch.cuda.set_device(local)
@@ -33,7 +34,7 @@ def main():
         max_depth=100.0, disparity_smoothness=1e-3, no_ssim=False, rand=True, trimin=a.boosted, decomp=a.boosted,
         pose_error=5.5, incremental_skip=a.boosted, partial_skip=a.boosted, num_layers=18, weights_init="scratch",
         learning_rate=1e-4, no_cuda=False, cuda=local, load_weights_folder="None", log_dir="/tmp/bbd_logs",
-        model_name="synthetic", num_epochs=a.epochs, save_frequency=1, save_models=False)
+        model_name="synthetic", num_epochs=a.epochs, save_frequency=1, ViT=a.ViT)
     trainer = Trainer(opt)
     trainer.epoch = 10 if a.boosted else 0
     distributed.attach(trainer)
