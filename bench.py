@@ -253,6 +253,11 @@ def main(argv=None):
     ap.add_argument("--no-fused-adam", action="store_true")
     ap.add_argument("--no-eager-ab", action="store_true",
                     help="skip timing the hot path / the whole step as eager PyTorch-ROCm ops (oracle) vs the fused kernels")
+    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole step (both HIP streams, MIOpen, the C-ABI launches, fused Adam) as one hipGraph: "
+                         "the ~1 200 launches of a step cost ~16 ms of host time, which a slow or busy host CPU turns into "
+                         "the bottleneck (measured: 480 vs 575 images/s on two boxes with identical GPU time).  auto = on for "
+                         "a single rank, falling back to the eager loop if capture fails; multi-rank runs are eager")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -288,17 +293,24 @@ def main(argv=None):
     torch.manual_seed(42)
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
-    opt = make_options(args.batch, local, args.config)
-    opt.fused_adam = not args.no_fused_adam
-    run_scales = list(opt.scales)
-    opt.scales = list(SCALES)      # networks + num_scales are built for 4 scales (trainer.py:44); the epoch>=10
-    trainer = Trainer(opt)         # curriculum then trains on scale 0 only (run_epoch, trainer.py:209-212)
-    trainer.opt.scales = run_scales
-    if args.channels_last:
-        for m in trainer.models.values():
-            m.to(memory_format=torch.channels_last)
-    trainer.set_train()
-    bdist.attach(trainer)
+    def build_trainer(step_graph):
+        torch.manual_seed(42)
+        opt = make_options(args.batch, local, args.config)
+        opt.fused_adam = not args.no_fused_adam
+        opt.step_graph = bool(step_graph)
+        run_scales = list(opt.scales)
+        opt.scales = list(SCALES)      # networks + num_scales are built for 4 scales (trainer.py:44); the epoch>=10
+        tr = Trainer(opt)              # curriculum then trains on scale 0 only (run_epoch, trainer.py:209-212)
+        tr.opt.scales = run_scales
+        if args.channels_last:
+            for m in tr.models.values():
+                m.to(memory_format=torch.channels_last)
+        tr.set_train()
+        bdist.attach(tr)
+        return tr, opt
+
+    want_graph = args.step_graph == "on" or (args.step_graph == "auto" and world == 1 and not args.no_fused_adam)
+    trainer, opt = build_trainer(want_graph)
     import random as _random
     draw = _random.Random(1234 + rank)
     if args.config in ("md2", "vit"):
@@ -322,10 +334,21 @@ def main(argv=None):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graph_note = None
+    if trainer.use_graph:
+        try:                                   # capture happens inside the first step of a batch signature
+            trainer.train_step(inputs)
+            torch.cuda.synchronize()
+        except Exception as e:                 # never lose the benchmark to the capture: fall back to the eager loop
+            if args.step_graph == "on":
+                raise
+            graph_note = "capture failed (%s: %s), eager loop used" % (type(e).__name__, str(e)[:120])
+            torch.cuda.synchronize()
+            trainer, opt = build_trainer(False)
     for _ in range(args.warmup):
         trainer.train_step(inputs)
     timer = ops.KernelTimer()
-    backend.timer = timer
+    backend.timer = None if trainer.use_graph else timer
     # per-step durations for the median: one event at every step boundary on the main stream (no host sync)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
@@ -337,6 +360,18 @@ def main(argv=None):
     sync_all()
     elapsed = time.perf_counter() - t0
     backend.timer = None
+    kernel_timing = "HIP events around each C-ABI launch inside the timed steps"
+    if trainer.use_graph:
+        # a replayed graph's nodes cannot be bracketed by events: the SAME kernels on the same inputs are timed over
+        # eager steps of the same trainer right after the timed region (rocprofv3 stats under profiles/ agree)
+        n_evt = max(5, min(args.steps, 20))
+        backend.timer = timer
+        for _ in range(n_evt):
+            trainer._eager_step(dict(inputs))
+        torch.cuda.synchronize()
+        backend.timer = None
+        kernel_timing = ("HIP events around each C-ABI launch over %d eager steps run right after the timed region "
+                         "(the timed region replays one hipGraph per step)" % n_evt)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2] if per_step else 0.0
     if world > 1:
@@ -400,7 +435,8 @@ def main(argv=None):
                                    "per-sample max offsets %s), ResNet-18, 640x192, per-GPU batch %d, %d scale(s)"
                                    % (args.config, ms, args.batch, S),
                        "global_batch": global_batch, "parallelism": "dp%d" % world},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
+            "step_graph": bool(trainer.use_graph) if graph_note is None else graph_note,
         }
         if world == 1 and not args.no_eager_ab and args.config == "md2":
             line["hot_path_ab"] = eager_hot_path_ab(trainer, inputs, opt)
