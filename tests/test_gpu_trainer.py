@@ -221,3 +221,32 @@ def test_predict_poses_modes_on_gpu_against_reference_vectors(name):
     from pose_checks import check_pose_case
     from baseboostdepth_amd import ops
     check_pose_case(name, ops.default_backend(), "cuda:0")
+
+
+def _run_bench_inline(capsys, argv):
+    import json
+    import bench
+    rc = bench.main(argv)
+    assert rc == 0
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_line_with_step_graph_and_fallback(capsys, monkeypatch):
+    """bench.py replays the step as one hipGraph by default; if capture fails it must fall back to the eager loop
+    (and say so) instead of losing the benchmark; `--step-graph off` is the plain eager loop."""
+    from baseboostdepth_amd.trainer import Trainer
+    argv = ["--batch", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-eager-ab"]
+    line = _run_bench_inline(capsys, argv)
+    assert line["step_graph"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["collective"] == "none"
+    assert set(line["kernels"]) == {"bbd_identity_loss_fwd", "bbd_warp_ssim_min_disp_fwd", "bbd_warp_ssim_min_disp_bwd"}
+    assert 0 < line["roofline"]["frac"] < 1 and line["ms_per_step_median"] > 0
+    off = _run_bench_inline(capsys, argv + ["--step-graph", "off"])
+    assert off["step_graph"] is False and "inside the timed steps" in off["kernel_timing"]
+
+    def broken(self, inputs):
+        raise RuntimeError("injected capture failure")
+    monkeypatch.setattr(Trainer, "_graph_step", broken)
+    fb = _run_bench_inline(capsys, argv)
+    assert isinstance(fb["step_graph"], str) and "capture failed" in fb["step_graph"] and fb["value"] > 0
