@@ -166,6 +166,7 @@ struct DispSrc {
   const float* disp[MAX_SCALES];   // per scale [B,1,h,w]; all NULL = depth-plane mode
   int h[MAX_SCALES], w[MAX_SCALES];
   float lo, span;                  // 1/max_depth, 1/min_depth - 1/max_depth
+  int grad_wrt_disp;               // backward hands back d loss / d (up-sampled disparity) instead of d loss / d depth
 };
 struct DepthSrc {
   const float* depth;              // [H,W] plane of this (scale, sample), or nullptr
@@ -206,7 +207,7 @@ __device__ __forceinline__ void load_depth(const DepthSrc& src, int H, int W, co
 }
 
 // Warp one source image into the staged region for one pose-table row.
-template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW>
+template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
@@ -236,6 +237,10 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
     for (int kk = 0; kk < BATCH; ++kk) {
       const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
       BbdSample sm;
+#if !defined(BBD_BWD_GUARDED)
+      if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+      else
+#endif
       bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
       bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
       clip[kk] = sm.clipx | (sm.clipy << 1);
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds<BBD_BWD2_WARP_BATCH>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
+    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
@@ -1229,7 +1234,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
 
-  if (dsrc.depth == nullptr) {
+  if (a.ds.grad_wrt_disp) {
     // disparity mode: hand back d loss / d (up-sampled disparity) = d loss / d depth * (-span * depth^2); the
     // bilinear adjoint onto the low-resolution map is bbd_disp_upsample_adjoint (one launch for all scales)
 #pragma unroll
@@ -1987,7 +1992,7 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
 static int fill_disp(const void* const* disp, const int32_t* disp_hw, double min_depth, double max_depth, int S, int H,
                      int W, DispSrc* ds) {
   for (int i = 0; i < MAX_SCALES; ++i) { ds->disp[i] = nullptr; ds->h[i] = H; ds->w[i] = W; }
-  ds->lo = 0.0f; ds->span = 0.0f;
+  ds->lo = 0.0f; ds->span = 0.0f; ds->grad_wrt_disp = 0;
   if (disp == nullptr) return 0;
   if (disp_hw == nullptr || S > MAX_SCALES || min_depth <= 0.0 || max_depth <= min_depth) return BBD_E_BADARG;
   for (int i = 0; i < S; ++i) {
@@ -1998,6 +2003,7 @@ static int fill_disp(const void* const* disp, const int32_t* disp_hw, double min
   // layers.py:18-20 evaluates these in Python doubles before they meet the fp32 tensor
   ds->lo = (float)(1.0 / max_depth);
   ds->span = (float)(1.0 / min_depth - 1.0 / max_depth);
+  ds->grad_wrt_disp = 1;
   return 0;
 }
 
@@ -2015,7 +2021,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.stamps = nullptr;
 #endif
   if (fill_frames(frames, &a.frames)) return BBD_E_BADARG;
-  if (fill_disp(depth ? nullptr : disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
+  if (fill_disp(disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.ident = ident; a.noise = noise;
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
   a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
@@ -2039,7 +2045,7 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.stamps = nullptr;
 #endif
   if (fill_frames(frames, &a.frames)) return BBD_E_BADARG;
-  if (fill_disp(depth ? nullptr : disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
+  if (fill_disp(disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.cand = cand; a.ncand = ncand; a.argmin = argmin;
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
@@ -2084,12 +2090,12 @@ int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, c
 }
 
 int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
-                               const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
-                               const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
-                               float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
-                               void* stream) {
+                               const int32_t* disp_hw, double min_depth, double max_depth, const float* depth,
+                               const float* proj, const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin,
+                               const float* gscale, float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W,
+                               int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
-  return launch_fused_bwd(frames, target, nullptr, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
+  return launch_fused_bwd(frames, target, depth, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
                           grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 

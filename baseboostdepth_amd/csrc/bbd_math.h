@@ -97,7 +97,20 @@ BBD_HD float bbd_div_const(float n, float d, float rd) {
   return n / d;
 }
 BBD_HD float bbd_rcp_approx(float d) { return bbd_rcp_refined(d); }   /* <= 1 ulp; backward only */
+/* The same refined-reciprocal sequences WITHOUT the exponent-window test: bit-identical to bbd_div2 /
+ * bbd_div_const whenever those take their fast path (every operand of moderate exponent, i.e. every pixel whose
+ * sampling coordinate is not astronomically large or exactly zero).  Used by the BACKWARD's warp recompute,
+ * which must select the same texels as the forward: where the forward fell back to the full IEEE sequence the
+ * coordinate is far outside the image or degenerate and clamps to the same border either way. */
+BBD_HD void bbd_div2_unguarded(float n0, float n1, float d, float* q0, float* q1) {
+  const float r = bbd_rcp_refined(d);
+  *q0 = bbd_div_with(n0, d, r);
+  *q1 = bbd_div_with(n1, d, r);
+}
+BBD_HD float bbd_div_const_unguarded(float n, float d, float rd) { return bbd_div_with(n, d, rd); }
 #else
+BBD_HD void bbd_div2_unguarded(float n0, float n1, float d, float* q0, float* q1) { *q0 = n0 / d; *q1 = n1 / d; }
+BBD_HD float bbd_div_const_unguarded(float n, float d, float rd) { (void)rd; return n / d; }
 BBD_HD float bbd_div(float n, float d) { return n / d; }
 BBD_HD void bbd_div2(float n0, float n1, float d, float* q0, float* q1) { *q0 = n0 / d; *q1 = n1 / d; }
 BBD_HD float bbd_div_const(float n, float d, float rd) { (void)rd; return n / d; }
@@ -184,6 +197,35 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const Bb
   o->clipx = !(ix > 0.0f && ix < wm1);
   o->clipy = !(iy > 0.0f && iy < hm1);
   ix = ix > 0.0f ? ix : 0.0f;   /* max(ix, 0): NaN -> 0 like std::max(NaN,0) argument order */
+  iy = iy > 0.0f ? iy : 0.0f;
+  o->ix = ix < wm1 ? ix : wm1;
+  o->iy = iy < hm1 ? iy : hm1;
+}
+
+/* bbd_project for the backward's warp recompute: the same operation sequence with the unguarded divisions. */
+BBD_HD void bbd_project_bwd(const float* proj, int xx, int yy, float depth, const BbdDims& dm, BbdSample* o) {
+  const float* P = proj;
+  const float* iK = proj + 12;
+  const float fx = (float)xx, fy = (float)yy;
+  o->cx = bbd_dot3_hom(iK, fx, fy);
+  o->cy = bbd_dot3_hom(iK + 3, fx, fy);
+  o->cz = bbd_dot3_hom(iK + 6, fx, fy);
+  o->X = depth * o->cx;
+  o->Y = depth * o->cy;
+  o->Z = depth * o->cz;
+  const float qx = bbd_dot4_hom(P, o->X, o->Y, o->Z);
+  const float qy = bbd_dot4_hom(P + 4, o->X, o->Y, o->Z);
+  const float qz = bbd_dot4_hom(P + 8, o->X, o->Y, o->Z);
+  o->zi = qz + BBD_EPS;
+  bbd_div2_unguarded(qx, qy, o->zi, &o->u, &o->v);
+  const float wm1 = dm.wm1, hm1 = dm.hm1;
+  const float gx = (bbd_div_const_unguarded(o->u, wm1, dm.rw) - 0.5f) * 2.0f;
+  const float gy = (bbd_div_const_unguarded(o->v, hm1, dm.rh) - 0.5f) * 2.0f;
+  float ix = ((gx + 1.0f) / 2.0f) * wm1;
+  float iy = ((gy + 1.0f) / 2.0f) * hm1;
+  o->clipx = !(ix > 0.0f && ix < wm1);
+  o->clipy = !(iy > 0.0f && iy < hm1);
+  ix = ix > 0.0f ? ix : 0.0f;
   iy = iy > 0.0f ? iy : 0.0f;
   o->ix = ix < wm1 ? ix : wm1;
   o->iy = iy < hm1 ? iy : hm1;

@@ -363,6 +363,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
                     ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), S, B, plan.NP,
                     H, W, int(no_ssim))
         ctx.save_for_backward(proj, target, argmin, ptab, *disps)
+        ctx.depth = depth         # by-product of the forward (or None): the backward reads it instead of re-deriving it
         ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, float(min_depth), float(max_depth))
         ctx.mark_non_differentiable(min_loss, argmin)
         if materialize:
@@ -385,7 +386,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         ntb = backend.num_tiles_bwd(H, W)
         gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
         backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
-                    ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
+                    ptr(ctx.depth), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
                     S, B, plan.NP, H, W, no_ssim)
         # a scale at full resolution: grad_up IS its disparity gradient; the reduced ones share one adjoint launch
         grads, small, small_g, small_up = [None] * S, [], [], []
