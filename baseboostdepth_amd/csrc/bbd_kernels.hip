@@ -348,6 +348,7 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
     float x[3][8], y[3][8];
     load_window<LS>(sx[ch], ly, lx0, x);
     load_window<LS>(sy[ch], ly, lx0, y);
+    float nn[PPT], dd[PPT], qq[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       float s = 0.0f, ss = 0.0f, sxy = 0.0f;
@@ -360,13 +361,17 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
           ss += v * v;
           sxy += v * y[r][j + c];
         }
-#if defined(BBD_ABLATE_SSIM)          // timing experiment only
-      ssim[j][ch] = s + ss + sxy;
-#else
-      ssim[j][ch] = no_ssim ? 0.0f : bbd_ssim(s, ss, sxy, mu_y[ch][j], sg_y[ch][j]);
-#endif
+      bbd_ssim_nd(s, ss, sxy, mu_y[ch][j], sg_y[ch][j], &nn[j], &dd[j]);
       l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
     }
+#if defined(BBD_SSIM_DIV_X4)     // four divisions behind one validity branch: measured SLOWER (0.246 vs 0.224 ms forward:
+    bbd_div_x4(nn, dd, qq);      // 14 spilled registers instead of 4) - kept for the record, profiles/r02/guard_variants.txt
+#else
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) qq[j] = bbd_div(nn[j], dd[j]);
+#endif
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) ssim[j][ch] = no_ssim ? 0.0f : bbd_ssim_from_ratio(qq[j]);
   }
 #pragma unroll
   for (int j = 0; j < PPT; ++j) out[j] = bbd_combine(ssim[j], l1[j], no_ssim);

@@ -186,11 +186,29 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const Bb
   const float qy = bbd_dot4_hom(P + 4, o->X, o->Y, o->Z);
   const float qz = bbd_dot4_hom(P + 8, o->X, o->Y, o->Z);
   o->zi = qz + BBD_EPS;                       /* layers.py:188 */
+  const float wm1 = dm.wm1, hm1 = dm.hm1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BBD_PROJECT_GUARD_EACH)
+  /* All four IEEE divisions through the refined-reciprocal sequence first, ONE validity test for the lot, and the
+   * full IEEE sequence only for lanes outside the exponent window (identical results: both forms are correctly
+   * rounded where the fast one is valid) - one rarely-taken branch per pixel instead of three with inlined
+   * v_div_scale/fmas/fixup fallbacks. */
+  bbd_div2_unguarded(qx, qy, o->zi, &o->u, &o->v);
+  float nu = bbd_div_const_unguarded(o->u, wm1, dm.rw), nv = bbd_div_const_unguarded(o->v, hm1, dm.rh);
+  const int ok = bbd_exp_ok3(qx, qy, o->zi) & (bbd_exp_ok(o->u) | (o->u == 0.0f)) & (bbd_exp_ok(o->v) | (o->v == 0.0f));
+  if (!ok) {
+    o->u = qx / o->zi;
+    o->v = qy / o->zi;
+    nu = o->u / wm1;
+    nv = o->v / hm1;
+  }
+  const float gx = (nu - 0.5f) * 2.0f;
+  const float gy = (nv - 0.5f) * 2.0f;
+#else
   bbd_div2(qx, qy, o->zi, &o->u, &o->v);
   /* layers.py:191-193 normalise, then ATen grid_sampler unnormalise (align_corners=True) */
-  const float wm1 = dm.wm1, hm1 = dm.hm1;
   const float gx = (bbd_div_const(o->u, wm1, dm.rw) - 0.5f) * 2.0f;
   const float gy = (bbd_div_const(o->v, hm1, dm.rh) - 0.5f) * 2.0f;
+#endif
   float ix = ((gx + 1.0f) / 2.0f) * wm1;
   float iy = ((gy + 1.0f) / 2.0f) * hm1;
   /* border padding: clip_coordinates; gradient is zeroed when the clamp is active */
@@ -302,14 +320,36 @@ BBD_HD void bbd_ystats(float sy, float syy, float* mu_y, float* sig_y) {
   *sig_y = bbd_div9(syy) - (*mu_y) * (*mu_y);
 }
 
-BBD_HD float bbd_ssim(float sx, float sxx, float sxy, float mu_y, float sig_y) {
+/* numerator and denominator of the SSIM ratio (layers.py:241-246), then the clamp of (1 - n/d)/2 */
+BBD_HD void bbd_ssim_nd(float sx, float sxx, float sxy, float mu_y, float sig_y, float* n, float* d) {
   const float mu_x = bbd_div9(sx);
   const float sig_x = bbd_div9(sxx) - mu_x * mu_x;
   const float sig_xy = bbd_div9(sxy) - mu_x * mu_y;
-  const float n = (2.0f * mu_x * mu_y + BBD_C1) * (2.0f * sig_xy + BBD_C2);
-  const float d = (mu_x * mu_x + mu_y * mu_y + BBD_C1) * (sig_x + sig_y + BBD_C2);
-  const float v = (1.0f - bbd_div(n, d)) / 2.0f;
+  *n = (2.0f * mu_x * mu_y + BBD_C1) * (2.0f * sig_xy + BBD_C2);
+  *d = (mu_x * mu_x + mu_y * mu_y + BBD_C1) * (sig_x + sig_y + BBD_C2);
+}
+BBD_HD float bbd_ssim_from_ratio(float q) {
+  const float v = (1.0f - q) / 2.0f;
   return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);   /* NaN stays NaN like torch.clamp */
+}
+BBD_HD float bbd_ssim(float sx, float sxx, float sxy, float mu_y, float sig_y) {
+  float n, d;
+  bbd_ssim_nd(sx, sxx, sxy, mu_y, sig_y, &n, &d);
+  return bbd_ssim_from_ratio(bbd_div(n, d));
+}
+/* four IEEE quotients n[j]/d[j] with ONE validity branch (see bbd_project) */
+BBD_HD void bbd_div_x4(const float n[4], const float d[4], float q[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int ok = 1;
+  for (int j = 0; j < 4; ++j) {
+    q[j] = bbd_div_with(n[j], d[j], bbd_rcp_refined(d[j]));
+    ok &= bbd_exp_ok3(n[j], d[j], d[j]);
+  }
+  if (!ok)
+    for (int j = 0; j < 4; ++j) q[j] = n[j] / d[j];
+#else
+  for (int j = 0; j < 4; ++j) q[j] = n[j] / d[j];
+#endif
 }
 
 /* 0.85 * mean_c(ssim) + 0.15 * mean_c(|y - x|)   (trainer.py:477-486) */
