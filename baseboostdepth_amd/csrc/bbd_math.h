@@ -377,12 +377,14 @@ BBD_HD void bbd_ssim_grad(float sx, float sxx, float sxy, float mu_y, float sig_
   const float n1 = 2.0f * mu_x * mu_y + BBD_C1, n2 = 2.0f * sig_xy + BBD_C2;
   const float d1 = mu_x * mu_x + mu_y * mu_y + BBD_C1, d2 = sig_x + sig_y + BBD_C2;
   const float n = n1 * n2, d = d1 * d2;
-  const float v = (1.0f - bbd_div(n, d)) / 2.0f;
+  const float rd = bbd_rcp_approx(d);
+  /* gradient arithmetic: the <= 1 ulp reciprocal is enough here (the forward's IEEE division fixes the VALUE of the
+   * loss; this only decides on which side of the clamp a pixel sits, and differs from it on a set of measure zero) */
+  const float v = (1.0f - n * rd) / 2.0f;
   if (!(v >= 0.0f && v <= 1.0f)) {   /* clamp passes gradient on [0,1] only */
     *A = 0.0f; *B = 0.0f; *C = 0.0f;
     return;
   }
-  const float rd = bbd_rcp_approx(d);
   const float dvdn = -0.5f * rd;
   const float dvdd = 0.5f * n * rd * rd;
   *A = dvdn * (2.0f * mu_y * (n2 - n1)) + dvdd * (2.0f * mu_x * (d2 - d1));
