@@ -14,8 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, "bbd_kernels.hip"), os.path.join(HERE, "bbd_eval.hip"),
         os.path.join(HERE, "bbd_image.hip"), os.path.join(HERE, "bbd_nn.hip"), os.path.join(HERE, "bbd_vit.hip")]
 OUT = os.path.join(HERE, "libbbd_hip.so")
-DEPS = SRCS + [os.path.join(HERE, "bbd_math.h"), os.path.join(HERE, "bbd_image_math.h"), os.path.join(HERE, "..", "..", "include", "bbd_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17"]
+DEPS = SRCS + [os.path.abspath(__file__), os.path.join(HERE, "bbd_math.h"), os.path.join(HERE, "bbd_image_math.h"), os.path.join(HERE, "..", "..", "include", "bbd_hip.h")]
+# -fno-slp-vectorize: hipcc otherwise SLP-packs neighbouring scalar fp32 adds / multiplies into v_pk_add/mul_f32 and
+# pays for it in v_mov register shuffles (129 moves in the forward's SSIM phase): measured forward 0.222 -> 0.208 ms,
+# identity 0.0365 -> 0.0340 ms, backward 0.348 -> 0.343 ms (profiles/r02/slp_variants.txt).  Same operations, same bits.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
+         "-std=c++17"]
 
 
 def build(force=False, verbose=False):

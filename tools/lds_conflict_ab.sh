@@ -11,7 +11,7 @@ SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hi
 for spec in "whole:" "plain:-DBBD_WINDOW_PLAIN" ${BBD_EXTRA_SPECS:-}; do
   name="${spec%%:*}"; flags="${spec#*:}"
   lib=/tmp/bbdvar/libbbd_lds_$name.so
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -std=c++17 -fPIC -shared $flags -o $lib $SRC 2>&1 | grep -E "error"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math ${BBD_BASE_FLAGS--fno-slp-vectorize} -std=c++17 -fPIC -shared $flags -o $lib $SRC 2>&1 | grep -E "error"
   BBD_HIP_LIB=$lib rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS \
       --kernel-trace --output-format csv -d "$OUT" -o $name -- python3 tools/kernel_bench.py --iters 3 --warmup 1 > "$OUT/$name.log" 2>&1
 done
