@@ -999,10 +999,11 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 }
 
 #ifndef BBD_BWD2_WGS
-#define BBD_BWD2_WGS 3   // waves per SIMD (HIP: second __launch_bounds__ argument).  3 = up to 168 VGPRs, no spills.
-                         // Measured: 3, 4 and 5 waves per SIMD run within 1 % of each other (the kernel is issue-bound,
-                         // profiles/r02/bwd_variants_narrow_tile.txt), but at 4 (128 VGPRs) hipcc spills 15 registers and
-                         // the scratch traffic doubles the launch's HBM bytes (PMC: 549 MB vs 265 MB algorithmic)
+#define BBD_BWD2_WGS 4   // waves per SIMD (HIP: second __launch_bounds__ argument): 128 VGPRs.
+                         // History (profiles/r02): with the heavier mid-round kernel 3, 4 and 5 waves per SIMD ran within 1 %
+                         // (bwd_variants_narrow_tile.txt) and 4 cost 15 spilled registers (scratch doubled the launch's HBM
+                         // bytes); after the instruction diet (unguarded recompute, reduce-scatter, no SLP packing) the
+                         // kernel fits 128 VGPRs and 4 waves per SIMD are 11 % faster than 3 (occupancy_after_diet.txt)
 #endif
 #ifndef BBD_BWD2_WARP_BATCH
 #define BBD_BWD2_WARP_BATCH 3
@@ -1036,8 +1037,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   BBD_STAMP(0);
   // setup: issue every global load first, then the LDS work that does not depend on them
   constexpr int NP_CELLS = (CH * CW2 + NT2 - 1) / NT2;
+  static_assert(NP_CELLS <= 4, "arg-min ids of the loss pixels are packed four to a word");
   int pcell[NP_CELLS];
-  unsigned parg[NP_CELLS];
+  unsigned pargw = 0u;                 // byte k = arg-min id of loss pixel k (255 = outside the image)
 #pragma unroll
   for (int k = 0; k < NP_CELLS; ++k) {
     const int i = k * NT2 + (int)threadIdx.x;
@@ -1045,8 +1047,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
     const bool in = i < CH * CW2 && py >= 0 && py < H && px >= 0 && px < W;
     pcell[k] = r * CS2 + c;
-    parg[k] = in ? (unsigned)am[py * W + px] : 255u;
+    pargw |= (in ? (unsigned)am[py * W + px] : 255u) << (8 * k);
   }
+#define BBD_PARG(k) ((pargw >> (8 * (k))) & 0xffu)
   typedef Cells<BH, BW2, BS2, 2, NT2> CellsB;
   CellsB cl;
   cl.init(H, W, tc.tx0, tc.ty0);
@@ -1068,9 +1071,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
   const bool q_row_ok = qy < H;
   const bool q_vec_ok = (qx0 + PPT2 <= W) && ((W & 1) == 0);
-  unsigned qarg[PPT2];
+  unsigned qargw = 0u;                 // byte j = arg-min id of own pixel j
 #pragma unroll
-  for (int j = 0; j < PPT2; ++j) qarg[j] = (q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u;
+  for (int j = 0; j < PPT2; ++j) qargw |= ((q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u) << (8 * j);
   const bool interior = tc.tx0 >= 2 && tc.tx0 + TW2 + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
   float gdepth[PPT2] = {0.0f, 0.0f};
   float qdepth[PPT2] = {1.0f, 1.0f};
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     unsigned mine = 0u;
 #pragma unroll
     for (int k = 0; k < NP_CELLS; ++k)
-      if (parg[k] != 255u) mine |= 1u << parg[k];
+      if (BBD_PARG(k) != 255u) mine |= 1u << BBD_PARG(k);
     if (mine) atomicOr(&s_present, mine);
   }
 #pragma unroll
@@ -1119,11 +1122,11 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     if (!a.no_ssim) {
 #pragma unroll
       for (int k = 0; k < NP_CELLS; ++k) {
-        if ((int)parg[k] == prev) {
+        if ((int)BBD_PARG(k) == prev) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
         }
-        if (parg[k] == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
+        if (BBD_PARG(k) == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
       }
     }
     prev = c;
@@ -1214,7 +1217,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       for (int j = 0; j < PPT2; ++j) {
         const float xq = xqv[j], yq = yqv[j];
         float acc = (S3[0][j] + xq * S3[1][j] + yq * S3[2][j]) * (1.0f / 9.0f);
-        if (qarg[j] == (unsigned)c) {
+        if (((qargw >> (8 * j)) & 0xffu) == (unsigned)c) {
           const float df = xq - yq;
           acc += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
         }
@@ -1293,6 +1296,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
   BBD_STAMP(20);
+#undef BBD_PARG
 }
 
 // ------------------------------------------------------------------------------------------
