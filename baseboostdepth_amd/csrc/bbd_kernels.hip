@@ -242,11 +242,21 @@ __device__ __forceinline__ void load_depth(const DepthSrc& src, int H, int W, co
 }
 
 // Warp one source image into the staged region for one pose-table row.
-template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false>
+// Sampling coordinates handed from the forward to the backward (one float2 per pixel and warp candidate): the
+// clamped (ix, iy) of bbd_project, with the "border clamp active" flags in the sign bits (ix, iy >= 0 otherwise).
+__device__ __forceinline__ float2 pack_coords(const BbdSample& sm) {
+  return make_float2(__uint_as_float(__float_as_uint(sm.ix) | ((unsigned)sm.clipx << 31)),
+                     __uint_as_float(__float_as_uint(sm.iy) | ((unsigned)sm.clipy << 31)));
+}
+
+// COORDS: 0 = project every cell (depth d, pose row); 1 = project and also store the coordinates of owned cells to
+// `coords` (forward, when a backward will follow); 2 = take the coordinates from `pre` (backward: no projection).
+template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int COORDS = 0>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
-                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr) {
+                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
+                                              float2* __restrict__ coords = nullptr, const float2* pre = nullptr) {
   // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
@@ -272,11 +282,20 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
     for (int kk = 0; kk < BATCH; ++kk) {
       const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
       BbdSample sm;
+      if (COORDS == 2) {
+        const unsigned bx = __float_as_uint(pre[k].x), by = __float_as_uint(pre[k].y);
+        sm.ix = __uint_as_float(bx & 0x7fffffffu);
+        sm.iy = __uint_as_float(by & 0x7fffffffu);
+        sm.clipx = (int)(bx >> 31);
+        sm.clipy = (int)(by >> 31);
+      } else {
 #if !defined(BBD_BWD_GUARDED)
-      if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
-      else
+        if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+        else
 #endif
-      bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+        bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+        if (COORDS == 1 && coords != nullptr && k0 + kk < CellsT::N && cl.own(k)) coords[cl.pix(k, dm.W)] = pack_coords(sm);
+      }
       bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
       clip[kk] = sm.clipx | (sm.clipy << 1);
     }
@@ -490,6 +509,7 @@ struct FwdArgs {
   float* partial;
   float* warped;
   float* depth_out;     // optional [S,B,H,W]: the depth this launch used (outputs[("depth",0,s)] of the reference)
+  float2* coords;       // optional [S,NP,H,W]: clamped sampling coordinates + clamp flags, for the backward
   DispSrc ds;
   BbdDims dm;
   int S, B, NP, ntiles, no_ssim;
@@ -566,7 +586,9 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
       float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
       BBD_STAMP(4 + 4 * (c & 3));
-      warp_into_lds<BBD_WARP_BATCH>(src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
+      float2* cout = a.coords ? a.coords + ((size_t)s * a.NP + cd.pose) * hw : nullptr;
+      warp_into_lds<BBD_WARP_BATCH, Cells<LH, LW, LS, 1>, FPLANE, TH * TW, false, 1>(
+          src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout, nullptr, cout);
       BBD_STAMP(5 + 4 * (c & 3));
       __syncthreads();
       BBD_STAMP(6 + 4 * (c & 3));
@@ -637,6 +659,7 @@ struct BwdArgs {
   const float* gscale;
   float* grad_depth;    // depth-plane mode: d loss / d depth; disparity mode: d loss / d up-sampled disparity
   float* grad_proj;
+  const float2* coords; // optional [S,NP,H,W] from the forward: the warp recompute then needs no projection
   DispSrc ds;
   BbdDims dm;
   int S, B, NP, ntiles, no_ssim;
@@ -1008,6 +1031,7 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 #ifndef BBD_BWD2_WARP_BATCH
 #define BBD_BWD2_WARP_BATCH 3
 #endif
+template <bool HANDOVER>     // true: a.coords holds the forward's sampling coordinates (no projection, no halo depth)
 __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float s_ybuf[3 * BPLANE2 + 8];
   __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE2 + 8];
@@ -1065,7 +1089,12 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
   float dcell[CellsB::N];
-  load_depth(dsrc, H, W, cl, dcell);
+  if (!HANDOVER) {
+    load_depth(dsrc, H, W, cl, dcell);       // depth of the halo'd cells is only needed to project them
+  } else {
+#pragma unroll
+    for (int q = 0; q < CellsB::N; ++q) dcell[q] = 1.0f;
+  }
 
   const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
   const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
@@ -1131,7 +1160,17 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
+    if (HANDOVER) {
+      // the forward's clamped sampling coordinates of the staged cells (coalesced 8-byte loads); no projection
+      float2 pre[CellsB::N];
+      const float2* cp = a.coords + ((size_t)s * a.NP + cd.pose) * hw;
+#pragma unroll
+      for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
+      warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
+                                                                            s_dv, nullptr, pre);
+    } else {
+      warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
+    }
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
@@ -2056,8 +2095,8 @@ static int fill_disp(const void* const* disp, const int32_t* disp_hw, double min
 static int launch_fused_fwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
                             const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                             const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
-                            float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out, int S, int B,
-                            int NP, int H, int W, int no_ssim, void* stream) {
+                            float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
+                            float* coords, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!target || (!depth && !disp) || !cand || !ncand || !min_loss || !argmin || !partial) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   FwdArgs a;
@@ -2070,7 +2109,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   if (fill_disp(disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.ident = ident; a.noise = noise;
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
-  a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
+  a.warped = warped; a.depth_out = depth_out; a.coords = reinterpret_cast<float2*>(coords); a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
@@ -2080,9 +2119,10 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
 static int launch_fused_bwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
                             const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                             const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
-                            float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
-                            void* stream) {
+                            const float* coords, float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W,
+                            int no_ssim, void* stream) {
   if (!target || (!depth && !disp) || !cand || !ncand || !argmin || !gscale || !grad_depth || !grad_proj) return BBD_E_BADARG;
+  if (coords && !depth) return BBD_E_BADARG;     // with hand-over coordinates the own-pixel depth comes from the planes
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   BwdArgs a;
 #ifdef BBD_STAMPS
@@ -2094,15 +2134,20 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   if (fill_disp(disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.cand = cand; a.ncand = ncand; a.argmin = argmin;
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
+  a.coords = reinterpret_cast<const float2*>(coords);
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
 #if defined(BBD_BWD_256)        // the round-1 form (4 waves, 4-pixel strips, depth planes only): A/B timing builds
-  if (!depth) return BBD_E_BADARG;
+  if (!depth || coords) return BBD_E_BADARG;
   hipLaunchKernelGGL(warp_ssim_min_bwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
 #else
-  hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (coords)
+    hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<false>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                       static_cast<hipStream_t>(stream), a);
 #endif
   return launch_status();
 }
@@ -2113,7 +2158,7 @@ int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const 
                           int H, int W, int no_ssim, void* stream) {
   if (!depth) return BBD_E_BADARG;
   return launch_fused_fwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, ident, noise, cand, ncand, min_loss,
-                          argmin, partial, warped, nullptr, S, B, NP, H, W, no_ssim, stream);
+                          argmin, partial, warped, nullptr, nullptr, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth, const float* proj,
@@ -2121,28 +2166,28 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
                           float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
                           void* stream) {
   if (!depth) return BBD_E_BADARG;
-  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, argmin, gscale,
+  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, argmin, gscale, nullptr,
                           grad_depth, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                                const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
-                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out, int S,
-                               int B, int NP, int H, int W, int no_ssim, void* stream) {
+                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
+                               float* coords_out, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
   return launch_fused_fwd(frames, target, nullptr, disp, disp_hw, min_depth, max_depth, proj, ident, noise, cand, ncand,
-                          min_loss, argmin, partial, warped, depth_out, S, B, NP, H, W, no_ssim, stream);
+                          min_loss, argmin, partial, warped, depth_out, coords_out, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* depth,
-                               const float* proj, const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin,
-                               const float* gscale, float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W,
-                               int no_ssim, void* stream) {
+                               const float* coords, const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
+                               const uint8_t* argmin, const float* gscale, float* grad_up, float* grad_proj, int S, int B,
+                               int NP, int H, int W, int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
   return launch_fused_bwd(frames, target, depth, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
-                          grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
+                          coords, grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B,

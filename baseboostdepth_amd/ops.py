@@ -16,6 +16,8 @@ from ._lib import POSE_STRIDE, PROJ_STRIDE, MAX_FRAME_SLOTS, ptr
 from .plan import frame_slot
 
 
+# BBD_COORD_HANDOVER=0: the backward re-projects instead of taking the forward's sampling coordinates (A/B runs)
+HANDOVER = os.environ.get("BBD_COORD_HANDOVER", "1") != "0"
 # BBD_FUSED_NN=0 sends the encoder / decoder glue (pad, max-pool) back to the stock ATen kernels (A/B runs)
 FUSED_NN = os.environ.get("BBD_FUSED_NN", "1") != "0"
 
@@ -354,15 +356,21 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         partial = torch.empty(S, B, ntiles, device=dev, dtype=torch.float32)
         warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
         depth = torch.empty(S, B, H, W, device=dev, dtype=torch.float32) if want_depth else None
+        # a backward will follow: let the forward hand over every candidate's sampling coordinates (8 B per pixel
+        # and warp candidate) so that the backward's warp recompute needs no projection
+        need_bwd = torch.is_grad_enabled() and (proj.requires_grad or any(d.requires_grad for d in disps))
+        coords = (torch.empty(S, plan.NP, H, W, 2, device=dev, dtype=torch.float32)
+                  if (need_bwd and depth is not None and HANDOVER) else None)
         backend._check(proj, target, ident, noise, *disps, *frame_tensors.values())
         frames = frame_pointer_array(frame_tensors)
         ptab = torch.empty(plan.NP, PROJ_STRIDE, device=dev, dtype=torch.float32)
         backend.run("bbd_pose_expand", proj, ptr(proj), ptr(ptab), plan.NP)
         backend.run("bbd_warp_ssim_min_disp_fwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps),
                     float(min_depth), float(max_depth), ptr(ptab), ptr(ident), ptr(noise), ptr(tb["cand"]),
-                    ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), S, B, plan.NP,
-                    H, W, int(no_ssim))
+                    ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), ptr(coords), S, B,
+                    plan.NP, H, W, int(no_ssim))
         ctx.save_for_backward(proj, target, argmin, ptab, *disps)
+        ctx.coords = coords
         ctx.depth = depth         # by-product of the forward (or None): the backward reads it instead of re-deriving it
         ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, float(min_depth), float(max_depth))
         ctx.mark_non_differentiable(min_loss, argmin)
@@ -386,7 +394,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         ntb = backend.num_tiles_bwd(H, W)
         gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
         backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
-                    ptr(ctx.depth), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
+                    ptr(ctx.depth), ptr(ctx.coords), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
                     S, B, plan.NP, H, W, no_ssim)
         # a scale at full resolution: grad_up IS its disparity gradient; the reduced ones share one adjoint launch
         grads, small, small_g, small_up = [None] * S, [], [], []
