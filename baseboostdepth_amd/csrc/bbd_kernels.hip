@@ -1136,6 +1136,10 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 
   const int nc = a.ncand[b];
   int prev = -1;
+#if defined(BBD_BWD2_PREFETCH)
+  float2 pre[CellsB::N];
+  int pre_c = -1;
+#endif
   for (int c = 0; c < nc; ++c) {
     const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
     if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
@@ -1162,12 +1166,32 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     BBD_STAMP(4 + 8 * (c & 1));
     if (HANDOVER) {
       // the forward's clamped sampling coordinates of the staged cells (coalesced 8-byte loads); no projection
+#if defined(BBD_BWD2_PREFETCH)
+      if (pre_c != c) {
+        const float2* cp = a.coords + ((size_t)s * a.NP + cd.pose) * hw;
+#pragma unroll
+        for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
+      }
+      warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
+                                                                            s_dv, nullptr, pre);
+      for (int n = c + 1; n < nc; ++n) {        // next candidate to be processed: its coordinates travel meanwhile
+        const bbd_cand_t nd = a.cand[b * BBD_MAX_CAND + n];
+        if ((nd.kind & KIND_MASK) == BBD_KIND_WARP && ((present >> n) & 1u)) {
+          const float2* cp = a.coords + ((size_t)s * a.NP + nd.pose) * hw;
+#pragma unroll
+          for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
+          pre_c = n;
+          break;
+        }
+      }
+#else
       float2 pre[CellsB::N];
       const float2* cp = a.coords + ((size_t)s * a.NP + cd.pose) * hw;
 #pragma unroll
       for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
       warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
                                                                             s_dv, nullptr, pre);
+#endif
     } else {
       warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
     }

@@ -91,24 +91,27 @@ def main():
     def k_ident():
         ops.identity_losses(plan, frame_tensors, target, False, be)
 
-    def k_fwd():
-        return ops.fused_reprojection_min(depth, table, target, ident, noise, plan, frame_tensors, False, False, be)
-
-    d2 = depth.clone().requires_grad_(True)
+    # the training path: disparity-mode launches (low-resolution disparities in, depth + coordinates by-products)
+    dd = [disp[s].detach().clone().requires_grad_(True) for s in scales]
     t2 = table.clone().requires_grad_(True)
-    ls, _, _, _ = ops.fused_reprojection_min(d2, t2, target, ident, noise, plan, frame_tensors, False, False, be)
+
+    def k_fwd():
+        return ops.fused_reprojection_min_disp(dd, t2, target, ident, noise, plan, frame_tensors, 0.1, 100.0, False, False,
+                                               True, be)
+
+    ls = k_fwd()[0]
     gsum = torch.full_like(ls, 1.0 / (B * H * W))
 
     def k_bwd():
-        torch.autograd.grad(ls, [d2, t2], gsum, retain_graph=True)
+        torch.autograd.grad(ls, dd + [t2], gsum, retain_graph=True)
 
     res = {"config": args.config, "batch": B, "scales": scales, "NP": plan.NP, "NI": plan.NI,
            "cands_per_sample": [len(n) for n in plan.cand_names]}
     # HIP events directly around each C-ABI launch (python overhead excluded)
     timer = ops.KernelTimer()
     for name, fn, nbytes, key in (("identity", k_ident, ib, "bbd_identity_loss_fwd"),
-                                  ("fwd", k_fwd, fb, "bbd_warp_ssim_min_fwd"),
-                                  ("bwd", k_bwd, bb, "bbd_warp_ssim_min_bwd")):
+                                  ("fwd", k_fwd, fb, "bbd_warp_ssim_min_disp_fwd"),
+                                  ("bwd", k_bwd, bb, "bbd_warp_ssim_min_disp_bwd")):
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize()
