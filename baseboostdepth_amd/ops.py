@@ -16,8 +16,10 @@ from ._lib import POSE_STRIDE, PROJ_STRIDE, MAX_FRAME_SLOTS, ptr
 from .plan import frame_slot
 
 
-# BBD_COORD_HANDOVER=0: the backward re-projects instead of taking the forward's sampling coordinates (A/B runs)
-HANDOVER = os.environ.get("BBD_COORD_HANDOVER", "1") != "0"
+# BBD_COORD_HANDOVER=1: the forward hands every warp candidate's clamped sampling coordinates to the backward
+# (8 B per pixel and candidate), whose warp recompute then skips the projection.  Measured neutral (backward -1..2 %,
+# forward +2 %: the dependent coordinate load costs what the arithmetic saved - profiles/r02/handover_ab.txt), so OFF.
+HANDOVER = os.environ.get("BBD_COORD_HANDOVER", "0") == "1"
 # BBD_FUSED_NN=0 sends the encoder / decoder glue (pad, max-pool) back to the stock ATen kernels (A/B runs)
 FUSED_NN = os.environ.get("BBD_FUSED_NN", "1") != "0"
 
