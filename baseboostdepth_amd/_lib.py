@@ -30,6 +30,7 @@ SIGNATURES = {
     "bbd_tile_w": [],
     "bbd_tile_h": [],
     "bbd_num_tiles": [_i, _i],
+    "bbd_num_tiles_fwd": [_i, _i],
     "bbd_num_tiles_bwd": [_i, _i],
     "bbd_pose_expand": [_p, _p, _i, _p],
     "bbd_identity_loss_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
@@ -114,6 +115,9 @@ class HipLibrary:
 
     def num_tiles(self, H, W):
         return self._dll.bbd_num_tiles(H, W)
+
+    def num_tiles_fwd(self, H, W):
+        return self._dll.bbd_num_tiles_fwd(H, W)
 
     def num_tiles_bwd(self, H, W):
         return self._dll.bbd_num_tiles_bwd(H, W)

@@ -1363,6 +1363,176 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused forward, narrow-tile form: 32x16-pixel tile, 256 threads, a 2-pixel strip per thread - the backward's
+// geometry.  Per-thread state halves (3 staged cells, 2-pixel windows, 12 target statistics instead of 24), so the
+// kernel fits 128 VGPRs (4 waves per SIMD instead of 3) and every thread's gathers of a candidate are in flight
+// together (one batch instead of two).  Same per-pixel arithmetic, same bits; only the per-tile partial sums of the
+// scalar loss are grouped differently (240 tiles per image instead of 120).
+// ------------------------------------------------------------------------------------------
+constexpr int LS2 = TW2 + 4;          // 36: row stride of the staged (TH+2) x (TW2+2) regions
+constexpr int LW2 = TW2 + 2;
+constexpr int FPLANE2 = LH * LS2;
+
+__device__ __forceinline__ void strip_ystats2(const float (*sy)[FPLANE2], int ly, int lx0, float mu_y[3][PPT2],
+                                              float sg_y[3][PPT2]) {
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float y[3][4];
+    load_window4<LS2>(sy[ch], ly, lx0, y);
+#pragma unroll
+    for (int j = 0; j < PPT2; ++j) {
+      float sm = 0.0f, ss = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = y[r][j + c];
+          sm += v;
+          ss += v * v;
+        }
+      bbd_ystats(sm, ss, &mu_y[ch][j], &sg_y[ch][j]);
+    }
+  }
+}
+
+__device__ __forceinline__ void strip_loss2(const float (*sx)[FPLANE2], const float (*sy)[FPLANE2], int ly, int lx0,
+                                            const float mu_y[3][PPT2], const float sg_y[3][PPT2], int no_ssim,
+                                            float out[PPT2]) {
+  float ssim[PPT2][3], l1[PPT2][3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float x[3][4], y[3][4];
+    load_window4<LS2>(sx[ch], ly, lx0, x);
+    load_window4<LS2>(sy[ch], ly, lx0, y);
+#pragma unroll
+    for (int j = 0; j < PPT2; ++j) {
+      float sm = 0.0f, ss = 0.0f, sxy = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = x[r][j + c];
+          sm += v;
+          ss += v * v;
+          sxy += v * y[r][j + c];
+        }
+      ssim[j][ch] = no_ssim ? 0.0f : bbd_ssim(sm, ss, sxy, mu_y[ch][j], sg_y[ch][j]);
+      l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PPT2; ++j) out[j] = bbd_combine(ssim[j], l1[j], no_ssim);
+}
+
+#ifndef BBD_FWD2_WAVES
+#define BBD_FWD2_WAVES 4
+#endif
+__global__ __launch_bounds__(NT2, BBD_FWD2_WAVES) void warp_ssim_min_fwd2_kernel(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE2];
+  __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE2];     // double-buffered: one barrier per candidate
+  __shared__ float s_red[4];
+  int buf = 0;
+  const BbdDims dm = a.dm;
+  const int H = dm.H, W = dm.W, hw = H * W;
+  int bid = blockIdx.x;
+  const int b = bid / (a.S * a.ntiles);
+  bid -= b * a.S * a.ntiles;
+  const int s = bid / a.ntiles;
+  const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
+  const size_t img = (size_t)3 * hw;
+  const size_t sb = (size_t)s * a.B + b;
+
+  BBD_STAMP(0);
+  typedef Cells<LH, LW2, LS2, 1, NT2> CellsF;
+  CellsF cl;
+  cl.init(H, W, tc.tx0, tc.ty0);
+  stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
+  float dcell[CellsF::N];
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  load_depth(dsrc, H, W, cl, dcell);
+  if (a.depth_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < CellsF::N; ++k)
+      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
+  }
+  BBD_STAMP(1);
+  __syncthreads();
+  BBD_STAMP(2);
+  const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
+  const int yy = tc.ty0 + ly, xx = tc.tx0 + lx0;
+  const bool row_ok = yy < H;
+  const bool vec_ok = (xx + PPT2 <= W) && ((W & 1) == 0);
+  const int pix = yy * W + xx;
+
+  float mu_y[3][PPT2], sg_y[3][PPT2];
+  strip_ystats2(s_y, ly, lx0, mu_y, sg_y);
+  float best[PPT2] = {INFINITY, INFINITY};
+  int arg[PPT2] = {0, 0};
+  BBD_STAMP(3);
+
+  const int nc = a.ncand[b];
+  for (int c = 0; c < nc; ++c) {
+    const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
+    float loss[PPT2] = {0.0f, 0.0f};
+    if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
+      const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
+      float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
+      float2* cout = a.coords ? a.coords + ((size_t)s * a.NP + cd.pose) * hw : nullptr;
+      BBD_STAMP(4 + 4 * (c & 3));
+      warp_into_lds<CellsF::N, CellsF, FPLANE2, TH * TW2, false, 1>(src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE,
+                                                                    dm, hw, cl, s_xx[buf], wout, nullptr, cout);
+      BBD_STAMP(5 + 4 * (c & 3));
+      __syncthreads();
+      BBD_STAMP(6 + 4 * (c & 3));
+      strip_loss2(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+      BBD_STAMP(7 + 4 * (c & 3));
+      buf ^= 1;
+    } else if (row_ok) {
+      const float* ip = a.ident + (size_t)cd.row * hw + pix;
+      const float* np = a.noise ? a.noise + (size_t)b * hw + pix : nullptr;
+      if (vec_ok) {
+        const float2 t = *reinterpret_cast<const float2*>(ip);
+        loss[0] = t.x; loss[1] = t.y;
+        if (np) {
+          const float2 z = *reinterpret_cast<const float2*>(np);
+          loss[0] += z.x; loss[1] += z.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PPT2; ++j)
+          if (xx + j < W) loss[j] = ip[j] + (np ? np[j] : 0.0f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PPT2; ++j) bbd_min_update(loss[j], c, &best[j], &arg[j]);
+  }
+
+  float tsum = 0.0f;
+  if (row_ok) {
+    float* mo = a.min_loss + sb * hw + pix;
+    uint8_t* ao = a.argmin + sb * hw + pix;
+    if (vec_ok) {
+      *reinterpret_cast<float2*>(mo) = make_float2(best[0], best[1]);
+      *reinterpret_cast<uint16_t*>(ao) = (uint16_t)((unsigned)arg[0] | ((unsigned)arg[1] << 8));
+      tsum = best[0] + best[1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j)
+        if (xx + j < W) {
+          mo[j] = best[j];
+          ao[j] = (uint8_t)arg[j];
+          tsum += best[j];
+        }
+    }
+  }
+  const float wsum = wave_sum63(tsum);
+  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+  BBD_STAMP(20);
+}
+
+// ------------------------------------------------------------------------------------------
 // disp -> depth (bilinear upsample + reciprocal affine), forward and adjoint.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void disp_to_depth_fwd_kernel(const float* __restrict__ disp,
@@ -2078,6 +2248,13 @@ int bbd_abi_version(void) { return BBD_ABI_VERSION; }
 int bbd_tile_w(void) { return TW; }
 int bbd_tile_h(void) { return TH; }
 int bbd_num_tiles(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
+int bbd_num_tiles_fwd(int H, int W) {      /* tiles of the fused FORWARD launch: sizes partial [S, B, tiles] */
+#if defined(BBD_FWD_WIDE)
+  return bbd_num_tiles(H, W);
+#else
+  return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2);
+#endif
+}
 int bbd_num_tiles_bwd(int H, int W) {
 #if defined(BBD_BWD_256)
   return bbd_num_tiles(H, W);
@@ -2134,9 +2311,14 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.target = target; a.depth = depth; a.pose = proj; a.ident = ident; a.noise = noise;
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
   a.warped = warped; a.depth_out = depth_out; a.coords = reinterpret_cast<float2*>(coords); a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
-  a.ntiles = bbd_num_tiles(H, W);
+  a.ntiles = bbd_num_tiles_fwd(H, W);
+#if defined(BBD_FWD_WIDE)       // the round-1 form (64x16 tile, 4-pixel strips, 3 waves per SIMD): A/B timing builds
   hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
+#else
+  hipLaunchKernelGGL(warp_ssim_min_fwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                     static_cast<hipStream_t>(stream), a);
+#endif
   return launch_status();
 }
 

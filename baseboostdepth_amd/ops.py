@@ -66,6 +66,9 @@ class HipBackend:
     def num_tiles(self, H, W):
         return self.lib.num_tiles(H, W)
 
+    def num_tiles_fwd(self, H, W):
+        return self.lib.num_tiles_fwd(H, W)
+
     def num_tiles_bwd(self, H, W):
         return self.lib.num_tiles_bwd(H, W)
 
@@ -278,7 +281,7 @@ class _FusedReprojectionMin(torch.autograd.Function):
         S, B, H, W = depth.shape
         dev = depth.device
         tb = plan.tables(dev)
-        ntiles = backend.num_tiles(H, W)
+        ntiles = backend.num_tiles_fwd(H, W)
         depth, proj = depth.contiguous(), proj.contiguous()
         min_loss = torch.empty(S, B, H, W, device=dev, dtype=torch.float32)
         argmin = torch.empty(S, B, H, W, device=dev, dtype=torch.uint8)
@@ -351,7 +354,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         H, W = target.shape[-2:]
         dev = target.device
         tb = plan.tables(dev)
-        ntiles = backend.num_tiles(H, W)
+        ntiles = backend.num_tiles_fwd(H, W)
         proj = proj.contiguous()
         min_loss = torch.empty(S, B, H, W, device=dev, dtype=torch.float32)
         argmin = torch.empty(S, B, H, W, device=dev, dtype=torch.uint8)

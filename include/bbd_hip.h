@@ -66,7 +66,10 @@ int bbd_abi_version(void);
 int bbd_tile_w(void);
 int bbd_tile_h(void);
 int bbd_num_tiles(int H, int W);
-/* tiles of the BACKWARD launch (narrower tile): sizes grad_proj [S, NP, bbd_num_tiles_bwd(H,W), 12] */
+/* tiles of the fused FORWARD launch: sizes partial [S, B, bbd_num_tiles_fwd(H,W)]; bbd_num_tiles = the 64x16 tiling
+ * of the identity / SSIM-map kernels */
+int bbd_num_tiles_fwd(int H, int W);
+/* tiles of the BACKWARD launch: sizes grad_proj [S, NP, bbd_num_tiles_bwd(H,W), 12] */
 int bbd_num_tiles_bwd(int H, int W);
 
 /* Pose table [NP,40] -> projection table [NP,24]: P = (K@T)[:3,:] formed with the rounding order of

@@ -34,6 +34,9 @@ class HostPortBackend:
     def num_tiles(self, H, W):
         return 1
 
+    def num_tiles_fwd(self, H, W):
+        return 1
+
     def num_tiles_bwd(self, H, W):
         return 1
 

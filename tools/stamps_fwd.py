@@ -27,8 +27,8 @@ plan = tr.valid_frames_trimin(inputs)
 disp = synthetic_disp(B, H, W, scales, device=dev, seed=1)
 outputs = {("disp", s): disp[s] for s in scales}
 outputs.update(synthetic_poses(plan, device=dev, seed=2))
-nblocks_f = 4 * B * be.num_tiles(H, W)
-nblocks = 4 * B * max(be.num_tiles(H, W), be.num_tiles_bwd(H, W))     # the backward tile is narrower
+nblocks_f = 4 * B * be.num_tiles_fwd(H, W)
+nblocks = 4 * B * max(be.num_tiles_fwd(H, W), be.num_tiles_bwd(H, W))     # the backward tile is narrower
 stamps = torch.zeros(nblocks * 32, dtype=torch.int64, device=dev)
 dll = be.lib._dll
 dll.bbd_debug_set_stamps.argtypes = [ctypes.c_void_p]
