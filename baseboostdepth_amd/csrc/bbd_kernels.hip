@@ -1363,8 +1363,10 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused forward, narrow-tile form: 32x16-pixel tile, 256 threads, a 2-pixel strip per thread - the backward's
-// geometry.  Per-thread state halves (3 staged cells, 2-pixel windows, 12 target statistics instead of 24), so the
+// Fused forward, narrow-tile form (-DBBD_FWD_NARROW; NOT shipped): 32x16-pixel tile, 256 threads, a 2-pixel strip per
+// thread - the backward's geometry.  Measured (profiles/r02/fwd_narrow_variants.txt): MD2 0.246 vs 0.235 ms for the
+// shipped 64x16 form (in the training step 0.191 vs 0.178), boosted m=7 0.331 vs 0.343: the 4th wave per SIMD does not
+// pay for the larger halo share (1.195 vs 1.16 cells per pixel) and the per-strip statistics.  Per-thread state halves (3 staged cells, 2-pixel windows, 12 target statistics instead of 24), so the
 // kernel fits 128 VGPRs (4 waves per SIMD instead of 3) and every thread's gathers of a candidate are in flight
 // together (one batch instead of two).  Same per-pixel arithmetic, same bits; only the per-tile partial sums of the
 // scalar loss are grouped differently (240 tiles per image instead of 120).
@@ -2249,7 +2251,7 @@ int bbd_tile_w(void) { return TW; }
 int bbd_tile_h(void) { return TH; }
 int bbd_num_tiles(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 int bbd_num_tiles_fwd(int H, int W) {      /* tiles of the fused FORWARD launch: sizes partial [S, B, tiles] */
-#if defined(BBD_FWD_WIDE)
+#if !defined(BBD_FWD_NARROW)
   return bbd_num_tiles(H, W);
 #else
   return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2);
@@ -2312,7 +2314,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
   a.warped = warped; a.depth_out = depth_out; a.coords = reinterpret_cast<float2*>(coords); a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
-#if defined(BBD_FWD_WIDE)       // the round-1 form (64x16 tile, 4-pixel strips, 3 waves per SIMD): A/B timing builds
+#if !defined(BBD_FWD_NARROW)    // shipped: 64x16 tile, 4-pixel strips, 3 waves per SIMD
   hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
 #else
