@@ -173,6 +173,28 @@ struct Cells {
   }
 };
 
+// Block-uniform table reads (candidate descriptors, pose-table rows, per-scale scalars): read-only for the whole
+// launch, so they are loaded through the constant address space.  hipcc then selects scalar loads (s_load_dword*,
+// values in SGPRs); through a plain pointer the same reads that follow a barrier or a store became per-lane
+// global_load + v_readfirstlane with s_waitcnt vmcnt(0) - three dependent vector-memory round trips per candidate
+// and the 21 pose values in VGPRs (profiles/r02/phase_stamps_final.txt: 6.3k + 4.3k of 64k ticks per workgroup).
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p) {
+#if defined(BBD_PLAIN_TABLE_LOADS)     // timing A/B only: round 1's form
+  return *p;
+#else
+  typedef const __attribute__((address_space(4))) T* const_ptr;
+  return *(const_ptr)p;
+#endif
+}
+__device__ __forceinline__ bbd_cand_t load_cand(const bbd_cand_t* p) {     // one s_load_dwordx4
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i w = uniform_load(reinterpret_cast<const v4i*>(p));
+  bbd_cand_t c;
+  c.kind = w.x; c.slot = w.y; c.row = w.z; c.pose = w.w;
+  return c;
+}
+
 template <typename CellsT, int PLANE>
 __device__ __forceinline__ void stage_image(const float* __restrict__ img, int hw, int hw_w, const CellsT& cl,
                                             float (*s)[PLANE]) {
@@ -261,7 +283,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
 #pragma unroll
-  for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
+  for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
 #if defined(BBD_ABLATE_WARP)          // timing experiment only: no projection, no gathers
 #pragma unroll
   for (int k = 0; k < CellsT::N; ++k) {
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(NT) void identity_loss_kernel(FramePtrs frames, con
   __shared__ __attribute__((aligned(16))) float s_x[3][FPLANE];
   const int item = blockIdx.x / ntiles;
   const TileCoord tc = decode_tile(blockIdx.x - item * ntiles, W);
-  const int b = items[item * 4 + 0], slot = items[item * 4 + 1], row = items[item * 4 + 2];
+  const int b = uniform_load(items + item * 4 + 0), slot = uniform_load(items + item * 4 + 1), row = uniform_load(items + item * 4 + 2);
   const int hw = H * W;
   const size_t img = (size_t)3 * hw;
   Cells<LH, LW, LS, 1> cl;
@@ -578,9 +600,9 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
-  const int nc = a.ncand[b];
+  const int nc = uniform_load(a.ncand + b);
   for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
+    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
     float loss[PPT];
     if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
@@ -695,7 +717,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   const size_t sb = (size_t)s * a.B + b;
   const float* depth = a.depth + sb * hw;      // (this timing-only form supports depth planes only)
   const uint8_t* am = a.argmin + sb * hw;
-  const float g = a.gscale[s];
+  const float g = uniform_load(a.gscale + s);
   const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
   const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
 
@@ -774,10 +796,10 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
   BBD_STAMP(2);
   const unsigned present = s_present;
 
-  const int nc = a.ncand[b];
+  const int nc = uniform_load(a.ncand + b);
   int prev = -1;                       // previous processed candidate: its coefficient entries get cleared
   for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
+    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
     if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
     float* gp_out = a.grad_proj + (((size_t)s * a.NP + cd.pose) * a.ntiles + tc.tile) * 12;
     if (!((present >> c) & 1u)) {     // block-uniform: this candidate won nothing around the tile
@@ -926,7 +948,7 @@ __global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(Bw
 #endif
       float pj[21];
 #pragma unroll
-      for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
+      for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
       // coordinate derivatives of this thread's 4 pixels, left in LDS by the warp phase
       float dxy[6][PPT];
 #pragma unroll
@@ -1054,7 +1076,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   const size_t sb = (size_t)s * a.B + b;
   const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
   const uint8_t* am = a.argmin + sb * hw;
-  const float g = a.gscale[s];
+  const float g = uniform_load(a.gscale + s);
   const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
   const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
 
@@ -1134,14 +1156,14 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   BBD_STAMP(2);
   const unsigned present = s_present;
 
-  const int nc = a.ncand[b];
+  const int nc = uniform_load(a.ncand + b);
   int prev = -1;
 #if defined(BBD_BWD2_PREFETCH)
   float2 pre[CellsB::N];
   int pre_c = -1;
 #endif
   for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
+    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
     if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
     float* gp_out = a.grad_proj + (((size_t)s * a.NP + cd.pose) * a.ntiles + tc.tile) * 12;
     if (!((present >> c) & 1u)) {
@@ -1175,7 +1197,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
                                                                             s_dv, nullptr, pre);
       for (int n = c + 1; n < nc; ++n) {        // next candidate to be processed: its coordinates travel meanwhile
-        const bbd_cand_t nd = a.cand[b * BBD_MAX_CAND + n];
+        const bbd_cand_t nd = load_cand(a.cand + b * BBD_MAX_CAND + n);
         if ((nd.kind & KIND_MASK) == BBD_KIND_WARP && ((present >> n) & 1u)) {
           const float2* cp = a.coords + ((size_t)s * a.NP + nd.pose) * hw;
 #pragma unroll
@@ -1297,7 +1319,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     if (q_row_ok) {
       float pj[21];
 #pragma unroll
-      for (int i = 0; i < 21; ++i) pj[i] = pose_row[i];
+      for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
       float dxy[6][PPT2];
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl) {
@@ -1472,9 +1494,9 @@ __global__ __launch_bounds__(NT2, BBD_FWD2_WAVES) void warp_ssim_min_fwd2_kernel
   int arg[PPT2] = {0, 0};
   BBD_STAMP(3);
 
-  const int nc = a.ncand[b];
+  const int nc = uniform_load(a.ncand + b);
   for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = a.cand[b * BBD_MAX_CAND + c];
+    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
     float loss[PPT2] = {0.0f, 0.0f};
     if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;

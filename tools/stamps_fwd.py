@@ -56,10 +56,13 @@ dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 ls.sum().backward()
 torch.cuda.synchronize()
 st = stamps.view(nblocks, 32)[:4 * B * be.num_tiles_bwd(H, W)].cpu().double()
-bn = {(0, 1): "setup: clear planes, arg ids, cells, stage", (1, 2): "barrier", (4, 5): "cand0 W: list + warp recompute",
+bn = {(0, 1): "setup: clear planes, arg ids, cells, stage", (1, 2): "barrier", (2, 4): "cand0 descriptor + winners' list",
+      (4, 5): "cand0 W: warp recompute",
       (5, 6): "cand0 barrier", (6, 7): "cand0 C: winners' SSIM partials", (7, 8): "cand0 barrier",
       (8, 9): "cand0 G: adjoint gather", (9, 10): "cand0 sample-grad + dP reduce", (10, 11): "cand0 barrier",
-      (12, 13): "cand1 W", (14, 15): "cand1 C", (16, 17): "cand1 G", (17, 18): "cand1 sample-grad + reduce",
+      (11, 12): "cand0 dP store, cand1 descriptor + list", (12, 13): "cand1 W", (13, 14): "cand1 barrier",
+      (14, 15): "cand1 C", (15, 16): "cand1 barrier", (16, 17): "cand1 G", (17, 18): "cand1 sample-grad + reduce",
+      (18, 19): "cand1 barrier", (19, 20): "dP store, depth-gradient store",
       (0, 20): "TOTAL workgroup"}
 print("== backward")
 for (a, b), n in bn.items():
