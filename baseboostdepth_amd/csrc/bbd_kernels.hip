@@ -1096,6 +1096,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     pargw |= (in ? (unsigned)am[py * W + px] : 255u) << (8 * k);
   }
 #define BBD_PARG(k) ((pargw >> (8 * (k))) & 0xffu)
+  BBD_STAMP(21);
   typedef Cells<BH, BW2, BS2, 2, NT2> CellsB;
   CellsB cl;
   cl.init(H, W, tc.tx0, tc.ty0);
@@ -1118,6 +1119,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     for (int q = 0; q < CellsB::N; ++q) dcell[q] = 1.0f;
   }
 
+  BBD_STAMP(22);
   const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
   const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
   const bool q_row_ok = qy < H;
@@ -1134,10 +1136,13 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       if (qx0 + j < W) qdepth[j] = depth_at(dsrc, qy, qx0 + j, H, W);
   }
 
+  BBD_STAMP(23);
   if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
   for (int i = threadIdx.x; i < 3 * CPLANE2 / 4; i += NT2)
     reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  BBD_STAMP(24);
   __syncthreads();
+  BBD_STAMP(25);
   {
     unsigned mine = 0u;
 #pragma unroll
@@ -1145,6 +1150,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       if (BBD_PARG(k) != 255u) mine |= 1u << BBD_PARG(k);
     if (mine) atomicOr(&s_present, mine);
   }
+  BBD_STAMP(26);
 #pragma unroll
   for (int k = 0; k < CellsB::N; ++k) {
     s_y[0][cl.lds[k]] = tcell[k][0];
@@ -1644,8 +1650,7 @@ __global__ __launch_bounds__(NT) void disp_to_depth_bwd_kernel(const float* __re
 }
 
 // Bilinear up-sampling adjoint for ALL reduced scales of a step in one launch (disparity mode of the fused
-// backward): grad_up [S,B,H,W] = d loss / d (up-sampled disparity)  ->  grad_disp_s [B,h_s,w_s].  Gather form,
-// Q lanes (4 / 16 / 64 by up-sampling factor) per low-resolution pixel, fixed xor-butterfly: deterministic.
+// backward): grad_up [S,B,H,W] = d loss / d (up-sampled disparity)  ->  grad_disp_s [B,h_s,w_s].  Deterministic.
 struct AdjointArgs {
   const float* gup[MAX_SCALES];     // [B,H,W] plane stack of the scale
   float* gdisp[MAX_SCALES];
@@ -1653,6 +1658,90 @@ struct AdjointArgs {
   int block0[MAX_SCALES + 1];       // first workgroup of each scale
   int n, B, H, W;
 };
+
+// The high-resolution indices whose bilinear stencil can touch low-resolution index i (a superset: the weight
+// decides), for an up-sampling factor s = out / in.
+__device__ __forceinline__ void adjoint_window(int i, float s, int out_size, int* lo, int* hi) {
+  *lo = max(0, (int)floorf(((float)i - 0.5f) * s - 0.5f) - 1);
+  *hi = min(out_size - 1, (int)ceilf(((float)i + 1.5f) * s - 0.5f) + 1);
+}
+// weight of high-resolution index o on low-resolution index i (bbd_up_src = the forward's source index / lambdas)
+__device__ __forceinline__ float adjoint_weight(int o, int i, int in_size, int out_size) {
+  int i0, i1;
+  float l0, l1;
+  bbd_up_src(o, in_size, out_size, &i0, &i1, &l0, &l1);
+  return (i0 == i ? l0 : 0.0f) + (i1 == i ? l1 : 0.0f);
+}
+
+// Separable form (the shipped one): the weight of (oy, ox) on (y, x) is wy(oy, y) * wx(ox, x), so a workgroup
+// owning an 8x32 low-resolution tile tabulates both weight sets once (<= AJ_TAPS per index), reduces the tile's
+// high-resolution rows horizontally into LDS and then vertically: (8 f + 5) * 32 * (2 f + 5) + 256 * (2 f + 5)
+// multiply-adds per tile instead of 256 * (2 f + 5)^2 stencil evaluations with two divisions each
+// (81 -> see profiles/r02 for the MD2 launch).  Up-sampling factors up to 8 (the reference's scales 1-3).
+constexpr int AJ_TY = 8, AJ_TX = 32;
+constexpr int AJ_TAPS = 24;                        // >= 2 f + 5 for f <= 8 (+ slack for non-integer factors)
+constexpr int AJ_WS = AJ_TAPS + 1;                 // odd row stride of the weight tables: conflict-free columns
+constexpr int AJ_ROWS = (AJ_TY + 1) * 8 + 8;       // high-resolution rows under one tile, f <= 8
+__global__ __launch_bounds__(NT) void upsample_adjoint_tiled_kernel(AdjointArgs a) {
+  __shared__ float s_wx[AJ_TX * AJ_WS], s_wy[AJ_TY * AJ_WS];
+  __shared__ int s_xlo[AJ_TX], s_nx[AJ_TX], s_ylo[AJ_TY], s_ny[AJ_TY];
+  __shared__ float s_tmp[AJ_ROWS][AJ_TX];
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.block0[k + 1]) ++k;
+  const int h = a.h[k], w = a.w[k], H = a.H, W = a.W;
+  const int tiles_x = (w + AJ_TX - 1) / AJ_TX, tiles_y = (h + AJ_TY - 1) / AJ_TY;
+  int bid = (int)blockIdx.x - a.block0[k];
+  const int b = bid / (tiles_x * tiles_y);
+  bid -= b * tiles_x * tiles_y;
+  const int ty0 = (bid / tiles_x) * AJ_TY, tx0 = (bid % tiles_x) * AJ_TX;
+  const float sy_ = (float)H / (float)h, sx_ = (float)W / (float)w;
+  const float* g = a.gup[k] + (size_t)b * H * W;
+  const int t = (int)threadIdx.x;
+
+  for (int i = t; i < AJ_TX * AJ_TAPS; i += NT) {
+    const int xl = i / AJ_TAPS, tap = i - xl * AJ_TAPS, x = tx0 + xl;
+    int lo, hi;
+    adjoint_window(x, sx_, W, &lo, &hi);
+    const bool in = x < w && lo + tap <= hi;
+    s_wx[xl * AJ_WS + tap] = in ? adjoint_weight(lo + tap, x, w, W) : 0.0f;
+    if (tap == 0) { s_xlo[xl] = lo; s_nx[xl] = x < w ? min(hi - lo + 1, AJ_TAPS) : 0; }
+  }
+  for (int i = t; i < AJ_TY * AJ_TAPS; i += NT) {
+    const int yl = i / AJ_TAPS, tap = i - yl * AJ_TAPS, y = ty0 + yl;
+    int lo, hi;
+    adjoint_window(y, sy_, H, &lo, &hi);
+    const bool in = y < h && lo + tap <= hi;
+    s_wy[yl * AJ_WS + tap] = in ? adjoint_weight(lo + tap, y, h, H) : 0.0f;
+    if (tap == 0) { s_ylo[yl] = lo; s_ny[yl] = y < h ? min(hi - lo + 1, AJ_TAPS) : 0; }
+  }
+  __syncthreads();
+  const int ylast = min(AJ_TY, h - ty0) - 1;
+  const int row0 = s_ylo[0], nrows = min(s_ylo[ylast] + s_ny[ylast] - row0, AJ_ROWS);
+
+  // horizontal: s_tmp[r][xl] = sum_ox wx(ox, x) * g[row0 + r][ox]
+  const int xl = t % AJ_TX;
+  {
+    const int xlo = s_xlo[xl], nx = s_nx[xl];
+    for (int r = t / AJ_TX; r < nrows; r += NT / AJ_TX) {
+      const float* row = g + (size_t)(row0 + r) * W + xlo;
+      float acc = 0.0f;
+      for (int tap = 0; tap < nx; ++tap) acc += s_wx[xl * AJ_WS + tap] * row[tap];
+      s_tmp[r][xl] = acc;
+    }
+  }
+  __syncthreads();
+  // vertical: one low-resolution pixel per thread
+  const int yl = t / AJ_TX, y = ty0 + yl, x = tx0 + xl;
+  if (y < h && x < w) {
+    const int r0 = s_ylo[yl] - row0, ny = s_ny[yl];
+    float acc = 0.0f;
+    for (int tap = 0; tap < ny && r0 + tap < nrows; ++tap) acc += s_wy[yl * AJ_WS + tap] * s_tmp[r0 + tap][xl];
+    a.gdisp[k][((size_t)b * h + y) * w + x] = acc;
+  }
+}
+
+// Gather form for up-sampling factors above 8 (never the reference's): Q lanes (4 / 16 / 64 by factor) per
+// low-resolution pixel evaluate the whole stencil window, fixed xor-butterfly.
 __global__ __launch_bounds__(NT) void upsample_adjoint_kernel(AdjointArgs a) {
   int k = 0;
   while (k + 1 < a.n && (int)blockIdx.x >= a.block0[k + 1]) ++k;
@@ -1667,20 +1756,14 @@ __global__ __launch_bounds__(NT) void upsample_adjoint_kernel(AdjointArgs a) {
   const int b = (int)(i / ((size_t)w * h));
   const float* g = a.gup[k] + (size_t)b * H * W;
   const float sy_ = (float)H / (float)h, sx_ = (float)W / (float)w;
-  const int oy_lo = max(0, (int)floorf(((float)y - 0.5f) * sy_ - 0.5f) - 1);
-  const int oy_hi = min(H - 1, (int)ceilf(((float)y + 1.5f) * sy_ - 0.5f) + 1);
-  const int ox_lo = max(0, (int)floorf(((float)x - 0.5f) * sx_ - 0.5f) - 1);
-  const int ox_hi = min(W - 1, (int)ceilf(((float)x + 1.5f) * sx_ - 0.5f) + 1);
+  int oy_lo, oy_hi, ox_lo, ox_hi;
+  adjoint_window(y, sy_, H, &oy_lo, &oy_hi);
+  adjoint_window(x, sx_, W, &ox_lo, &ox_hi);
   const int nx = ox_hi - ox_lo + 1, ncand = (oy_hi - oy_lo + 1) * nx;
   float acc = 0.0f;
   for (int c = sub; c < ncand; c += Q) {
     const int oy = oy_lo + c / nx, ox = ox_lo + c % nx;
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
-    bbd_up_src(oy, h, H, &y0, &y1, &ly0, &ly1);
-    bbd_up_src(ox, w, W, &x0, &x1, &lx0, &lx1);
-    const float wy = (y0 == y ? ly0 : 0.0f) + (y1 == y ? ly1 : 0.0f);
-    const float wx = (x0 == x ? lx0 : 0.0f) + (x1 == x ? lx1 : 0.0f);
+    const float wy = adjoint_weight(oy, y, h, H), wx = adjoint_weight(ox, x, w, W);
     if (wy == 0.0f || wx == 0.0f) continue;
     acc += g[(size_t)oy * W + ox] * wy * wx;
   }
@@ -2426,19 +2509,26 @@ int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw
   if (n == 0) return 0;
   AdjointArgs a;
   a.n = n; a.B = B; a.H = H; a.W = W;
-  int blocks = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bool tiled = true;
   for (int i = 0; i < n; ++i) {
     a.gup[i] = static_cast<const float*>(grad_up[i]);
     a.gdisp[i] = static_cast<float*>(grad_disp[i]);
     a.h[i] = disp_hw[2 * i]; a.w[i] = disp_hw[2 * i + 1];
     if (!a.gup[i] || !a.gdisp[i] || a.h[i] <= 0 || a.w[i] <= 0 || a.h[i] > H || a.w[i] > W) return BBD_E_BADARG;
+    if ((long long)H > 8LL * a.h[i] || (long long)W > 8LL * a.w[i]) tiled = false;
+  }
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
     const int f = (H + a.h[i] - 1) / a.h[i];
     a.q[i] = f <= 1 ? 1 : (f <= 2 ? 4 : (f <= 4 ? 16 : 64));
     a.block0[i] = blocks;
-    blocks += (int)(((size_t)B * a.h[i] * a.w[i] * a.q[i] + NT - 1) / NT);
+    if (tiled) blocks += B * ((a.h[i] + AJ_TY - 1) / AJ_TY) * ((a.w[i] + AJ_TX - 1) / AJ_TX);
+    else blocks += (int)(((size_t)B * a.h[i] * a.w[i] * a.q[i] + NT - 1) / NT);
   }
   a.block0[n] = blocks;
-  hipLaunchKernelGGL(upsample_adjoint_kernel, dim3((unsigned)blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), a);
+  if (tiled) hipLaunchKernelGGL(upsample_adjoint_tiled_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL(upsample_adjoint_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, a);
   return launch_status();
 }
 

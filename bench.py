@@ -286,7 +286,7 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from baseboostdepth_amd import ops
+    from baseboostdepth_amd import ops, tuning
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
 
@@ -434,7 +434,11 @@ def main(argv=None):
                                    "BaseBoostDepth boosted step (trimin+decomp+incremental+partial, config %s, "
                                    "per-sample max offsets %s), ResNet-18, 640x192, per-GPU batch %d, %d scale(s)"
                                    % (args.config, ms, args.batch, S),
-                       "global_batch": global_batch, "parallelism": "dp%d" % world},
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "miopen": {"user_db": ("shipped (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh)"
+                                              if os.environ.get("MIOPEN_USER_DB_PATH") == tuning.DB_DIR else
+                                              os.environ.get("MIOPEN_USER_DB_PATH")),
+                                  "find": bool(torch.backends.cudnn.benchmark)}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
             "step_graph": bool(trainer.use_graph) if graph_note is None else graph_note,
         }

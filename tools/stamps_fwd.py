@@ -56,7 +56,10 @@ dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 ls.sum().backward()
 torch.cuda.synchronize()
 st = stamps.view(nblocks, 32)[:4 * B * be.num_tiles_bwd(H, W)].cpu().double()
-bn = {(0, 1): "setup: clear planes, arg ids, cells, stage", (1, 2): "barrier", (2, 4): "cand0 descriptor + winners' list",
+bn = {(0, 21): "  setup: loss-pixel arg-min ids (issue)", (21, 22): "  setup: cells, target + depth loads (issue)",
+      (22, 23): "  setup: own arg ids, own depth (issue)", (23, 24): "  setup: clear coefficient planes", (24, 25): "  setup: barrier",
+      (25, 26): "  setup: wait arg ids, present mask", (26, 1): "  setup: wait target, stage",
+      (0, 1): "setup: clear planes, arg ids, cells, stage", (1, 2): "barrier", (2, 4): "cand0 descriptor + winners' list",
       (4, 5): "cand0 W: warp recompute",
       (5, 6): "cand0 barrier", (6, 7): "cand0 C: winners' SSIM partials", (7, 8): "cand0 barrier",
       (8, 9): "cand0 G: adjoint gather", (9, 10): "cand0 sample-grad + dP reduce", (10, 11): "cand0 barrier",
