@@ -60,7 +60,7 @@ SIGNATURES = {
     "bbd_u8_to_float_chw": [_p, _p, _p, _i, _i, _i, _p],
     "bbd_bn_scratch_doubles": [_i, _i, _i],
     "bbd_bn_act_fwd": [_p] * 11 + [_i, _i, _i, _d, _d, _i, _p],
-    "bbd_bn_act_bwd": [_p] * 11 + [_i, _i, _i, _i, _p],
+    "bbd_bn_act_bwd": [_p] * 12 + [_i, _i, _i, _i, _p],
     "bbd_reflect_pad1_fwd": [_p, _p, _i, _i, _i, _p],
     "bbd_reflect_pad1_bwd": [_p, _p, _i, _i, _i, _p],
     "bbd_maxpool3s2_fwd": [_p, _p, _p, _i, _i, _i, _p],

@@ -166,6 +166,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
   int lo, hi;
   plane_slice(a.HW, a.split, &lo, &hi);
   const float mean = a.mean[c], invstd = a.invstd[c];
+  // ReLU mask without the saved output (no residual in the forward): bn_apply_kernel's own expression on x
+  const bool remask = a.relu && a.y == nullptr;
+  const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   double dg = 0.0, dgx = 0.0;
   const bool vec = (a.HW & 3) == 0;
   for (int n = 0; n < a.N; ++n) {
@@ -176,7 +179,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
         float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
         const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
         if (a.relu) {
-          const float4 y = *reinterpret_cast<const float4*>(a.y + base + i);
+          float4 y;
+          if (remask) {
+            y.x = (x.x - mean) * scale + shift; y.y = (x.y - mean) * scale + shift;
+            y.z = (x.z - mean) * scale + shift; y.w = (x.w - mean) * scale + shift;
+          } else {
+            y = *reinterpret_cast<const float4*>(a.y + base + i);
+          }
           g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f;
           g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
         }
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
     } else {
       for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
         float g = a.dy[base + i];
-        if (a.relu && !(a.y[base + i] > 0.0f)) g = 0.0f;
+        if (a.relu && !((remask ? (a.x[base + i] - mean) * scale + shift : a.y[base + i]) > 0.0f)) g = 0.0f;
         sg += g;
         sgx += g * ((a.x[base + i] - mean) * invstd);
       }
@@ -223,6 +232,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
   __syncthreads();
   const float mg = s_k[0], mgx = s_k[1], k = s_k[2];
   const float mean = a.mean[c], invstd = a.invstd[c];
+  const bool remask = a.relu && a.y == nullptr;
+  const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   int lo, hi;
   plane_slice(a.HW, a.split, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
@@ -233,7 +244,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
         float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
         const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
         if (a.relu) {
-          const float4 y = *reinterpret_cast<const float4*>(a.y + base + i);
+          float4 y;
+          if (remask) {
+            y.x = (x.x - mean) * scale + shift; y.y = (x.y - mean) * scale + shift;
+            y.z = (x.z - mean) * scale + shift; y.w = (x.w - mean) * scale + shift;
+          } else {
+            y = *reinterpret_cast<const float4*>(a.y + base + i);
+          }
           g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f;
           g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
         }
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
     } else {
       for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
         float g = a.dy[base + i];
-        if (a.relu && !(a.y[base + i] > 0.0f)) g = 0.0f;
+        if (a.relu && !((remask ? (a.x[base + i] - mean) * scale + shift : a.y[base + i]) > 0.0f)) g = 0.0f;
         if (a.dres) a.dres[base + i] = g;
         a.dx[base + i] = k * (g - mg - ((a.x[base + i] - mean) * invstd) * mgx);
       }
@@ -711,14 +728,14 @@ int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, co
   return status();
 }
 
-int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* save_mean,
-                   const float* save_invstd, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                    double* scratch, int N, int C, int HW, int relu, void* stream) {
   if (!x || !grad_y || !gamma || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !scratch ||
-      N <= 0 || C <= 0 || HW <= 0 || (relu && !y))
+      N <= 0 || C <= 0 || HW <= 0 || (relu && !y && !beta))
     return BBD_E_BADARG;
   BnArgs a = {};
-  a.x = x; a.y = const_cast<float*>(y); a.dy = grad_y; a.gamma = gamma; a.mean = const_cast<float*>(save_mean);
+  a.x = x; a.y = const_cast<float*>(y); a.dy = grad_y; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(save_mean);
   a.invstd = const_cast<float*>(save_invstd); a.dx = grad_x; a.dres = grad_residual; a.dgamma = grad_gamma;
   a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.split = pick_split(N, HW); a.relu = relu;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -273,13 +273,15 @@ int bbd_u8_to_float_chw(const uint8_t* src, float* dst, const int32_t* jobs, int
  * doubles; running_mean/var may both be NULL (no tracking); relu != 0 applies max(0, .).
  *   fwd: writes y, save_mean[C], save_invstd[C]; updates running stats with `momentum` and increments
  *        *num_batches_tracked (int64 device scalar, may be NULL)
- *   bwd: y is needed only when relu != 0 (mask y > 0); grad_residual may be NULL */
+ *   bwd: the ReLU mask (relu != 0) is y > 0; a forward WITHOUT a residual may pass y = NULL and `beta`: the mask is
+ *        then re-derived from x with the forward's own expression (identical bits), which saves one read of the
+ *        activation in each of the two backward launches; grad_residual may be NULL */
 int bbd_bn_scratch_doubles(int N, int C, int HW);
 int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                    long long* num_batches_tracked, double* scratch, int N, int C, int HW, double eps,
                    double momentum, int relu, void* stream);
-int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma,
+int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
                    const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
                    float* grad_gamma, float* grad_beta, double* scratch, int N, int C, int HW, int relu,
                    void* stream);

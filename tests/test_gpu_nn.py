@@ -230,3 +230,27 @@ def test_bias_elu_in_place_and_its_backward():
         for name, a, b_, tol in zip(("y", "grad_x", "grad_bias"), got, want, (1e-6, 1e-6, 2e-5)):
             assert _rel(a, b_) < tol, (name, _rel(a, b_))
         assert all(torch.equal(p, q) for p, q in zip(got, run(True)))       # deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,smalls", [
+    (2, 192, 640, [(96, 320), (48, 160), (24, 80)]),      # the reference's scales 1-3: separable tiled kernel
+    (3, 50, 70, [(25, 35), (13, 18), (7, 9)]),            # ragged sizes, non-integer factors, partial tiles
+    (1, 64, 96, [(4, 6)]),                                 # factor 16: the gather-form fallback
+    (2, 64, 96, [(32, 48), (4, 6)]),                       # one launch mixing both -> fallback for all
+])
+def test_upsample_adjoint_matches_autograd_of_interpolate(B, H, W, smalls):
+    """bbd_disp_upsample_adjoint (one launch for every reduced scale) = the autograd of
+    F.interpolate(bilinear, align_corners=False) (trainer.py:455-458) applied to grad_up."""
+    from baseboostdepth_amd import ops
+    be = ops.default_backend()
+    torch.manual_seed(5)
+    grad_up = [torch.randn(B, H, W, device=DEV) for _ in smalls]
+    outs = [torch.full((B, 1, h, w), float("nan"), device=DEV) for h, w in smalls]
+    be.run("bbd_disp_upsample_adjoint", grad_up[0], ops._ptr_array(grad_up), ops._hw_array(outs), ops._ptr_array(outs),
+           len(smalls), B, H, W)
+    for g, o, (h, w) in zip(grad_up, outs, smalls):
+        d = torch.zeros(B, 1, h, w, device=DEV, requires_grad=True)
+        F.interpolate(d, [H, W], mode="bilinear", align_corners=False).backward(g.unsqueeze(1))
+        assert torch.isfinite(o).all()
+        assert float((o - d.grad).abs().max()) <= 2e-6 * float(d.grad.abs().max()), (h, w)
