@@ -301,8 +301,18 @@ BBD_HD void bbd_taps(float ix, float iy, const BbdDims& dm, BbdTaps* t) {
 
 /* The four texel values (nw, ne, sw, se) of one channel plane. */
 BBD_HD void bbd_fetch4(const float* plane, const BbdTaps* t, float v[4]) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BBD_GATHER_SADDR)
+  /* NOT shipped (-DBBD_GATHER_SADDR): uniform plane pointer + zero-extended 32-bit byte offset, so hipcc selects the
+   * SGPR-base form of global_load_dwordx2 (one 32-bit shift per texel pair instead of sign-extend + 64-bit shift +
+   * 64-bit add per pair and channel: 73 -> 55 v_lshl_add_u64 in the backward).  Measured neutral to slower
+   * (profiles/r02/gather_saddr_variants.txt: MD2 bwd 0.282 -> 0.279 ms, m=7 fwd 0.329 -> 0.344, bwd 0.351 -> 0.357). */
+  const char* base = reinterpret_cast<const char*>(plane);
+  const float* r0 = reinterpret_cast<const float*>(base + ((unsigned)t->i0 << 2));
+  const float* r1 = reinterpret_cast<const float*>(base + ((unsigned)t->i1 << 2));
+#else
   const float* r0 = plane + t->i0;
   const float* r1 = plane + t->i1;
+#endif
   v[0] = r0[0]; v[1] = r0[1]; v[2] = r1[0]; v[3] = r1[1];
 }
 

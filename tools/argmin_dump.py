@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Dump the arg-min ids of a training step of bench.py's workload (diagnostics: which share of the staged cells of a
+backward workgroup lie next to a winner of each warp candidate).  usage: tools/argmin_dump.py CONFIG OUT.npz [steps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+from baseboostdepth_amd.trainer import Trainer
+from baseboostdepth_amd.synthetic import synthetic_batch
+
+cfg, out = sys.argv[1], sys.argv[2]
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+torch.manual_seed(42)
+opt = bench.make_options(12, 0, cfg)
+opt.fused_adam, opt.step_graph = True, False
+run_scales = list(opt.scales)
+opt.scales = list(bench.SCALES)
+tr = Trainer(opt)
+tr.opt.scales = run_scales
+tr.set_train()
+ms = [1] * 12 if cfg in ("md2", "vit") else [7] * 12
+inputs = synthetic_batch(ms, bench.H, bench.W, opt.scales, device="cuda:0", seed=42)
+inputs.pop("noise")
+if cfg != "md2":
+    inputs["cutt"] = torch.tensor(1.35)
+for _ in range(steps):
+    outputs, losses = tr.process_batch(inputs)
+    tr.model_optimizer.zero_grad()
+    losses["loss"].backward()
+    tr.model_optimizer.step()
+arg = outputs[("bbd", "argmin")].cpu().numpy()
+names = [[list(n) for n in row] for row in tr.plan.cand_names]
+np.savez_compressed(out, argmin=arg, names=np.array(repr(names)))
+print(arg.shape, [(int(v), float((arg == v).mean())) for v in np.unique(arg)], names[0])
