@@ -78,13 +78,18 @@ class GradientAverager:
     def divide_after(self):
         return not (self.backend == "nccl" and self.use_avg)
 
-    def __call__(self):
-        self.flat.pack()
+    def exchange(self):
+        """Average the (already packed) flat buffer over the ranks.  Also the eager middle of the split-graph step
+        (Trainer._graph_step_dp): forward+backward+pack and the optimizer are hipGraphs, this stays a plain call."""
         if self.world == 1:
             return
         self._reduce(self.flat.flat)
         if self.divide_after:               # gloo (CPU tests) has no AVG
             self.flat.flat.div_(self.world)
+
+    def __call__(self):
+        self.flat.pack()
+        self.exchange()
 
 
 class OverlappedGradientAverager(GradientAverager):
@@ -226,7 +231,9 @@ def attach(trainer, group=None):
             for b in m.buffers():
                 if b.is_floating_point():
                     dist.broadcast(b.data, src=0, group=group)
-        overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1"
+        # a step replayed as hipGraphs cannot launch collectives from autograd hooks: the split-graph step packs inside
+        # its forward+backward graph and exchanges the whole buffer between its two graphs
+        overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1" and not getattr(trainer, "use_graph", False)
         bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
         never = trainer.gradient_free_parameters() if hasattr(trainer, "gradient_free_parameters") else ()
         trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket, never=never) if overlap

@@ -172,18 +172,36 @@ class Trainer:
                                     v.zero_()          # fresh Adam state: exp_avg = exp_avg_sq = step = 0
             self.step = step0
             torch.cuda.current_stream(self.device).wait_stream(warm)
-            self.model_optimizer.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                outputs, losses = self.process_batch(dict(static))
-                losses["loss"].backward()
-                self.model_optimizer.step()
-            entry = self._graphs[key] = (graph, static, outputs, losses)
-        graph, static, outputs, losses = entry
+            graph, tail = torch.cuda.CUDAGraph(), None
+            if self.grad_sync is None:
+                self.model_optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    outputs, losses = self.process_batch(dict(static))
+                    losses["loss"].backward()
+                    self.model_optimizer.step()
+            else:
+                # data parallel: the step is split in two graphs around ONE eager exchange of the flat gradient
+                # buffer - forward + backward + pack | all-reduce (RCCL, outside any capture) | optimizer.  The
+                # collective's ~1 ms is not overlapped with backward, in exchange for ~1 350 launches per step
+                # leaving the host (an eager multi-rank loop is host-bound on a busy node).  thread_local capture
+                # mode: the process group's watchdog thread may query events while this thread captures.
+                self.flat_grads.zero()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    outputs, losses = self.process_batch(dict(static))
+                    losses["loss"].backward()
+                    self.flat_grads.pack()
+                tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tail, capture_error_mode="thread_local"):
+                    self.model_optimizer.step()
+            entry = self._graphs[key] = (graph, tail, static, outputs, losses)
+        graph, tail, static, outputs, losses = entry
         for k, v in inputs.items():
             if torch.is_tensor(v) and v.is_cuda:
                 static[k].copy_(v, non_blocking=True)
         graph.replay()
+        if tail is not None:
+            self.grad_sync.exchange()
+            tail.replay()
         self.step += 1
         return outputs, losses
 
@@ -191,7 +209,7 @@ class Trainer:
         """One optimisation step on a collated batch, as the body of `run_epoch` does it."""
         if "frames" in inputs:
             self.opt.frame_ids = sorted(inputs["frames"], key=_frame_sort_key)
-        if self.use_graph and self.grad_sync is None and self.device.type == "cuda":
+        if self.use_graph and self.device.type == "cuda":
             for key, ipt in inputs.items():
                 if key not in ["frames", "ordering", "cutt"] and torch.is_tensor(ipt):
                     inputs[key] = ipt.to(self.device, non_blocking=True)

@@ -257,7 +257,8 @@ def main(argv=None):
                     help="replay the whole step (both HIP streams, MIOpen, the C-ABI launches, fused Adam) as one hipGraph: "
                          "the ~1 200 launches of a step cost ~16 ms of host time, which a slow or busy host CPU turns into "
                          "the bottleneck (measured: 480 vs 575 images/s on two boxes with identical GPU time).  auto = on for "
-                         "a single rank, falling back to the eager loop if capture fails; multi-rank runs are eager")
+                         "every run, falling back to the eager loop if capture fails; multi-rank runs replay two graphs "
+                         "per step (forward+backward+gradient pack | eager RCCL all-reduce | optimizer)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -309,7 +310,7 @@ def main(argv=None):
         bdist.attach(tr)
         return tr, opt
 
-    want_graph = args.step_graph == "on" or (args.step_graph == "auto" and world == 1 and not args.no_fused_adam)
+    want_graph = args.step_graph == "on" or (args.step_graph == "auto" and not args.no_fused_adam)
     trainer, opt = build_trainer(want_graph)
     import random as _random
     draw = _random.Random(1234 + rank)
@@ -336,14 +337,22 @@ def main(argv=None):
 
     graph_note = None
     if trainer.use_graph:
+        failure = None
         try:                                   # capture happens inside the first step of a batch signature
             trainer.train_step(inputs)
             torch.cuda.synchronize()
         except Exception as e:                 # never lose the benchmark to the capture: fall back to the eager loop
             if args.step_graph == "on":
                 raise
-            graph_note = "capture failed (%s: %s), eager loop used" % (type(e).__name__, str(e)[:120])
+            failure = "%s: %s" % (type(e).__name__, str(e)[:120])
             torch.cuda.synchronize()
+        if world > 1:                          # the fallback re-attaches (collectives): every rank takes it, or none
+            ok = torch.tensor([0.0 if failure else 1.0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if float(ok) < 0.5 and failure is None:
+                failure = "capture failed on another rank"
+        if failure:
+            graph_note = "capture failed (%s), eager loop used" % failure
             trainer, opt = build_trainer(False)
     for _ in range(args.warmup):
         trainer.train_step(inputs)
@@ -440,7 +449,9 @@ def main(argv=None):
                                               os.environ.get("MIOPEN_USER_DB_PATH")),
                                   "find": bool(torch.backends.cudnn.benchmark)}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
-            "step_graph": bool(trainer.use_graph) if graph_note is None else graph_note,
+            "step_graph": (graph_note if graph_note is not None else
+                           ("split: forward+backward+pack graph | eager all-reduce | optimizer graph"
+                            if (trainer.use_graph and world > 1) else bool(trainer.use_graph))),
         }
         if world == 1 and not args.no_eager_ab and args.config == "md2":
             line["hot_path_ab"] = eager_hot_path_ab(trainer, inputs, opt)

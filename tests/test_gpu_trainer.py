@@ -178,6 +178,21 @@ def test_two_ranks_on_one_gpu_exchange_gradients():
     assert "DDP_CHECK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
+def test_two_ranks_split_graph_step_matches_eager_data_parallel():
+    """Multi-rank step as hipGraphs (forward+backward+gradient pack | eager all-reduce | optimizer), two ranks on this
+    GPU over gloo: same parameters as the eager data-parallel step, ranks identical (tools/ddp_check.py --graph)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29300 + os.getpid() % 300)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "tools", "ddp_check.py"),
+                          "--graph"], env=env, capture_output=True, text=True, timeout=900)
+    assert "DDP_GRAPH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
 def test_step_graph_replay_matches_eager():
     """Opt-in whole-step hipGraph (`opt.step_graph`): capture after an eager warm-up that must NOT train
     (parameters, BatchNorm buffers, Adam state and the step counter are restored), then every batch with

@@ -24,11 +24,55 @@ from baseboostdepth_amd.synthetic import synthetic_batch  # noqa: E402
 H, W, B, STEPS = 96, 320, 4, 2
 
 
-def make_trainer():
+def make_trainer(step_graph=False):
     opt = bench.make_options(B, 0, "md2")
     opt.height, opt.width = H, W
+    opt.step_graph, opt.fused_adam = step_graph, True
     torch.manual_seed(7)
     return Trainer(opt), opt
+
+
+def graph_mode():
+    """--graph: the split-graph data-parallel step (forward+backward+pack graph | eager all-reduce | optimizer
+    graph) against the eager data-parallel step on the same batches: same parameters after 4 steps (to the
+    run-to-run tolerance of MIOpen's atomics), ranks bit-identical to each other."""
+    rank, _, world = bdist.init_from_env()
+    torch.cuda.set_device(0)
+    res = {}
+    for mode in (False, True):
+        tr, opt = make_trainer(step_graph=mode)
+        tr.set_train()
+        bdist.attach(trainer=tr)
+        assert tr.use_graph == mode and tr.grad_sync is not None
+        assert hasattr(tr.grad_sync, "buckets") != mode      # hooks-free averager under graphs
+        batch = synthetic_batch([1] * B, H, W, opt.scales, device="cuda:0", seed=100 + rank)
+        for _ in range(4):
+            _, losses = tr.train_step(dict(batch))
+        torch.cuda.synchronize()
+        assert tr.step == 4
+        if mode:
+            assert len(tr._graphs) == 1 and list(tr._graphs.values())[0][1] is not None
+        res[mode] = (torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"]))
+    mine = res[True][0]
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    for g in gathered[1:]:
+        assert torch.equal(g, gathered[0]), "ranks diverged under the split-graph step"
+    init = torch.cat([p.detach().flatten() for p in make_trainer()[0].parameters_to_train])
+    moved = float((res[True][0] - init).abs().max())
+    diff = float((res[True][0] - res[False][0]).abs().max())
+    print("rank %d: graph vs eager max parameter difference %.3e (graph path moved them by up to %.3e); loss %.6f vs %.6f"
+          % (rank, diff, moved, res[True][1], res[False][1]))
+    # 4 Adam steps from a random initialisation amplify MIOpen's atomically accumulated (run-to-run different) weight
+    # gradients - a parameter whose gradient is round-off moves by +-lr per step either way: same bars as the
+    # single-rank graph test (tests/test_gpu_trainer.py::test_step_graph_replay_matches_eager)
+    assert moved > 1e-4, moved
+    assert abs(res[True][1] - res[False][1]) < 5e-2 * abs(res[False][1])
+    assert diff < 5e-3 * float(res[False][0].abs().max()), diff
+    dist.barrier()
+    if rank == 0:
+        print("DDP_GRAPH_OK")
+    dist.destroy_process_group()
 
 
 def main():
@@ -88,4 +132,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    graph_mode() if "--graph" in sys.argv else main()
