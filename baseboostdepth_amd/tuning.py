@@ -22,6 +22,17 @@ def use_shipped_db():
         return None
     if not any(f.endswith(".ufdb.txt") for f in os.listdir(DB_DIR)):
         return None
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", DB_DIR)
-    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(DB_DIR, "cache"))
-    return os.environ["MIOPEN_USER_DB_PATH"]
+    if "MIOPEN_USER_DB_PATH" in os.environ:
+        return os.environ["MIOPEN_USER_DB_PATH"]
+    db = DB_DIR
+    if not os.access(DB_DIR, os.W_OK):
+        # MIOpen keeps lock files next to its databases and appends what it learns: a read-only checkout gets a
+        # private writable copy (a few MB) instead
+        import shutil
+        import tempfile
+        db = os.path.join(tempfile.mkdtemp(prefix="bbd_miopen_"), "miopen_db")
+        shutil.copytree(DB_DIR, db)
+    os.makedirs(os.path.join(db, "cache"), exist_ok=True)
+    os.environ["MIOPEN_USER_DB_PATH"] = db
+    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(db, "cache"))
+    return db

@@ -445,7 +445,7 @@ def main(argv=None):
                                    % (args.config, ms, args.batch, S),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "miopen": {"user_db": ("shipped (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh)"
-                                              if os.environ.get("MIOPEN_USER_DB_PATH") == tuning.DB_DIR else
+                                              if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "")) == "miopen_db" else
                                               os.environ.get("MIOPEN_USER_DB_PATH")),
                                   "find": bool(torch.backends.cudnn.benchmark)}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,

@@ -1,0 +1,38 @@
+"""The shipped MIOpen performance database (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh) is wired in by
+environment only, never over a caller's own setting, and covers every configuration bench.py names."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROBE = ("import os, baseboostdepth_amd; "
+         "print(os.environ.get('MIOPEN_USER_DB_PATH'), os.environ.get('MIOPEN_CUSTOM_CACHE_DIR'))")
+
+
+def _probe(**env):
+    e = {k: v for k, v in os.environ.items() if not k.startswith("MIOPEN_") and k != "BBD_MIOPEN_DB"}
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", PROBE], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout.strip().split()
+
+
+def test_import_points_miopen_at_the_shipped_database():
+    db, cache = _probe()
+    assert db == os.path.join(ROOT, "baseboostdepth_amd", "miopen_db") and cache == os.path.join(db, "cache")
+
+
+def test_caller_settings_win_and_the_switch_disables():
+    assert _probe(MIOPEN_USER_DB_PATH="/tmp/mine")[0] == "/tmp/mine"
+    assert _probe(BBD_MIOPEN_DB="0") == ["None", "None"]
+
+
+def test_database_holds_forward_backward_and_weight_gradient_records_for_md2_shapes():
+    d = os.path.join(ROOT, "baseboostdepth_amd", "miopen_db")
+    fdb = [f for f in os.listdir(d) if f.endswith(".ufdb.txt")]
+    assert len(fdb) == 1 and fdb[0].startswith("gfx950")
+    text = open(os.path.join(d, fdb[0])).read()
+    # ResNet-18 layer1 3x3 (64 -> 64 at 48x160, batch 12) in all three directions, and the 7x7 stem
+    for direction in ("F", "B", "W"):
+        assert "64-48-160-3x3-64-48-160-12-1x1-1x1-1x1-0-NCHW-FP32-%s=" % direction in text, direction
+    assert "-7x7-64-96-320-12-3x3-2x2-1x1-0-NCHW-FP32-F=" in text
