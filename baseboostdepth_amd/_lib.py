@@ -61,6 +61,9 @@ SIGNATURES = {
     "bbd_bn_scratch_doubles": [_i, _i, _i],
     "bbd_bn_act_fwd": [_p] * 11 + [_i, _i, _i, _d, _d, _i, _p],
     "bbd_bn_act_bwd": [_p] * 12 + [_i, _i, _i, _i, _p],
+    "bbd_bn_grouped_scratch_doubles": [_i, _i, _i, _i],
+    "bbd_bn_act_grouped_fwd": [_p] * 12 + [_i, _i, _i, _i, _d, _d, _i, _p],
+    "bbd_bn_act_grouped_bwd": [_p] * 13 + [_i, _i, _i, _i, _i, _p],
     "bbd_reflect_pad1_fwd": [_p, _p, _i, _i, _i, _p],
     "bbd_reflect_pad1_bwd": [_p, _p, _i, _i, _i, _p],
     "bbd_maxpool3s2_fwd": [_p, _p, _p, _i, _i, _i, _p],
@@ -124,6 +127,9 @@ class HipLibrary:
 
     def bn_scratch_doubles(self, N, C, HW):
         return self._dll.bbd_bn_scratch_doubles(N, C, HW)
+
+    def bn_grouped_scratch_doubles(self, max_rows, G, C, HW):
+        return self._dll.bbd_bn_grouped_scratch_doubles(max_rows, G, C, HW)
 
     def dwconv_wgrad_scratch_floats(self, B, H, W, C, k):
         return self._dll.bbd_dwconv_tokens_wgrad_scratch_floats(B, H, W, C, k)

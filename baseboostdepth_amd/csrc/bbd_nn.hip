@@ -46,6 +46,10 @@ struct BnArgs {
   float* dbeta;
   int N, C, HW, split, relu;
   float eps, momentum;
+  // call groups: samples [rows[g], rows[g+1]) are normalised with their own statistics, as if each group had been
+  // a separate call of the layer (one batched pass of a network that the reference calls G times); blockIdx.z = g
+  int G;
+  int rows[BBD_BN_MAX_GROUPS + 1];
 };
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -67,13 +71,13 @@ __device__ __forceinline__ void plane_slice(int HW, int split, int* lo, int* hi)
 
 __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
   __shared__ double sh[4];
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, grp = blockIdx.z;
   int lo, hi;
   plane_slice(a.HW, a.split, &lo, &hi);
   float s = 0.0f, ss = 0.0f;
   double ds = 0.0, dss = 0.0;
   const bool vec = (a.HW & 3) == 0;
-  for (int n = 0; n < a.N; ++n) {
+  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
     const float* p = a.x + ((size_t)n * a.C + c) * a.HW;
     if (vec) {
       for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
@@ -93,21 +97,28 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
   }
   const double ts = block_sum(ds, sh), tss = block_sum(dss, sh);
   if (threadIdx.x == 0) {
-    a.part[((size_t)c * a.split + blockIdx.x) * 2] = ts;
-    a.part[((size_t)c * a.split + blockIdx.x) * 2 + 1] = tss;
+    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2] = ts;
+    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2 + 1] = tss;
   }
+}
+
+// per-(channel, group) sums of the two partial columns written by the reduction kernels
+__device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, double* t0, double* t1) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < a.split; ++k) {
+    s0 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2];
+    s1 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2 + 1];
+  }
+  *t0 = s0; *t1 = s1;
 }
 
 __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
   __shared__ float s_mean, s_scale, s_shift;
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, grp = blockIdx.z;
   if (threadIdx.x == 0) {
-    double ts = 0.0, tss = 0.0;
-    for (int k = 0; k < a.split; ++k) {
-      ts += a.part[((size_t)c * a.split + k) * 2];
-      tss += a.part[((size_t)c * a.split + k) * 2 + 1];
-    }
-    const double cnt = (double)a.N * (double)a.HW;
+    double ts, tss;
+    group_totals(a, c, grp, &ts, &tss);
+    const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
     const double mean = ts / cnt;
     double var = tss / cnt - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -116,14 +127,28 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
     s_scale = a.gamma[c] * invstd;
     s_shift = a.beta[c];
     if (blockIdx.x == 0) {
-      a.mean[c] = (float)mean;
-      a.invstd[c] = invstd;
-      if (a.run_mean) {
-        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-        a.run_mean[c] = (1.0f - a.momentum) * a.run_mean[c] + a.momentum * (float)mean;
-        a.run_var[c] = (1.0f - a.momentum) * a.run_var[c] + a.momentum * (float)unbiased;
+      a.mean[(size_t)grp * a.C + c] = (float)mean;
+      a.invstd[(size_t)grp * a.C + c] = invstd;
+      if (grp == 0) {
+        // running statistics: one momentum update per group, in group order = the order of the calls replaced
+        if (a.run_mean) {
+          float rm = a.run_mean[c], rv = a.run_var[c];
+          for (int q = 0; q < a.G; ++q) {
+            double qs, qss;
+            group_totals(a, c, q, &qs, &qss);
+            const double qcnt = (double)(a.rows[q + 1] - a.rows[q]) * (double)a.HW;
+            const double qmean = qs / qcnt;
+            double qvar = qss / qcnt - qmean * qmean;
+            qvar = qvar > 0.0 ? qvar : 0.0;
+            const double unbiased = qcnt > 1.0 ? qvar * qcnt / (qcnt - 1.0) : qvar;
+            rm = (1.0f - a.momentum) * rm + a.momentum * (float)qmean;
+            rv = (1.0f - a.momentum) * rv + a.momentum * (float)unbiased;
+          }
+          a.run_mean[c] = rm;
+          a.run_var[c] = rv;
+        }
+        if (a.batches && c == 0) *a.batches += a.G;
       }
-      if (a.batches && c == 0) *a.batches += 1;
     }
   }
   __syncthreads();
@@ -131,7 +156,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
   int lo, hi;
   plane_slice(a.HW, a.split, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
-  for (int n = 0; n < a.N; ++n) {
+  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
       for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
@@ -162,16 +187,16 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
 
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
   __shared__ double sh[4];
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, grp = blockIdx.z;
   int lo, hi;
   plane_slice(a.HW, a.split, &lo, &hi);
-  const float mean = a.mean[c], invstd = a.invstd[c];
+  const float mean = a.mean[(size_t)grp * a.C + c], invstd = a.invstd[(size_t)grp * a.C + c];
   // ReLU mask without the saved output (no residual in the forward): bn_apply_kernel's own expression on x
   const bool remask = a.relu && a.y == nullptr;
   const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   double dg = 0.0, dgx = 0.0;
   const bool vec = (a.HW & 3) == 0;
-  for (int n = 0; n < a.N; ++n) {
+  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     float sg = 0.0f, sgx = 0.0f;
     if (vec) {
@@ -206,38 +231,41 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
   }
   const double tg = block_sum(dg, sh), tgx = block_sum(dgx, sh);
   if (threadIdx.x == 0) {
-    a.part[((size_t)c * a.split + blockIdx.x) * 2] = tg;
-    a.part[((size_t)c * a.split + blockIdx.x) * 2 + 1] = tgx;
+    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2] = tg;
+    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2 + 1] = tgx;
   }
 }
 
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
   __shared__ float s_k[3];
-  const int c = blockIdx.y;
+  const int c = blockIdx.y, grp = blockIdx.z;
   if (threadIdx.x == 0) {
-    double tg = 0.0, tgx = 0.0;
-    for (int k = 0; k < a.split; ++k) {
-      tg += a.part[((size_t)c * a.split + k) * 2];
-      tgx += a.part[((size_t)c * a.split + k) * 2 + 1];
-    }
-    const double cnt = (double)a.N * (double)a.HW;
+    double tg, tgx;
+    group_totals(a, c, grp, &tg, &tgx);
+    const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
     s_k[0] = (float)(tg / cnt);
     s_k[1] = (float)(tgx / cnt);
-    s_k[2] = a.gamma[c] * a.invstd[c];
-    if (blockIdx.x == 0) {
-      a.dgamma[c] = (float)tgx;
-      a.dbeta[c] = (float)tg;
+    s_k[2] = a.gamma[c] * a.invstd[(size_t)grp * a.C + c];
+    if (blockIdx.x == 0 && grp == 0) {      // parameter gradients: sums over every group, in group order
+      double sg = tg, sgx = tgx;
+      for (int q = 1; q < a.G; ++q) {
+        double qg, qgx;
+        group_totals(a, c, q, &qg, &qgx);
+        sg += qg; sgx += qgx;
+      }
+      a.dgamma[c] = (float)sgx;
+      a.dbeta[c] = (float)sg;
     }
   }
   __syncthreads();
   const float mg = s_k[0], mgx = s_k[1], k = s_k[2];
-  const float mean = a.mean[c], invstd = a.invstd[c];
+  const float mean = a.mean[(size_t)grp * a.C + c], invstd = a.invstd[(size_t)grp * a.C + c];
   const bool remask = a.relu && a.y == nullptr;
   const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   int lo, hi;
   plane_slice(a.HW, a.split, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
-  for (int n = 0; n < a.N; ++n) {
+  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
       for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
@@ -709,40 +737,81 @@ int status() {
 extern "C" {
 
 int bbd_bn_scratch_doubles(int N, int C, int HW) { return C * pick_split(N, HW) * 2; }
+int bbd_bn_grouped_scratch_doubles(int max_group_rows, int G, int C, int HW) {
+  return G * C * pick_split(max_group_rows, HW) * 2;
+}
 
-int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
-                   float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                   long long* num_batches_tracked, double* scratch, int N, int C, int HW, double eps, double momentum,
-                   int relu, void* stream) {
+namespace {
+// copies the group table into the launch arguments; returns the largest group (0 = invalid table)
+int fill_groups(const int32_t* group_rows, int G, int N, BnArgs* a) {
+  if (!group_rows || G < 1 || G > BBD_BN_MAX_GROUPS || group_rows[0] != 0 || group_rows[G] != N) return 0;
+  int biggest = 0;
+  for (int g = 0; g < G; ++g) {
+    const int n = group_rows[g + 1] - group_rows[g];
+    if (n <= 0) return 0;
+    biggest = n > biggest ? n : biggest;
+  }
+  a->G = G;
+  for (int g = 0; g <= G; ++g) a->rows[g] = group_rows[g];
+  return biggest;
+}
+}  // namespace
+
+int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                           float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                           long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G, int N, int C,
+                           int HW, double eps, double momentum, int relu, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch || N <= 0 || C <= 0 || HW <= 0)
     return BBD_E_BADARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return BBD_E_BADARG;
   BnArgs a = {};
+  const int biggest = fill_groups(group_rows, G, N, &a);
+  if (!biggest) return BBD_E_BADARG;
   a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.y = y; a.part = scratch; a.mean = save_mean;
   a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.batches = num_batches_tracked; a.N = N; a.C = C; a.HW = HW;
-  a.split = pick_split(N, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
+  a.split = pick_split(biggest, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)a.split, (unsigned)C);
+  const dim3 grid((unsigned)a.split, (unsigned)C, (unsigned)G);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(NT), 0, st, a);
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, st, a);
   return status();
 }
 
-int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
-                   const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
-                   double* scratch, int N, int C, int HW, int relu, void* stream) {
+int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
+                           float* grad_gamma, float* grad_beta, double* scratch, const int32_t* group_rows, int G, int N,
+                           int C, int HW, int relu, void* stream) {
   if (!x || !grad_y || !gamma || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !scratch ||
       N <= 0 || C <= 0 || HW <= 0 || (relu && !y && !beta))
     return BBD_E_BADARG;
   BnArgs a = {};
+  const int biggest = fill_groups(group_rows, G, N, &a);
+  if (!biggest) return BBD_E_BADARG;
   a.x = x; a.y = const_cast<float*>(y); a.dy = grad_y; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(save_mean);
   a.invstd = const_cast<float*>(save_invstd); a.dx = grad_x; a.dres = grad_residual; a.dgamma = grad_gamma;
-  a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.split = pick_split(N, HW); a.relu = relu;
+  a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.split = pick_split(biggest, HW); a.relu = relu;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)a.split, (unsigned)C);
+  const dim3 grid((unsigned)a.split, (unsigned)C, (unsigned)G);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
   return status();
+}
+
+int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                   float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                   long long* num_batches_tracked, double* scratch, int N, int C, int HW, double eps, double momentum,
+                   int relu, void* stream) {
+  const int32_t rows[2] = {0, N};
+  return bbd_bn_act_grouped_fwd(x, residual, gamma, beta, y, save_mean, save_invstd, running_mean, running_var,
+                                num_batches_tracked, scratch, rows, 1, N, C, HW, eps, momentum, relu, stream);
+}
+
+int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                   double* scratch, int N, int C, int HW, int relu, void* stream) {
+  const int32_t rows[2] = {0, N};
+  return bbd_bn_act_grouped_bwd(x, y, grad_y, gamma, beta, save_mean, save_invstd, grad_x, grad_residual, grad_gamma,
+                                grad_beta, scratch, rows, 1, N, C, HW, relu, stream);
 }
 
 int bbd_reflect_pad1_fwd(const float* in, float* out, int planes, int H, int W, void* stream) {

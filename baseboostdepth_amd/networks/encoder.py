@@ -27,6 +27,9 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
             from .. import ops
             return ops.batch_norm_act(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
                                       self.momentum, self.eps, relu, num_batches_tracked=self.num_batches_tracked)
+        if self.training and x.is_cuda:
+            from .. import ops
+            assert ops._bn_groups is None, "a batched pass with call groups needs the fused BatchNorm path"
         y = super().forward(x)
         if residual is not None:
             y = y + residual

@@ -654,6 +654,36 @@ def factor_attention_supported(C, heads, backend=None):
 
 
 # ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)
+BN_MAX_GROUPS = 32          # BBD_BN_MAX_GROUPS of include/bbd_hip.h
+_bn_groups = None           # row counts of the call groups of the batched pass being run (None = one group)
+
+
+class bn_call_groups:
+    """`with ops.bn_call_groups([n_0, n_1, ...]):` - every fused BatchNorm inside treats its batch as consecutive
+    call groups of n_g samples with their own batch statistics: one batched pass of a network computes what the
+    reference's separate calls on the sub-batches compute (the pose network: trainer.py:348-418)."""
+
+    def __init__(self, rows):
+        self.rows = [int(r) for r in rows] if rows is not None and len(rows) > 1 else None
+        assert self.rows is None or (len(self.rows) <= BN_MAX_GROUPS and min(self.rows) > 0)
+
+    def __enter__(self):
+        global _bn_groups
+        self.prev, _bn_groups = _bn_groups, self.rows
+        return self
+
+    def __exit__(self, *exc):
+        global _bn_groups
+        _bn_groups = self.prev
+
+
+def _group_table(rows):
+    arr = (ctypes.c_int32 * (len(rows) + 1))()
+    for i, r in enumerate(rows):
+        arr[i + 1] = arr[i] + r
+    return arr
+
+
 class _BatchNormAct(torch.autograd.Function):
     """Training-mode BatchNorm2d, optional residual add and ReLU in two launches each way
     (csrc/bbd_nn.hip) - the tail of every ResNet block of the encoders."""
@@ -666,31 +696,38 @@ class _BatchNormAct(torch.autograd.Function):
             residual = residual.contiguous()
             assert residual.shape == x.shape
         backend._check(x, weight, bias, residual, running_mean, running_var)
+        rows = _bn_groups if _bn_groups is not None else [N]
+        assert sum(rows) == N, "ops.bn_call_groups does not describe this batch (%s vs %d rows)" % (rows, N)
+        G = len(rows)
         y = torch.empty_like(x)
-        mean = torch.empty(C, device=x.device, dtype=torch.float32)
-        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(backend.lib.bn_scratch_doubles(N, C, H * W), device=x.device, dtype=torch.float64)
-        backend.run("bbd_bn_act_fwd", x, ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(invstd),
-                    ptr(running_mean), ptr(running_var), ptr(batches), ptr(scratch), N, C, H * W, float(eps), float(momentum),
-                    int(relu))
+        mean = torch.empty(G, C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(G, C, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(backend.lib.bn_grouped_scratch_doubles(max(rows), G, C, H * W), device=x.device,
+                              dtype=torch.float64)
+        backend.run("bbd_bn_act_grouped_fwd", x, ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean),
+                    ptr(invstd), ptr(running_mean), ptr(running_var), ptr(batches), ptr(scratch), _group_table(rows), G,
+                    N, C, H * W, float(eps), float(momentum), int(relu))
         # without a residual the backward re-derives the ReLU mask from x (one activation read less per launch)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, mean, invstd)
-        ctx.meta = (bool(relu), residual is not None, backend)
+        ctx.meta = (bool(relu), residual is not None, backend, rows)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
         x, y, weight, bias, mean, invstd = ctx.saved_tensors
-        relu, has_res, backend = ctx.meta
+        relu, has_res, backend, rows = ctx.meta
         N, C, H, W = x.shape
+        G = len(rows)
         grad_y = grad_y.contiguous()
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if has_res else None
         grad_w = torch.empty(C, device=x.device, dtype=torch.float32)
         grad_b = torch.empty(C, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(backend.lib.bn_scratch_doubles(N, C, H * W), device=x.device, dtype=torch.float64)
-        backend.run("bbd_bn_act_bwd", x, ptr(x), ptr(y), ptr(grad_y), ptr(weight), ptr(bias), ptr(mean), ptr(invstd), ptr(grad_x),
-                    ptr(grad_res), ptr(grad_w), ptr(grad_b), ptr(scratch), N, C, H * W, int(relu))
+        scratch = torch.empty(backend.lib.bn_grouped_scratch_doubles(max(rows), G, C, H * W), device=x.device,
+                              dtype=torch.float64)
+        backend.run("bbd_bn_act_grouped_bwd", x, ptr(x), ptr(y), ptr(grad_y), ptr(weight), ptr(bias), ptr(mean),
+                    ptr(invstd), ptr(grad_x), ptr(grad_res), ptr(grad_w), ptr(grad_b), ptr(scratch), _group_table(rows),
+                    G, N, C, H * W, int(relu))
         return grad_x, grad_w, grad_b, grad_res, None, None, None, None, None, None, None
 
 

@@ -431,6 +431,38 @@ class Trainer:
         axisangle, translation = self.models["pose"](feats)
         return transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=invert)
 
+    def _batched_pose_pairs(self):
+        """One batched pass for all pose-network calls of a step?  The reference calls the pose network once per
+        frame pair (trainer.py:348-418: 2 calls for MD2, up to 26 on <= 12 samples each for the boosted recipe); no
+        call depends on another's output.  On the GPU the calls run as ONE pass over the concatenated pairs, with
+        every fused BatchNorm keeping separate batch statistics per call group (`ops.bn_call_groups`,
+        `bbd_bn_act_grouped_*`) - the numbers of the separate calls, fewer and larger launches."""
+        if getattr(self.opt, "batched_pose", True) is False or os.environ.get("BBD_BATCHED_POSE", "1") == "0":
+            return False
+        if self.device.type != "cuda":
+            return False
+        from .networks.encoder import FusedBatchNorm2d
+        enc = self.models["pose_encoder"]
+        return (not enc.training) or FusedBatchNorm2d.fused
+
+    def _pose_pairs(self, requests):
+        """requests: [(first, second, invert)] in the reference's call order -> [T] (4x4 per row of the pair)."""
+        if len(requests) <= 1 or not self._batched_pose_pairs():
+            return [self._pose_pair(a, b, inv) for a, b, inv in requests]
+        out = []
+        for lo in range(0, len(requests), ops.BN_MAX_GROUPS):
+            chunk = requests[lo:lo + ops.BN_MAX_GROUPS]
+            rows = [a.shape[0] for a, _, _ in chunk]
+            x = torch.cat([torch.cat([a, b], 1) for a, b, _ in chunk], 0)
+            with ops.bn_call_groups(rows):
+                feats = [self.models["pose_encoder"](x)]
+            axisangle, translation = self.models["pose"](feats)
+            r0 = 0
+            for n, (_, _, inv) in zip(rows, chunk):
+                out.append(transformation_from_parameters(axisangle[r0:r0 + n, 0], translation[r0:r0 + n, 0], invert=inv))
+                r0 += n
+        return out
+
     def _error_pose(self, T):
         Te = T.clone().detach()                       # no pose gradient through the error-induced warp
         # tensor / tensor: a Python-scalar divisor would be turned into a multiply by 1/pose_error on
@@ -446,20 +478,55 @@ class Trainer:
         temporal = [f for f in opt.frame_ids[1:] if f != STEREO]
         incremental = bool(opt.incremental_skip and self.maxing_valid_frames)
 
+        # every pose-network call of the step, in the reference's call order; none depends on another's result, so
+        # they are collected first and run as one batched pass (`_pose_pairs`)
+        requests, slot = [], {}
+
+        def want(key, first, second, invert):
+            slot[key] = len(requests)
+            requests.append((first, second, invert))
+
         if incremental:
             # one pose-net call per ADJACENT pair, chained back to frame 0 (trainer.py:348-388)
             for f in temporal:
                 cur = inputs["color_aug", f, 0]
                 if abs(f) == 1:
                     ref = inputs["color_aug", 0, 0]
-                    T = self._pose_pair(cur, ref, True) if f < 0 else self._pose_pair(ref, cur, False)
-                    outputs[("cam_T_cam", 0, f)] = T
-                    outputs[("cam_T_cam_step", 0, f)] = T.clone()
+                    want(("step", f), *((cur, ref, True) if f < 0 else (ref, cur, False)))
                 else:
                     nb = f + 1 if f < 0 else f - 1
                     own_f, own_nb = plan.owners(f), plan.owners(nb)
                     near = self._rows(inputs["color_aug", nb, 0], [own_nb.index(b) for b in own_f])
-                    step = self._pose_pair(cur, near, True) if f < 0 else self._pose_pair(near, cur, False)
+                    want(("step", f), *((cur, near, True) if f < 0 else (near, cur, False)))
+        else:
+            # one call per warp job on the already selected sub-batch (trainer.py:390-405)
+            for f in self.valid_frames:
+                if f == STEREO:
+                    continue
+                mid = self._rows(inputs["color_aug", 0, 0], plan.jobs[f])
+                other = self._rows(inputs["color_aug", f, 0], plan.job_rows_in_source(f))
+                want(("job", f), *((other, mid, True) if f < 0 else (mid, other, False)))
+        partial = bool(opt.partial_skip and self.maxing_valid_frames)
+        if partial:
+            # direct 0->f pose supplies the translation column except where |f| == m-2 (trainer.py:407-418)
+            assert incremental, "--partial_skip needs --incremental_skip (the reference's shapes only fit then)"
+            for f in self.valid_frames:
+                if f == STEREO or abs(f) <= 1:
+                    continue
+                mid = self._rows(inputs["color_aug", 0, 0], plan.owners(f))
+                cur = inputs["color_aug", f, 0]
+                want(("direct", f), *((cur, mid, True) if f < 0 else (mid, cur, False)))
+        Ts = self._pose_pairs(requests)
+
+        if incremental:
+            for f in temporal:
+                step = Ts[slot[("step", f)]]
+                if abs(f) == 1:
+                    outputs[("cam_T_cam", 0, f)] = step
+                    outputs[("cam_T_cam_step", 0, f)] = step.clone()
+                else:
+                    nb = f + 1 if f < 0 else f - 1
+                    own_f = plan.owners(f)
                     outputs[("cam_T_cam_step", nb, f)] = step
                     if f not in self.valid_frames_pose:
                         continue
@@ -474,27 +541,20 @@ class Trainer:
                 if opt.decomp:
                     outputs[("cam_T_cam_error", 0, f)] = self._error_pose(outputs[("cam_T_cam", 0, f)])
         else:
-            # one call per warp job on the already selected sub-batch (trainer.py:390-405)
             for f in self.valid_frames:
                 if f == STEREO:
                     continue
-                mid = self._rows(inputs["color_aug", 0, 0], plan.jobs[f])
-                other = self._rows(inputs["color_aug", f, 0], plan.job_rows_in_source(f))
-                T = self._pose_pair(other, mid, True) if f < 0 else self._pose_pair(mid, other, False)
+                T = Ts[slot[("job", f)]]
                 outputs[("cam_T_cam", 0, f)] = T
                 if opt.decomp:
                     outputs[("cam_T_cam_error", 0, f)] = self._error_pose(T)
 
-        if opt.partial_skip and self.maxing_valid_frames:
-            # direct 0->f pose supplies the translation column except where |f| == m-2 (trainer.py:407-418)
-            assert incremental, "--partial_skip needs --incremental_skip (the reference's shapes only fit then)"
+        if partial:
             nonstereo = [m for m in plan.ms if m != 0]
             for f in self.valid_frames:
                 if f == STEREO or abs(f) <= 1:
                     continue
-                mid = self._rows(inputs["color_aug", 0, 0], plan.owners(f))
-                cur = inputs["color_aug", f, 0]
-                direct = self._pose_pair(cur, mid, True) if f < 0 else self._pose_pair(mid, cur, False)
+                direct = Ts[slot[("direct", f)]]
                 chained = outputs[("cam_T_cam", 0, f)]
                 replaced = torch.cat([chained[:, :, :3], direct[:, :, 3:]], dim=2)
                 # the reference indexes its all-sample list by ROW number of the n_f-row tensor

@@ -277,6 +277,23 @@ int bbd_u8_to_float_chw(const uint8_t* src, float* dst, const int32_t* jobs, int
  *        then re-derived from x with the forward's own expression (identical bits), which saves one read of the
  *        activation in each of the two backward launches; grad_residual may be NULL */
 int bbd_bn_scratch_doubles(int N, int C, int HW);
+/* Grouped form: the N samples are G consecutive call groups, rows [group_rows[g], group_rows[g+1]) (HOST array of
+ * G+1 ints, group_rows[0] = 0, group_rows[G] = N, G <= BBD_BN_MAX_GROUPS), each normalised with its OWN batch
+ * statistics - bit for bit what G separate calls of the layer on the G sub-batches compute, in one pass.  This is how
+ * the pose network's per-frame calls (trainer.py:348-418: up to 26 calls per step on <= 12 samples each) run as one
+ * batched pass.  save_mean / save_invstd are [G,C]; the running statistics receive G momentum updates in group order
+ * and num_batches_tracked += G; grad_gamma / grad_beta are summed over the groups.  scratch:
+ * bbd_bn_grouped_scratch_doubles(largest group, G, C, HW) doubles. */
+#define BBD_BN_MAX_GROUPS 32
+int bbd_bn_grouped_scratch_doubles(int max_group_rows, int G, int C, int HW);
+int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                           float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                           long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G, int N,
+                           int C, int HW, double eps, double momentum, int relu, void* stream);
+int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
+                           float* grad_gamma, float* grad_beta, double* scratch, const int32_t* group_rows, int G, int N,
+                           int C, int HW, int relu, void* stream);
 int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                    long long* num_batches_tracked, double* scratch, int N, int C, int HW, double eps,

@@ -254,3 +254,85 @@ def test_upsample_adjoint_matches_autograd_of_interpolate(B, H, W, smalls):
         F.interpolate(d, [H, W], mode="bilinear", align_corners=False).backward(g.unsqueeze(1))
         assert torch.isfinite(o).all()
         assert float((o - d.grad).abs().max()) <= 2e-6 * float(d.grad.abs().max()), (h, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,res,relu", [([5, 3, 4], True, True), ([12, 12], False, True), ([1, 7, 2, 6], False, False)])
+def test_grouped_batch_norm_equals_separate_calls(rows, res, relu):
+    """`ops.bn_call_groups`: one batched pass whose BatchNorm keeps its statistics per call group = the separate calls
+    of the layer on the sub-batches (outputs, data gradients and running statistics bit for bit; parameter gradients
+    to rounding - the separate calls' are added up by autograd in fp32, the grouped form sums in fp64)."""
+    import copy
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.networks.encoder import FusedBatchNorm2d
+    torch.manual_seed(11)
+    C, H, W = 16, 12, 20
+    N = sum(rows)
+    x = torch.randn(N, C, H, W, device=DEV) * 2 + 0.5
+    r = torch.randn(N, C, H, W, device=DEV) if res else None
+    wgt = torch.randn(N, C, H, W, device=DEV)
+    sep = FusedBatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        sep.weight.uniform_(0.5, 1.5)
+        sep.bias.uniform_(-0.5, 0.5)
+    grp = copy.deepcopy(sep)
+
+    xs, rs = x.clone().requires_grad_(True), (r.clone().requires_grad_(True) if res else None)
+    ys, lo = [], 0
+    for n in rows:
+        ys.append(sep(xs[lo:lo + n], residual=rs[lo:lo + n] if res else None, relu=relu))
+        lo += n
+    y_sep = torch.cat(ys)
+    (y_sep * wgt).sum().backward()
+
+    xg, rg = x.clone().requires_grad_(True), (r.clone().requires_grad_(True) if res else None)
+    with ops.bn_call_groups(rows):
+        y_grp = grp(xg, residual=rg, relu=relu)
+    (y_grp * wgt).sum().backward()
+
+    assert torch.equal(y_grp, y_sep)
+    assert torch.equal(xg.grad, xs.grad)
+    if res:
+        assert torch.equal(rg.grad, rs.grad)
+    assert torch.equal(grp.running_mean, sep.running_mean) and torch.equal(grp.running_var, sep.running_var)
+    assert int(grp.num_batches_tracked) == int(sep.num_batches_tracked) == len(rows)
+    assert _rel(grp.weight.grad, sep.weight.grad) < 1e-5 and _rel(grp.bias.grad, sep.bias.grad) < 1e-5
+
+
+@pytest.mark.gpu
+def test_batched_pose_pairs_equal_the_separate_calls():
+    """Trainer._pose_pairs: all pose-network calls of a step as ONE pass (call groups in every BatchNorm) give the poses
+    and the network gradients of the reference's separate calls."""
+    import types
+    from baseboostdepth_amd.trainer import Trainer
+    import bench
+    torch.manual_seed(3)
+    opt = bench.make_options(4, 0, "md2")
+    opt.height, opt.width = 64, 128
+    tr = Trainer(opt)
+    tr.set_train()
+    frames = [torch.rand(n, 3, 64, 128, device=DEV) for n in (4, 4, 3, 2, 3, 2)]
+    reqs = [(frames[0], frames[1], False), (frames[2], frames[4], True), (frames[3], frames[5], False)]
+    params = [p for k in ("pose_encoder", "pose") for p in tr.models[k].parameters()]
+    state = {k: {n: b.clone() for n, b in tr.models[k].named_buffers()} for k in ("pose_encoder", "pose")}
+
+    def run(batched):
+        for k in state:
+            for n, b in tr.models[k].named_buffers():
+                b.copy_(state[k][n])
+        for p in params:
+            p.grad = None
+        tr.opt.batched_pose = batched
+        Ts = tr._pose_pairs(reqs)
+        sum((T * T).sum() for T in Ts).backward()
+        return ([T.detach().clone() for T in Ts], [p.grad.clone() for p in params if p.grad is not None],
+                [b.clone() for b in tr.models["pose_encoder"].buffers()])
+
+    Ta, ga, ba = run(False)
+    Tb, gb, bb = run(True)
+    for a, b in zip(Ta, Tb):
+        assert float((a - b).abs().max()) < 1e-5, float((a - b).abs().max())
+    for a, b in zip(ba, bb):
+        assert _rel(a.float(), b.float()) < 1e-5
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-7
