@@ -61,6 +61,17 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// number of plane slices for a batch of N images (host: grid size for the largest group; device: each group's own, so
+// that a group is reduced exactly as a separate call on that sub-batch would reduce it)
+__host__ __device__ inline int pick_split(int N, int HW) {
+  long long per = (long long)N * HW;
+  int s = (int)((per + 4095) / 4096);
+  if (s < 1) s = 1;
+  if (s > MAX_SPLIT) s = MAX_SPLIT;
+  const int max_by_plane = (HW + 3) / 4;     // at least one float4 of the plane per slice
+  return s < max_by_plane ? s : max_by_plane;
+}
+
 // slice [lo, hi) of the HW plane owned by blockIdx.x (multiples of 4 when HW % 4 == 0)
 __device__ __forceinline__ void plane_slice(int HW, int split, int* lo, int* hi) {
   int len = (HW + split - 1) / split;
@@ -72,21 +83,26 @@ __device__ __forceinline__ void plane_slice(int HW, int split, int* lo, int* hi)
 __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
   __shared__ double sh[4];
   const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;      // the grid is sized for the largest group
   int lo, hi;
-  plane_slice(a.HW, a.split, &lo, &hi);
+  plane_slice(a.HW, split, &lo, &hi);
   float s = 0.0f, ss = 0.0f;
   double ds = 0.0, dss = 0.0;
   const bool vec = (a.HW & 3) == 0;
-  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
+  // thread layout: 64 lanes sweep the slice, the 4 waves take every 4th image - a slice is only ~100 float4 long, so
+  // 256 lanes along it left most of them idle with one dependent load per image in flight
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const float* p = a.x + ((size_t)n * a.C + c) * a.HW;
     if (vec) {
-      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+      for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
         const float4 v = *reinterpret_cast<const float4*>(p + i);
         s += (v.x + v.y) + (v.z + v.w);
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
     } else {
-      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+      for (int i = lo + lane; i < hi; i += 64) {
         const float v = p[i];
         s += v;
         ss += v * v;
@@ -105,7 +121,8 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
 // per-(channel, group) sums of the two partial columns written by the reduction kernels
 __device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, double* t0, double* t1) {
   double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < a.split; ++k) {
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  for (int k = 0; k < split; ++k) {
     s0 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2];
     s1 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2 + 1];
   }
@@ -115,6 +132,8 @@ __device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, do
 __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
   __shared__ float s_mean, s_scale, s_shift;
   const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;
   if (threadIdx.x == 0) {
     double ts, tss;
     group_totals(a, c, grp, &ts, &tss);
@@ -154,12 +173,13 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
   __syncthreads();
   const float mean = s_mean, scale = s_scale, shift = s_shift;
   int lo, hi;
-  plane_slice(a.HW, a.split, &lo, &hi);
+  plane_slice(a.HW, split, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
-  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;      // see bn_stats_kernel
+  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
-      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+      for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
         const float4 v = *reinterpret_cast<const float4*>(a.x + base + i);
         float4 o;
         o.x = (v.x - mean) * scale + shift; o.y = (v.y - mean) * scale + shift;
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
         *reinterpret_cast<float4*>(a.y + base + i) = o;
       }
     } else {
-      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+      for (int i = lo + lane; i < hi; i += 64) {
         float o = (a.x[base + i] - mean) * scale + shift;
         if (a.res) o += a.res[base + i];
         if (a.relu) o = o > 0.0f ? o : 0.0f;
@@ -188,19 +208,22 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
   __shared__ double sh[4];
   const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;
   int lo, hi;
-  plane_slice(a.HW, a.split, &lo, &hi);
+  plane_slice(a.HW, split, &lo, &hi);
   const float mean = a.mean[(size_t)grp * a.C + c], invstd = a.invstd[(size_t)grp * a.C + c];
   // ReLU mask without the saved output (no residual in the forward): bn_apply_kernel's own expression on x
   const bool remask = a.relu && a.y == nullptr;
   const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   double dg = 0.0, dgx = 0.0;
   const bool vec = (a.HW & 3) == 0;
-  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;      // see bn_stats_kernel
+  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     float sg = 0.0f, sgx = 0.0f;
     if (vec) {
-      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+      for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
         float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
         const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
         if (a.relu) {
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
                (g.z * ((x.z - mean) * invstd) + g.w * ((x.w - mean) * invstd));
       }
     } else {
-      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+      for (int i = lo + lane; i < hi; i += 64) {
         float g = a.dy[base + i];
         if (a.relu && !((remask ? (a.x[base + i] - mean) * scale + shift : a.y[base + i]) > 0.0f)) g = 0.0f;
         sg += g;
@@ -239,6 +262,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
   __shared__ float s_k[3];
   const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;
   if (threadIdx.x == 0) {
     double tg, tgx;
     group_totals(a, c, grp, &tg, &tgx);
@@ -263,12 +288,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
   const bool remask = a.relu && a.y == nullptr;
   const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   int lo, hi;
-  plane_slice(a.HW, a.split, &lo, &hi);
+  plane_slice(a.HW, split, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
-  for (int n = a.rows[grp]; n < a.rows[grp + 1]; ++n) {
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;      // see bn_stats_kernel
+  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
-      for (int i = lo + 4 * (int)threadIdx.x; i < hi; i += 4 * NT) {
+      for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
         float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
         const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
         if (a.relu) {
@@ -291,7 +317,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
         *reinterpret_cast<float4*>(a.dx + base + i) = o;
       }
     } else {
-      for (int i = lo + (int)threadIdx.x; i < hi; i += NT) {
+      for (int i = lo + lane; i < hi; i += 64) {
         float g = a.dy[base + i];
         if (a.relu && !((remask ? (a.x[base + i] - mean) * scale + shift : a.y[base + i]) > 0.0f)) g = 0.0f;
         if (a.dres) a.dres[base + i] = g;
@@ -716,15 +742,6 @@ __global__ __launch_bounds__(64) void dispconv_bwd_weight_final_kernel(const dou
     if (i < C * 9) gw[i] = (float)v;
     else if (gb) gb[0] = (float)v;
   }
-}
-
-int pick_split(int N, int HW) {
-  long long per = (long long)N * HW;
-  int s = (int)((per + 4095) / 4096);
-  if (s < 1) s = 1;
-  if (s > MAX_SPLIT) s = MAX_SPLIT;
-  const int max_by_plane = (HW + 3) / 4;     // at least one float4 of the plane per slice
-  return s < max_by_plane ? s : max_by_plane;
 }
 
 int status() {

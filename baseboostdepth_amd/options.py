@@ -46,6 +46,8 @@ _FLAGS = [
     ("--ViT", dict(action="store_true")), ("--mpvit_checkpoint", dict(type=str, default="./ckpt/mpvit_small.pth")),
     ("--materialize_warps", dict(action="store_true")), ("--synthetic", dict(action="store_true")),
     ("--step_graph", dict(action="store_true")), ("--loader_workers", dict(type=str, default="process", choices=["process", "thread"])),
+    # the step's pose-network calls as one batched pass with per-call BatchNorm statistics (default) or one by one
+    ("--separate_pose_calls", dict(dest="batched_pose", action="store_false")),
 ]
 # other zoos / datasets of the reference: parsed, refused when set
 _OUT_OF_SCOPE = ["--SYNS_eval", "--SQL", "--SQL_L", "--CA_depth", "--DIFFNet", "--chamfer", "--stereo_guide",

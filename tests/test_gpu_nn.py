@@ -257,8 +257,11 @@ def test_upsample_adjoint_matches_autograd_of_interpolate(B, H, W, smalls):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,res,relu", [([5, 3, 4], True, True), ([12, 12], False, True), ([1, 7, 2, 6], False, False)])
-def test_grouped_batch_norm_equals_separate_calls(rows, res, relu):
+@pytest.mark.parametrize("rows,res,relu,H,W", [([5, 3, 4], True, True, 12, 20), ([12, 12], False, True, 12, 20),
+                                                ([1, 7, 2, 6], False, False, 12, 20),
+                                                ([12, 2, 7], True, True, 48, 160),      # groups with different slice counts
+                                                ([3, 12], False, True, 31, 47)])       # HW % 4 != 0: scalar path
+def test_grouped_batch_norm_equals_separate_calls(rows, res, relu, H, W):
     """`ops.bn_call_groups`: one batched pass whose BatchNorm keeps its statistics per call group = the separate calls
     of the layer on the sub-batches (outputs, data gradients and running statistics bit for bit; parameter gradients
     to rounding - the separate calls' are added up by autograd in fp32, the grouped form sums in fp64)."""
@@ -266,7 +269,7 @@ def test_grouped_batch_norm_equals_separate_calls(rows, res, relu):
     from baseboostdepth_amd import ops
     from baseboostdepth_amd.networks.encoder import FusedBatchNorm2d
     torch.manual_seed(11)
-    C, H, W = 16, 12, 20
+    C = 16
     N = sum(rows)
     x = torch.randn(N, C, H, W, device=DEV) * 2 + 0.5
     r = torch.randn(N, C, H, W, device=DEV) if res else None
