@@ -160,7 +160,10 @@ def test_pose_stream_on_off_same_step(monkeypatch):
     l1, g1 = run("1")
     l0, g0 = run("0")
     assert abs(l1 - l0) < 1e-6
-    assert float((g1 - g0).abs().max()) < 1e-4 * float(g0.abs().max())
+    # run-to-run noise of MIOpen's split-K weight-gradient kernels (atomic accumulation; which solver runs depends on
+    # the performance database): 1.0e-4 of the maximum observed between two identical runs - a missing stream
+    # dependency shows up as O(1) differences
+    assert float((g1 - g0).abs().max()) < 5e-4 * float(g0.abs().max())
 
 
 def test_two_ranks_on_one_gpu_exchange_gradients():
