@@ -25,6 +25,9 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int MAX_SPLIT = 64;
+#ifndef BN_SMALL_ELEMS
+#define BN_SMALL_ELEMS 8192     // per (channel, call group): at or below this the two passes of a direction share one launch
+#endif
 
 struct BnArgs {
   const float* x;        // [N,C,HW] conv output
@@ -72,26 +75,29 @@ __host__ __device__ inline int pick_split(int N, int HW) {
   return s < max_by_plane ? s : max_by_plane;
 }
 
-// slice [lo, hi) of the HW plane owned by blockIdx.x (multiples of 4 when HW % 4 == 0)
-__device__ __forceinline__ void plane_slice(int HW, int split, int* lo, int* hi) {
+// slice k of `split` of the HW plane: [lo, hi), multiples of 4 when HW % 4 == 0
+__device__ __forceinline__ void plane_slice(int HW, int split, int k, int* lo, int* hi) {
   int len = (HW + split - 1) / split;
   len = (len + 3) & ~3;
-  *lo = blockIdx.x * len;
+  *lo = k * len;
   *hi = min(HW, *lo + len);
 }
 
-__global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
-  __shared__ double sh[4];
-  const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
-  if ((int)blockIdx.x >= split) return;      // the grid is sized for the largest group
+// The four passes below are written per (channel c, call group grp, plane slice k).  Large activations launch one
+// workgroup per slice and pass the per-slice sums through `part` (two launches per direction); small ones (a whole
+// (channel, group) fits one workgroup comfortably) run both passes in ONE launch, the workgroup looping over the same
+// slices and adding their block totals in the same order - identical numbers, half the launches, no partial round trip.
+// Thread layout: 64 lanes sweep the slice, the 4 waves take every 4th image - a slice is only ~100 float4 long, so 256
+// lanes along it left most of them idle with one dependent load per image in flight.
+
+// forward statistics of slice k: block totals of x and x^2
+__device__ __forceinline__ void stats_slice(const BnArgs& a, int c, int grp, int split, int k, double* sh, double* ts,
+                                            double* tss) {
   int lo, hi;
-  plane_slice(a.HW, split, &lo, &hi);
+  plane_slice(a.HW, split, k, &lo, &hi);
   float s = 0.0f, ss = 0.0f;
   double ds = 0.0, dss = 0.0;
   const bool vec = (a.HW & 3) == 0;
-  // thread layout: 64 lanes sweep the slice, the 4 waves take every 4th image - a slice is only ~100 float4 long, so
-  // 256 lanes along it left most of them idle with one dependent load per image in flight
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
   for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const float* p = a.x + ((size_t)n * a.C + c) * a.HW;
@@ -111,71 +117,45 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
     ds += (double)s; dss += (double)ss;     // short fp32 runs, fp64 across images
     s = 0.0f; ss = 0.0f;
   }
-  const double ts = block_sum(ds, sh), tss = block_sum(dss, sh);
-  if (threadIdx.x == 0) {
-    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2] = ts;
-    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2 + 1] = tss;
-  }
+  *ts = block_sum(ds, sh);
+  *tss = block_sum(dss, sh);
 }
 
-// per-(channel, group) sums of the two partial columns written by the reduction kernels
-__device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, double* t0, double* t1) {
-  double s0 = 0.0, s1 = 0.0;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
-  for (int k = 0; k < split; ++k) {
-    s0 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2];
-    s1 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2 + 1];
-  }
-  *t0 = s0; *t1 = s1;
+// mean / invstd of one (channel, group) from its totals
+__device__ __forceinline__ void group_moments(const BnArgs& a, int grp, double ts, double tss, double* mean, double* var) {
+  const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
+  *mean = ts / cnt;
+  double v = tss / cnt - (*mean) * (*mean);
+  *var = v > 0.0 ? v : 0.0;
 }
-
-__global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
-  __shared__ float s_mean, s_scale, s_shift;
-  const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
-  if ((int)blockIdx.x >= split) return;
-  if (threadIdx.x == 0) {
-    double ts, tss;
-    group_totals(a, c, grp, &ts, &tss);
-    const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
-    const double mean = ts / cnt;
-    double var = tss / cnt - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    s_mean = (float)mean;
-    s_scale = a.gamma[c] * invstd;
-    s_shift = a.beta[c];
-    if (blockIdx.x == 0) {
-      a.mean[(size_t)grp * a.C + c] = (float)mean;
-      a.invstd[(size_t)grp * a.C + c] = invstd;
-      if (grp == 0) {
-        // running statistics: one momentum update per group, in group order = the order of the calls replaced
-        if (a.run_mean) {
-          float rm = a.run_mean[c], rv = a.run_var[c];
-          for (int q = 0; q < a.G; ++q) {
-            double qs, qss;
-            group_totals(a, c, q, &qs, &qss);
-            const double qcnt = (double)(a.rows[q + 1] - a.rows[q]) * (double)a.HW;
-            const double qmean = qs / qcnt;
-            double qvar = qss / qcnt - qmean * qmean;
-            qvar = qvar > 0.0 ? qvar : 0.0;
-            const double unbiased = qcnt > 1.0 ? qvar * qcnt / (qcnt - 1.0) : qvar;
-            rm = (1.0f - a.momentum) * rm + a.momentum * (float)qmean;
-            rv = (1.0f - a.momentum) * rv + a.momentum * (float)unbiased;
-          }
-          a.run_mean[c] = rm;
-          a.run_var[c] = rv;
-        }
-        if (a.batches && c == 0) *a.batches += a.G;
-      }
+// running statistics: one momentum update per group, in group order = the order of the calls replaced.
+// totals(q, &s, &ss) yields group q's sums.
+template <typename Totals>
+__device__ __forceinline__ void update_running(const BnArgs& a, int c, Totals totals) {
+  if (a.run_mean) {
+    float rm = a.run_mean[c], rv = a.run_var[c];
+    for (int q = 0; q < a.G; ++q) {
+      double qs, qss, qmean, qvar;
+      totals(q, &qs, &qss);
+      group_moments(a, q, qs, qss, &qmean, &qvar);
+      const double qcnt = (double)(a.rows[q + 1] - a.rows[q]) * (double)a.HW;
+      const double unbiased = qcnt > 1.0 ? qvar * qcnt / (qcnt - 1.0) : qvar;
+      rm = (1.0f - a.momentum) * rm + a.momentum * (float)qmean;
+      rv = (1.0f - a.momentum) * rv + a.momentum * (float)unbiased;
     }
+    a.run_mean[c] = rm;
+    a.run_var[c] = rv;
   }
-  __syncthreads();
-  const float mean = s_mean, scale = s_scale, shift = s_shift;
+  if (a.batches && c == 0) *a.batches += a.G;
+}
+
+// forward apply of slice k
+__device__ __forceinline__ void apply_slice(const BnArgs& a, int c, int grp, int split, int k, float mean, float scale,
+                                            float shift) {
   int lo, hi;
-  plane_slice(a.HW, split, &lo, &hi);
+  plane_slice(a.HW, split, k, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
-  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;      // see bn_stats_kernel
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
   for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
@@ -205,20 +185,18 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
   }
 }
 
-__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
-  __shared__ double sh[4];
-  const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
-  if ((int)blockIdx.x >= split) return;
+// backward reduction of slice k: block totals of g = dy * (y > 0) and g * xhat
+__device__ __forceinline__ void bwd_reduce_slice(const BnArgs& a, int c, int grp, int split, int k, double* sh, double* tg,
+                                                 double* tgx) {
   int lo, hi;
-  plane_slice(a.HW, split, &lo, &hi);
+  plane_slice(a.HW, split, k, &lo, &hi);
   const float mean = a.mean[(size_t)grp * a.C + c], invstd = a.invstd[(size_t)grp * a.C + c];
-  // ReLU mask without the saved output (no residual in the forward): bn_apply_kernel's own expression on x
+  // ReLU mask without the saved output (no residual in the forward): apply_slice's own expression on x
   const bool remask = a.relu && a.y == nullptr;
   const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
   double dg = 0.0, dgx = 0.0;
   const bool vec = (a.HW & 3) == 0;
-  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;      // see bn_stats_kernel
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
   for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     float sg = 0.0f, sgx = 0.0f;
@@ -252,7 +230,111 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
     dg += (double)sg;
     dgx += (double)sgx;
   }
-  const double tg = block_sum(dg, sh), tgx = block_sum(dgx, sh);
+  *tg = block_sum(dg, sh);
+  *tgx = block_sum(dgx, sh);
+}
+
+// backward apply of slice k
+__device__ __forceinline__ void bwd_apply_slice(const BnArgs& a, int c, int grp, int split, int k, float mg, float mgx,
+                                                float kk) {
+  const float mean = a.mean[(size_t)grp * a.C + c], invstd = a.invstd[(size_t)grp * a.C + c];
+  const bool remask = a.relu && a.y == nullptr;
+  const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
+  int lo, hi;
+  plane_slice(a.HW, split, k, &lo, &hi);
+  const bool vec = (a.HW & 3) == 0;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
+    const size_t base = ((size_t)n * a.C + c) * a.HW;
+    if (vec) {
+      for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
+        float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
+        const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
+        if (a.relu) {
+          float4 y;
+          if (remask) {
+            y.x = (x.x - mean) * scale + shift; y.y = (x.y - mean) * scale + shift;
+            y.z = (x.z - mean) * scale + shift; y.w = (x.w - mean) * scale + shift;
+          } else {
+            y = *reinterpret_cast<const float4*>(a.y + base + i);
+          }
+          g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f;
+          g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
+        }
+        if (a.dres) *reinterpret_cast<float4*>(a.dres + base + i) = g;
+        float4 o;
+        o.x = kk * (g.x - mg - ((x.x - mean) * invstd) * mgx);
+        o.y = kk * (g.y - mg - ((x.y - mean) * invstd) * mgx);
+        o.z = kk * (g.z - mg - ((x.z - mean) * invstd) * mgx);
+        o.w = kk * (g.w - mg - ((x.w - mean) * invstd) * mgx);
+        *reinterpret_cast<float4*>(a.dx + base + i) = o;
+      }
+    } else {
+      for (int i = lo + lane; i < hi; i += 64) {
+        float g = a.dy[base + i];
+        if (a.relu && !((remask ? (a.x[base + i] - mean) * scale + shift : a.y[base + i]) > 0.0f)) g = 0.0f;
+        if (a.dres) a.dres[base + i] = g;
+        a.dx[base + i] = kk * (g - mg - ((a.x[base + i] - mean) * invstd) * mgx);
+      }
+    }
+  }
+}
+
+// per-(channel, group) sums of the two partial columns written by the two-launch reduction kernels
+__device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, double* t0, double* t1) {
+  double s0 = 0.0, s1 = 0.0;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  for (int k = 0; k < split; ++k) {
+    s0 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2];
+    s1 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2 + 1];
+  }
+  *t0 = s0; *t1 = s1;
+}
+
+// ---- two launches per direction: grid (slices of the largest group, C, G)
+__global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;      // the grid is sized for the largest group
+  double ts, tss;
+  stats_slice(a, c, grp, split, blockIdx.x, sh, &ts, &tss);
+  if (threadIdx.x == 0) {
+    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2] = ts;
+    a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2 + 1] = tss;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
+  __shared__ float s_mean, s_scale, s_shift;
+  const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;
+  if (threadIdx.x == 0) {
+    double ts, tss, mean, var;
+    group_totals(a, c, grp, &ts, &tss);
+    group_moments(a, grp, ts, tss, &mean, &var);
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    s_mean = (float)mean;
+    s_scale = a.gamma[c] * invstd;
+    s_shift = a.beta[c];
+    if (blockIdx.x == 0) {
+      a.mean[(size_t)grp * a.C + c] = (float)mean;
+      a.invstd[(size_t)grp * a.C + c] = invstd;
+      if (grp == 0) update_running(a, c, [&](int q, double* s0, double* s1) { group_totals(a, c, q, s0, s1); });
+    }
+  }
+  __syncthreads();
+  apply_slice(a, c, grp, split, blockIdx.x, s_mean, s_scale, s_shift);
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  if ((int)blockIdx.x >= split) return;
+  double tg, tgx;
+  bwd_reduce_slice(a, c, grp, split, blockIdx.x, sh, &tg, &tgx);
   if (threadIdx.x == 0) {
     a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2] = tg;
     a.part[(((size_t)c * a.G + grp) * a.split + blockIdx.x) * 2 + 1] = tgx;
@@ -283,48 +365,88 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
     }
   }
   __syncthreads();
-  const float mg = s_k[0], mgx = s_k[1], k = s_k[2];
-  const float mean = a.mean[(size_t)grp * a.C + c], invstd = a.invstd[(size_t)grp * a.C + c];
-  const bool remask = a.relu && a.y == nullptr;
-  const float scale = remask ? a.gamma[c] * invstd : 0.0f, shift = remask ? a.beta[c] : 0.0f;
-  int lo, hi;
-  plane_slice(a.HW, split, &lo, &hi);
-  const bool vec = (a.HW & 3) == 0;
-  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;      // see bn_stats_kernel
-  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
-    const size_t base = ((size_t)n * a.C + c) * a.HW;
-    if (vec) {
-      for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
-        float4 g = *reinterpret_cast<const float4*>(a.dy + base + i);
-        const float4 x = *reinterpret_cast<const float4*>(a.x + base + i);
-        if (a.relu) {
-          float4 y;
-          if (remask) {
-            y.x = (x.x - mean) * scale + shift; y.y = (x.y - mean) * scale + shift;
-            y.z = (x.z - mean) * scale + shift; y.w = (x.w - mean) * scale + shift;
-          } else {
-            y = *reinterpret_cast<const float4*>(a.y + base + i);
-          }
-          g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f;
-          g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
-        }
-        if (a.dres) *reinterpret_cast<float4*>(a.dres + base + i) = g;
-        float4 o;
-        o.x = k * (g.x - mg - ((x.x - mean) * invstd) * mgx);
-        o.y = k * (g.y - mg - ((x.y - mean) * invstd) * mgx);
-        o.z = k * (g.z - mg - ((x.z - mean) * invstd) * mgx);
-        o.w = k * (g.w - mg - ((x.w - mean) * invstd) * mgx);
-        *reinterpret_cast<float4*>(a.dx + base + i) = o;
-      }
+  bwd_apply_slice(a, c, grp, split, blockIdx.x, s_k[0], s_k[1], s_k[2]);
+}
+
+// ---- one launch per direction for small activations: grid (1, C, G), the workgroup owns its whole (channel, group).
+// `part` then holds one (total, total) pair per (channel, group): [C][G][2].  With more than one group the
+// cross-group results (running statistics; parameter gradients) come from a C-thread follow-up launch.
+__global__ __launch_bounds__(NT) void bn_fwd_small_kernel(BnArgs a) {
+  __shared__ double sh[4];
+  __shared__ float s_mean, s_scale, s_shift;
+  const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  double ts = 0.0, tss = 0.0;
+  for (int k = 0; k < split; ++k) {          // the same slices, added in the same order, as the two-launch form
+    double ks, kss;
+    stats_slice(a, c, grp, split, k, sh, &ks, &kss);
+    ts += ks; tss += kss;
+  }
+  if (threadIdx.x == 0) {
+    double mean, var;
+    group_moments(a, grp, ts, tss, &mean, &var);
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    s_mean = (float)mean;
+    s_scale = a.gamma[c] * invstd;
+    s_shift = a.beta[c];
+    a.mean[(size_t)grp * a.C + c] = (float)mean;
+    a.invstd[(size_t)grp * a.C + c] = invstd;
+    if (a.G == 1) {
+      update_running(a, c, [&](int, double* s0, double* s1) { *s0 = ts; *s1 = tss; });
     } else {
-      for (int i = lo + lane; i < hi; i += 64) {
-        float g = a.dy[base + i];
-        if (a.relu && !((remask ? (a.x[base + i] - mean) * scale + shift : a.y[base + i]) > 0.0f)) g = 0.0f;
-        if (a.dres) a.dres[base + i] = g;
-        a.dx[base + i] = k * (g - mg - ((a.x[base + i] - mean) * invstd) * mgx);
-      }
+      a.part[((size_t)c * a.G + grp) * 2] = ts;
+      a.part[((size_t)c * a.G + grp) * 2 + 1] = tss;
     }
   }
+  __syncthreads();
+  for (int k = 0; k < split; ++k) apply_slice(a, c, grp, split, k, s_mean, s_scale, s_shift);
+}
+__global__ __launch_bounds__(64) void bn_running_small_kernel(BnArgs a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.C) return;
+  update_running(a, c, [&](int q, double* s0, double* s1) {
+    *s0 = a.part[((size_t)c * a.G + q) * 2];
+    *s1 = a.part[((size_t)c * a.G + q) * 2 + 1];
+  });
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_small_kernel(BnArgs a) {
+  __shared__ double sh[4];
+  __shared__ float s_k[3];
+  const int c = blockIdx.y, grp = blockIdx.z;
+  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  double tg = 0.0, tgx = 0.0;
+  for (int k = 0; k < split; ++k) {
+    double kg, kgx;
+    bwd_reduce_slice(a, c, grp, split, k, sh, &kg, &kgx);
+    tg += kg; tgx += kgx;
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
+    s_k[0] = (float)(tg / cnt);
+    s_k[1] = (float)(tgx / cnt);
+    s_k[2] = a.gamma[c] * a.invstd[(size_t)grp * a.C + c];
+    if (a.G == 1) {
+      a.dgamma[c] = (float)tgx;
+      a.dbeta[c] = (float)tg;
+    } else {
+      a.part[((size_t)c * a.G + grp) * 2] = tg;
+      a.part[((size_t)c * a.G + grp) * 2 + 1] = tgx;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < split; ++k) bwd_apply_slice(a, c, grp, split, k, s_k[0], s_k[1], s_k[2]);
+}
+__global__ __launch_bounds__(64) void bn_param_grad_small_kernel(BnArgs a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int q = 0; q < a.G; ++q) {            // group order, like bn_bwd_apply_kernel
+    sg += a.part[((size_t)c * a.G + q) * 2];
+    sgx += a.part[((size_t)c * a.G + q) * 2 + 1];
+  }
+  a.dgamma[c] = (float)sgx;
+  a.dbeta[c] = (float)sg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -788,6 +910,12 @@ int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* g
   a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.batches = num_batches_tracked; a.N = N; a.C = C; a.HW = HW;
   a.split = pick_split(biggest, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((long long)biggest * HW <= BN_SMALL_ELEMS) {       // one launch (+ a C-thread one for the cross-group results)
+    hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(1, (unsigned)C, (unsigned)G), dim3(NT), 0, st, a);
+    if (G > 1 && (running_mean || num_batches_tracked))
+      hipLaunchKernelGGL(bn_running_small_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, a);
+    return status();
+  }
   const dim3 grid((unsigned)a.split, (unsigned)C, (unsigned)G);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(NT), 0, st, a);
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, st, a);
@@ -808,6 +936,11 @@ int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, 
   a.invstd = const_cast<float*>(save_invstd); a.dx = grad_x; a.dres = grad_residual; a.dgamma = grad_gamma;
   a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.split = pick_split(biggest, HW); a.relu = relu;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((long long)biggest * HW <= BN_SMALL_ELEMS) {
+    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, (unsigned)C, (unsigned)G), dim3(NT), 0, st, a);
+    if (G > 1) hipLaunchKernelGGL(bn_param_grad_small_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, a);
+    return status();
+  }
   const dim3 grid((unsigned)a.split, (unsigned)C, (unsigned)G);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);

@@ -25,10 +25,7 @@ inputs.pop("noise")
 if cfg != "md2":
     inputs["cutt"] = torch.tensor(1.35)
 for _ in range(steps):
-    outputs, losses = tr.process_batch(inputs)
-    tr.model_optimizer.zero_grad()
-    losses["loss"].backward()
-    tr.model_optimizer.step()
+    outputs, losses = tr.train_step(dict(inputs))
 arg = outputs[("bbd", "argmin")].cpu().numpy()
 names = [[list(n) for n in row] for row in tr.plan.cand_names]
 np.savez_compressed(out, argmin=arg, names=np.array(repr(names)))
