@@ -74,26 +74,31 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restri
     if (w0 + q < W) yo[(long)q * y_row] = acc[q];
 }
 
-// Weight / bias gradient.  Stage 1: one thread per (row segment of WCH pixels, channel) accumulates its
-// k*k + 1 partial sums, sliding the k-wide window of x through registers; stage 2 / 3: column sums of the
-// partial matrix [segments, C*(k*k+1)] in two fixed-order passes (fp64 in the last) - deterministic.
+// Weight / bias gradient.  Stage 1: one thread per (run of `spt` consecutive row segments of WCH pixels, channel)
+// accumulates its k*k + 1 partial sums, sliding the k-wide window of x through registers (spt = 1..8 by problem size:
+// the partial matrix is what this pipeline moves through HBM, 147 MB for MPViT-small's 7x7 layer at spt = 1); stage
+// 2 / 3: column sums of the partial matrix [segment runs, C*(k*k+1)] in two fixed-order passes (fp64 in the last,
+// four row lanes per column) - deterministic.
 constexpr int WCH = 8;
 template <int K>
 __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __restrict__ x, int x_row,
                                                                  const float* __restrict__ dy, int dy_row,
-                                                                 float* __restrict__ partial, int B, int H, int W, int C) {
+                                                                 float* __restrict__ partial, int B, int H, int W, int C,
+                                                                 int spt) {
   constexpr int P = K / 2;
   const int wseg = (W + WCH - 1) / WCH;
+  const long segs = (long)B * H * wseg, runs = (segs + spt - 1) / spt;
   const long id = (long)blockIdx.x * NT + threadIdx.x;
-  if (id >= (long)B * H * wseg * C) return;
+  if (id >= runs * C) return;
   const int c = (int)(id % C);
-  const long seg = id / C;
-  const int w0 = (int)(seg % wseg) * WCH;
-  const int bh = (int)(seg / wseg);
-  const int h = bh % H, b = bh / H;
+  const long run = id / C;
   float acc[K * K + 1];
 #pragma unroll
   for (int i = 0; i <= K * K; ++i) acc[i] = 0.0f;
+  for (long seg = run * spt; seg < min(segs, (run + 1) * spt); ++seg) {
+  const int w0 = (int)(seg % wseg) * WCH;
+  const int bh = (int)(seg / wseg);
+  const int h = bh % H, b = bh / H;
   float g[WCH];
   const float* dr = dy + ((long)bh * W + w0) * dy_row + c;
 #pragma unroll
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __
 #pragma unroll
       for (int q = 0; q < WCH; ++q) acc[i * K + j] = fmaf(g[q], win[q + j], acc[i * K + j]);
   }
-  float* po = partial + (seg * C + c) * (K * K + 1);
+  }
+  float* po = partial + (run * C + c) * (K * K + 1);
 #pragma unroll
   for (int i = 0; i <= K * K; ++i) po[i] = acc[i];
 }
@@ -133,16 +139,27 @@ __global__ __launch_bounds__(NT) void colsum_stage_kernel(const float* __restric
   out[(long)blockIdx.y * cols + col] = s;
 }
 
+// column sums with RL row lanes per column: block = 64 columns x RL rows, fixed-order combine through LDS
+constexpr int RL = NT / 64;
 __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
                                                                        float* __restrict__ dw, float* __restrict__ dbias,
                                                                        int rows, int C, int kk) {
-  const int id = blockIdx.x * NT + threadIdx.x;
-  if (id >= C * (kk + 1)) return;
-  const int c = id / (kk + 1), t = id - c * (kk + 1);
+  __shared__ double sh[RL][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int id = blockIdx.x * 64 + cl;
+  const bool live = id < C * (kk + 1);
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partial[(long)r * C * (kk + 1) + id];
-  if (t < kk) dw[c * kk + t] = (float)s;
-  else if (dbias) dbias[c] = (float)s;
+  if (live)
+    for (int r = rl; r < rows; r += RL) s += (double)partial[(long)r * C * (kk + 1) + id];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (!live || rl != 0) return;
+  double t = sh[0][cl];
+#pragma unroll
+  for (int q = 1; q < RL; ++q) t += sh[q][cl];
+  const int c = id / (kk + 1), tap = id - c * (kk + 1);
+  if (tap < kk) dw[c * kk + tap] = (float)t;
+  else if (dbias) dbias[c] = (float)t;
 }
 
 constexpr int WGRAD_STAGE_ROWS = 64;
@@ -182,20 +199,37 @@ __global__ __launch_bounds__(NT) void fa_kstats_kernel(const float* __restrict__
 __global__ __launch_bounds__(NT) void fa_kstats_combine_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
                                                                float* __restrict__ kmax, float* __restrict__ krsum,
                                                                int nseg, int C, int total) {
-  const int id = blockIdx.x * NT + threadIdx.x;
-  if (id >= total) return;
-  const int b = id / C, c = id - b * C;
+  // 64 (sample, channel) columns x RL segment lanes per workgroup (one thread per column looping over ~90 segments in
+  // 3-14 workgroups took 30 us per call); fixed-order combine through LDS
+  __shared__ float sh[RL][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int id = blockIdx.x * 64 + cl;
+  const bool live = id < total;
+  const int b = live ? id / C : 0, c = live ? id - b * C : 0;
   float m = -INFINITY;
-  for (int s = 0; s < nseg; ++s) m = fmaxf(m, pm[((long)b * nseg + s) * C + c]);
+  if (live)
+    for (int s = rl; s < nseg; s += RL) m = fmaxf(m, pm[((long)b * nseg + s) * C + c]);
+  sh[rl][cl] = m;
+  __syncthreads();
+  m = sh[0][cl];
+#pragma unroll
+  for (int q = 1; q < RL; ++q) m = fmaxf(m, sh[q][cl]);
+  __syncthreads();
   float sum = 0.0f;
-  for (int s = 0; s < nseg; ++s) {
-    const float sm = ps[((long)b * nseg + s) * C + c];
-    if (sm > 0.0f) sum += sm * __expf(pm[((long)b * nseg + s) * C + c] - m);
-  }
+  if (live)
+    for (int s = rl; s < nseg; s += RL) {
+      const float sm = ps[((long)b * nseg + s) * C + c];
+      if (sm > 0.0f) sum += sm * __expf(pm[((long)b * nseg + s) * C + c] - m);
+    }
+  sh[rl][cl] = sum;
+  __syncthreads();
+  if (!live || rl != 0) return;
+  sum = sh[0][cl];
+#pragma unroll
+  for (int q = 1; q < RL; ++q) sum += sh[q][cl];
   kmax[id] = m;
   krsum[id] = 1.0f / sum;
 }
-
 // partial[b, seg, o] = sum over the segment's tokens of A[n, hk(o)] * Bm[n, hv(o)],  o = (h, kc, vc) flattened.
 // SOFTMAX: A = exp(k - kmax) * krsum (the softmax over tokens), Bm = v      -> forward contexts
 // else   : A = q,                                               Bm = dout   -> their gradient
@@ -252,11 +286,20 @@ __global__ __launch_bounds__(NT) void fa_context_kernel(const float* __restrict_
 // ctx[b, o] = scale * sum_seg partial[b, seg, o]   (fixed order)
 __global__ __launch_bounds__(NT) void fa_context_reduce_kernel(const float* __restrict__ partial, float* __restrict__ ctx,
                                                                int nseg, int nout, int total, float scale) {
-  const int id = blockIdx.x * NT + threadIdx.x;
-  if (id >= total) return;
-  const int b = id / nout, o = id - b * nout;
+  __shared__ float sh[RL][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int id = blockIdx.x * 64 + cl;
+  const bool live = id < total;
+  const int b = live ? id / nout : 0, o = live ? id - b * nout : 0;
   float s = 0.0f;
-  for (int g = 0; g < nseg; ++g) s += partial[((long)b * nseg + g) * nout + o];
+  if (live)
+    for (int g = rl; g < nseg; g += RL) s += partial[((long)b * nseg + g) * nout + o];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (!live || rl != 0) return;
+  s = sh[0][cl];
+#pragma unroll
+  for (int q = 1; q < RL; ++q) s += sh[q][cl];
   ctx[id] = s * scale;
 }
 
@@ -402,18 +445,22 @@ int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int 
   if (!x || !grad_y || !partial || !grad_weight || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BBD_E_BADARG;
   if (k != 3 && k != 5 && k != 7) return BBD_E_BADARG;
   const long segs = (long)B * H * ((W + WCH - 1) / WCH);
-  const long total = segs * C;
+  // consecutive segments per thread: as many as keep >= 512 workgroups in flight, at most 8
+  long spt_l = segs * C / ((long)NT * 512);
+  const int spt = (int)(spt_l < 1 ? 1 : (spt_l > 8 ? 8 : spt_l));
+  const long runs = (segs + spt - 1) / spt;
+  const long total = runs * C;
   const dim3 grid((unsigned)((total + NT - 1) / NT));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<3>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
-  else if (k == 5) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<5>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
-  else hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<7>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
+  if (k == 3) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<3>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C, spt);
+  else if (k == 5) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<5>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C, spt);
+  else hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<7>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C, spt);
   const int cols = C * (k * k + 1);
-  float* stage = partial + segs * cols;
-  const int srows = segs < WGRAD_STAGE_ROWS ? (int)segs : WGRAD_STAGE_ROWS;
+  float* stage = partial + runs * cols;
+  const int srows = runs < WGRAD_STAGE_ROWS ? (int)runs : WGRAD_STAGE_ROWS;
   hipLaunchKernelGGL(colsum_stage_kernel, dim3((unsigned)((cols + NT - 1) / NT), (unsigned)srows), dim3(NT), 0, st, partial,
-                     stage, segs, cols);
-  hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + NT - 1) / NT)), dim3(NT), 0, st, stage,
+                     stage, runs, cols);
+  hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(NT), 0, st, stage,
                      grad_weight, grad_bias, srows, C, k * k);
   return launch_status();
 }
@@ -433,11 +480,11 @@ int bbd_factor_att_fwd(const float* qkv, const float* convv, float* kmax, float*
   float* ps = pm + (long)B * nseg * C;            // [B, nseg, C]
   float* part = ps + (long)B * nseg * C;          // [B, nseg, C*Ch]
   hipLaunchKernelGGL(fa_kstats_kernel, dim3(nseg, B), dim3(NT), 0, st, qkv, pm, ps, N, C, seg_tokens);
-  hipLaunchKernelGGL(fa_kstats_combine_kernel, dim3((unsigned)((B * C + NT - 1) / NT)), dim3(NT), 0, st, pm, ps, kmax,
+  hipLaunchKernelGGL(fa_kstats_combine_kernel, dim3((unsigned)((B * C + 63) / 64)), dim3(NT), 0, st, pm, ps, kmax,
                      krsum, nseg, C, B * C);
   fa_launch_context<true>(dim3(nseg, B), (size_t)2 * FA_TOK * C * sizeof(float), st, qkv, qkv + 2 * C, 3 * C, kmax, krsum,
                           part, N, C, Ch, seg_tokens);
-  hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + NT - 1) / NT)), dim3(NT), 0, st, part,
+  hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + 63) / 64)), dim3(NT), 0, st, part,
                      ctxs, nseg, nout, B * nout, (float)scale);
   const int tpb = 8;
   hipLaunchKernelGGL(fa_apply_kernel, dim3((unsigned)((N + tpb - 1) / tpb), B), dim3(NT),
@@ -461,7 +508,7 @@ int bbd_factor_att_bwd(const float* qkv, const float* convv, const float* kmax, 
   float* part = scratch + 2L * B * nseg * C;
   fa_launch_context<false>(dim3(nseg, B), (size_t)2 * FA_TOK * C * sizeof(float), st, qkv, grad_out, C, kmax, krsum, part,
                            N, C, Ch, seg_tokens);
-  hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + NT - 1) / NT)), dim3(NT), 0, st, part,
+  hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + 63) / 64)), dim3(NT), 0, st, part,
                      dctx, nseg, nout, B * nout, (float)scale);
   const int tpb = 8, Chp = Ch | 1;
   const size_t lds = (size_t)(2 * C * Chp + C + 3 * tpb * C) * sizeof(float);
