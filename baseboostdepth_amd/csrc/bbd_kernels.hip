@@ -538,7 +538,7 @@ struct FwdArgs {
 };
 
 #ifndef BBD_FWD_WAVES
-#define BBD_FWD_WAVES 3   // 168 VGPRs: the kernel sits right at this line; 2 waves/SIMD is 15 % slower
+#define BBD_FWD_WAVES 3   // <= 168 VGPRs (154 used since the pose rows moved to SGPRs); 2 waves/SIMD is 15 % slower
 #endif
 #ifdef BBD_FWD_VGPR
 #define BBD_FWD_ATTR __attribute__((amdgpu_num_vgpr(BBD_FWD_VGPR)))
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   float mu_y[3][PPT], sg_y[3][PPT];
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
 
-  // (register budget: this kernel sits on the 168-VGPR line of 3 waves per SIMD - the four arg-min ids share one
+  // (register budget: this kernel sat on the 168-VGPR line of 3 waves per SIMD, 154 now - the four arg-min ids share one
   // word and the identity noise is fetched where an identity candidate needs it, not held across the loop)
   float best[PPT];
   unsigned argw = 0u;
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 }
 
 #ifndef BBD_BWD2_WGS
-#define BBD_BWD2_WGS 4   // waves per SIMD (HIP: second __launch_bounds__ argument): 128 VGPRs.
+#define BBD_BWD2_WGS 4   // waves per SIMD (HIP: second __launch_bounds__ argument): <= 128 VGPRs (120 used).
                          // History (profiles/r02): with the heavier mid-round kernel 3, 4 and 5 waves per SIMD ran within 1 %
                          // (bwd_variants_narrow_tile.txt) and 4 cost 15 spilled registers (scratch doubled the launch's HBM
                          // bytes); after the instruction diet (unguarded recompute, reduce-scatter, no SLP packing) the
