@@ -196,6 +196,24 @@ def test_two_ranks_split_graph_step_matches_eager_data_parallel():
     assert "DDP_GRAPH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
+def test_bench_two_ranks_sharing_this_gpu_print_one_split_graph_line():
+    """`python bench.py --gpus 2` end to end (self-launch, rendezvous, split-graph data-parallel loop, max over ranks, ONE
+    JSON line from rank 0), with both ranks on this GPU and gloo standing in for RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBD_DIST_BACKEND="gloo", BBD_SHARE_GPU0="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["collective"] == "gloo" and line["value"] > 0
+    assert line["config"]["global_batch"] == 4 and str(line["step_graph"]).startswith("split")
+
+
 def test_step_graph_replay_matches_eager():
     """Opt-in whole-step hipGraph (`opt.step_graph`): capture after an eager warm-up that must NOT train
     (parameters, BatchNorm buffers, Adam state and the step counter are restored), then every batch with
