@@ -18,7 +18,7 @@ MAX_CAND = 20
 POSE_STRIDE = 40
 PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

@@ -18,6 +18,7 @@
 // Arithmetic lives in bbd_math.h and is shared with the host port used by the CPU tests.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/bbd_hip.h"
 #include "bbd_math.h"
@@ -127,6 +128,17 @@ __device__ __forceinline__ TileCoord decode_tile(int t, int W) {
   return c;
 }
 
+// XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, Workgroup dispatch):
+// blocks b and b + 8 share an XCD and its 4 MiB L2.  The work items of these kernels are ordered sample-major -> scale
+// -> tile, and neighbouring tiles (and the scales of a sample) gather from the same source-image rows, so the items are
+// re-dealt such that each XCD walks ONE contiguous range of them: its L2 then serves the halo / parallax overlap of
+// neighbouring tiles instead of the Infinity Cache.  Bijective for every grid size (cdna_hip_programming.md T1); a pure
+// speed choice - any placement computes the same result.
+__device__ __forceinline__ int xcd_work_item(int bid, int n) {
+  const int q = n >> 3, r = n & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 // Strip owned by a thread: row ly, first tile-local column lx0 (rotated by the row, see header).
 __device__ __forceinline__ void strip_of_thread(int* ly, int* lx0) {
   const int r = threadIdx.x / SPR;
@@ -180,12 +192,8 @@ struct Cells {
 // and the 21 pose values in VGPRs (profiles/r02/phase_stamps_final.txt: 6.3k + 4.3k of 64k ticks per workgroup).
 template <typename T>
 __device__ __forceinline__ T uniform_load(const T* p) {
-#if defined(BBD_PLAIN_TABLE_LOADS)     // timing A/B only: round 1's form
-  return *p;
-#else
   typedef const __attribute__((address_space(4))) T* const_ptr;
   return *(const_ptr)p;
-#endif
 }
 __device__ __forceinline__ bbd_cand_t load_cand(const bbd_cand_t* p) {     // one s_load_dwordx4
   typedef int v4i __attribute__((ext_vector_type(4)));
@@ -284,14 +292,6 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
   float pj[21];
 #pragma unroll
   for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
-#if defined(BBD_ABLATE_WARP)          // timing experiment only: no projection, no gathers
-#pragma unroll
-  for (int k = 0; k < CellsT::N; ++k) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) s[ch][cl.lds[k]] = d[k] + pj[ch];
-  }
-  return;
-#endif
   // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
   // its gathers are in flight together (6 x 8-byte loads per cell), then the blends.  The batch
   // size trades loads in flight against VGPRs (occupancy): measured best at 3 cells for the forward
@@ -311,11 +311,9 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
         sm.clipx = (int)(bx >> 31);
         sm.clipy = (int)(by >> 31);
       } else {
-#if !defined(BBD_BWD_GUARDED)
         if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
         else
-#endif
-        bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+          bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
         if (COORDS == 1 && coords != nullptr && k0 + kk < CellsT::N && cl.own(k)) coords[cl.pix(k, dm.W)] = pack_coords(sm);
       }
       bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
@@ -326,12 +324,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
     for (int kk = 0; kk < BATCH; ++kk)
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-#if defined(BBD_ABLATE_GATHER)        // timing experiment only: coalesced loads instead of gathers
-        const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-        v[kk][ch][0] = v[kk][ch][1] = v[kk][ch][2] = v[kk][ch][3] = src[ch * hw + cl.pix(k, dm.W)];
-#else
         bbd_fetch4(src + ch * hw, &t[kk], v[kk][ch]);
-#endif
       }
 #pragma unroll
     for (int kk = 0; kk < BATCH; ++kk) {
@@ -368,20 +361,11 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
 template <int STRIDE>
 __device__ __forceinline__ void load_window(const float* plane, int r0, int c0, float win[3][8]) {
   static_assert(STRIDE % 4 == 0, "rows must stay 16-byte aligned");
-  // index in float4 units so the compiler keeps the 16-byte alignment and emits ds_read_b128
-  // hipcc narrows these loads to the 6 columns that are used and re-pairs them (ds_read_b128 + ds_read2_b32 /
-  // ds_read_b64).  -DBBD_WINDOW_WHOLE forces both halves to stay whole 16-byte reads (volatile, explicit LDS
-  // address space); measured A/B (profiles/r02/lds_window_ab.txt): identical SQ_LDS_BANK_CONFLICT (7.4 % of
-  // the forward's LDS cycles either way) and SQ_LDS_IDX_ACTIVE, and the forced form is 8 % SLOWER (register
-  // pressure / load ordering) - so the compiler's pairing stays the default.
+  // index in float4 units so the compiler keeps the 16-byte alignment and emits ds_read_b128.  hipcc narrows these
+  // loads to the 6 columns that are used and re-pairs them (ds_read_b128 + ds_read2_b32 / ds_read_b64); forcing whole
+  // 16-byte reads changed no LDS counter and was 8 % slower (profiles/r02/lds_window_ab_*.txt).
   typedef float v4f __attribute__((ext_vector_type(4)));
-#ifndef BBD_WINDOW_WHOLE
   const v4f* p4 = reinterpret_cast<const v4f*>(plane) + (r0 * (STRIDE / 4) + (c0 >> 2));
-#else
-  // (explicit LDS address space: a volatile access through a generic pointer would become flat_load)
-  typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f_ptr;
-  lds_v4f_ptr p4 = (lds_v4f_ptr)(plane) + (r0 * (STRIDE / 4) + (c0 >> 2));
-#endif
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const v4f a = p4[r * (STRIDE / 4)];
@@ -440,12 +424,8 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
       bbd_ssim_nd(s, ss, sxy, mu_y[ch][j], sg_y[ch][j], &nn[j], &dd[j]);
       l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
     }
-#if defined(BBD_SSIM_DIV_X4)     // four divisions behind one validity branch: measured SLOWER (0.246 vs 0.224 ms forward:
-    bbd_div_x4(nn, dd, qq);      // 14 spilled registers instead of 4) - kept for the record, profiles/r02/guard_variants.txt
-#else
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) qq[j] = bbd_div(nn[j], dd[j]);
-#endif
+    for (int j = 0; j < PPT; ++j) qq[j] = bbd_div(nn[j], dd[j]);   // (one validity branch for all four: slower, profiles/r02/guard_variants.txt)
 #pragma unroll
     for (int j = 0; j < PPT; ++j) ssim[j][ch] = no_ssim ? 0.0f : bbd_ssim_from_ratio(qq[j]);
   }
@@ -479,11 +459,12 @@ __device__ __forceinline__ void load_strip(const float* p, int xx, int W, bool v
 __global__ __launch_bounds__(NT) void identity_loss_kernel(FramePtrs frames, const float* __restrict__ target,
                                                            const int32_t* __restrict__ items,
                                                            float* __restrict__ ident, int H, int W,
-                                                           int ntiles, int no_ssim) {
+                                                           int ntiles, int no_ssim, int remap) {
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
   __shared__ __attribute__((aligned(16))) float s_x[3][FPLANE];
-  const int item = blockIdx.x / ntiles;
-  const TileCoord tc = decode_tile(blockIdx.x - item * ntiles, W);
+  const int wid = remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int item = wid / ntiles;
+  const TileCoord tc = decode_tile(wid - item * ntiles, W);
   const int b = uniform_load(items + item * 4 + 0), slot = uniform_load(items + item * 4 + 1), row = uniform_load(items + item * 4 + 2);
   const int hw = H * W;
   const size_t img = (size_t)3 * hw;
@@ -534,32 +515,23 @@ struct FwdArgs {
   float2* coords;       // optional [S,NP,H,W]: clamped sampling coordinates + clamp flags, for the backward
   DispSrc ds;
   BbdDims dm;
-  int S, B, NP, ntiles, no_ssim;
+  int S, B, NP, ntiles, no_ssim, remap;
 };
 
 #ifndef BBD_FWD_WAVES
 #define BBD_FWD_WAVES 3   // <= 168 VGPRs (154 used since the pose rows moved to SGPRs); 2 waves/SIMD is 15 % slower
 #endif
-#ifdef BBD_FWD_VGPR
-#define BBD_FWD_ATTR __attribute__((amdgpu_num_vgpr(BBD_FWD_VGPR)))
-#else
-#define BBD_FWD_ATTR
-#endif
 __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(FwdArgs a) {
   // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
   // still read candidate c, so one barrier per warp candidate is enough
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
-#ifdef BBD_FWD_SINGLE_BUF
-  __shared__ __attribute__((aligned(16))) float s_xx[1][3][FPLANE];
-#else
   __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE];
-#endif
   __shared__ float s_red[4];
   int buf = 0;
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
   // grid order: sample-major, then scale, then tile
-  int bid = blockIdx.x;
+  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int b = bid / (a.S * a.ntiles);
   bid -= b * a.S * a.ntiles;
   const int s = bid / a.ntiles;
@@ -616,11 +588,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
       BBD_STAMP(6 + 4 * (c & 3));
       strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
       BBD_STAMP(7 + 4 * (c & 3));
-#ifdef BBD_FWD_SINGLE_BUF
-      __syncthreads();
-#else
       buf ^= 1;
-#endif
     } else {
 #pragma unroll
       for (int j = 0; j < PPT; ++j) loss[j] = 0.0f;
@@ -684,315 +652,8 @@ struct BwdArgs {
   const float2* coords; // optional [S,NP,H,W] from the forward: the warp recompute then needs no projection
   DispSrc ds;
   BbdDims dm;
-  int S, B, NP, ntiles, no_ssim;
+  int S, B, NP, ntiles, no_ssim, remap;
 };
-
-#ifndef BBD_BWD_WAVES
-#define BBD_BWD_WAVES 1
-#endif
-#ifdef BBD_BWD_VGPR
-#define BBD_BWD_ATTR __attribute__((amdgpu_num_vgpr(BBD_BWD_VGPR)))
-#else
-#define BBD_BWD_ATTR
-#endif
-__global__ __launch_bounds__(NT, BBD_BWD_WAVES) void warp_ssim_min_bwd_kernel(BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_ybuf[3 * BPLANE + 8];
-  __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE + 8];
-  __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE];  // {A,B,C} of the channel in flight, sparse
-  __shared__ uint16_t s_list[CH * CW];                            // coefficient cells won by the candidate
-  __shared__ __attribute__((aligned(16))) float s_dv[6][TH * TW];   // d warped_c / d ix (0..2), / d iy (3..5)
-  __shared__ float s_red[4][12];
-  __shared__ unsigned s_present;
-  __shared__ int s_count;
-  float (*s_y)[BPLANE] = reinterpret_cast<float (*)[BPLANE]>(s_ybuf);
-  float (*s_x)[BPLANE] = reinterpret_cast<float (*)[BPLANE]>(s_xbuf);
-  const BbdDims dm = a.dm;
-  const int H = dm.H, W = dm.W, hw = H * W;
-  int bid = blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
-  const size_t img = (size_t)3 * hw;
-  const size_t sb = (size_t)s * a.B + b;
-  const float* depth = a.depth + sb * hw;      // (this timing-only form supports depth planes only)
-  const uint8_t* am = a.argmin + sb * hw;
-  const float g = uniform_load(a.gscale + s);
-  const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
-  const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
-
-  BBD_STAMP(0);
-  // Setup in two steps so that one memory round trip covers all of it: first every global load is
-  // issued (arg-min ids, target cells, depth cells, the thread's own strip), then the LDS work that
-  // does not depend on them (clearing the sparse coefficient planes), then the loads are consumed.
-  //
-  // Loss pixels of the (TH+2)x(TW+2) region that see this tile's texels: every thread owns a fixed
-  // set of them and keeps their arg-min id in registers (255 = outside the image).
-  constexpr int NP_CELLS = (CH * CW + NT - 1) / NT;
-  int pcell[NP_CELLS];
-  unsigned parg[NP_CELLS];
-#pragma unroll
-  for (int k = 0; k < NP_CELLS; ++k) {
-    const int i = k * NT + (int)threadIdx.x;
-    const int r = i / CW, c = i - r * CW;
-    const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
-    const bool in = i < CH * CW && py >= 0 && py < H && px >= 0 && px < W;
-    pcell[k] = r * CS + c;
-    parg[k] = in ? (unsigned)am[py * W + px] : 255u;
-  }
-  Cells<BH, BW, BS, 2> cl;
-  cl.init(H, W, tc.tx0, tc.ty0);
-  float tcell[Cells<BH, BW, BS, 2>::N][3];
-  {
-    const float* tg = a.target + (size_t)b * img;
-#pragma unroll
-    for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
-      const int px = cl.pix(k, W);
-      tcell[k][0] = tg[px];
-      tcell[k][1] = tg[px + hw];
-      tcell[k][2] = tg[px + 2 * hw];
-    }
-  }
-  float dcell[Cells<BH, BW, BS, 2>::N];
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  load_depth(dsrc, H, W, cl, dcell);
-
-  int ly, lx0;
-  strip_of_thread(&ly, &lx0);
-  const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
-  const bool q_row_ok = qy < H;
-  // arg-min ids of this thread's own 4 pixels (for the L1 term)
-  unsigned qarg[PPT];
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) qarg[j] = (q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u;
-  // Tiles at least two pixels away from every image border see neither reflection multiplicities nor
-  // missing loss pixels: their 3x3 adjoint is a plain 9-term sum (block-uniform fast path).
-  const bool interior = tc.tx0 >= 2 && tc.tx0 + TW + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
-  float gdepth[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float qdepth[PPT] = {1.0f, 1.0f, 1.0f, 1.0f};     // depth of the thread's own 4 pixels (sample-gradient phase)
-  if (q_row_ok) load_strip(depth + qy * W + qx0, qx0, W, (qx0 + PPT <= W) && ((W & 3) == 0), qdepth);
-
-  if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
-  // the coefficient planes are sparse (only loss pixels won by the current candidate are non-zero):
-  // cleared once here, and each candidate's entries are cleared again by the thread that owns them
-  for (int i = threadIdx.x; i < 3 * CPLANE / 4; i += NT)
-    reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  {
-    unsigned mine = 0u;
-#pragma unroll
-    for (int k = 0; k < NP_CELLS; ++k)
-      if (parg[k] != 255u) mine |= 1u << parg[k];
-    if (mine) atomicOr(&s_present, mine);
-  }
-#pragma unroll
-  for (int k = 0; k < Cells<BH, BW, BS, 2>::N; ++k) {
-    s_y[0][cl.lds[k]] = tcell[k][0];
-    s_y[1][cl.lds[k]] = tcell[k][1];
-    s_y[2][cl.lds[k]] = tcell[k][2];
-  }
-  BBD_STAMP(1);
-  __syncthreads();
-  BBD_STAMP(2);
-  const unsigned present = s_present;
-
-  const int nc = uniform_load(a.ncand + b);
-  int prev = -1;                       // previous processed candidate: its coefficient entries get cleared
-  for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
-    if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
-    float* gp_out = a.grad_proj + (((size_t)s * a.NP + cd.pose) * a.ntiles + tc.tile) * 12;
-    if (!((present >> c) & 1u)) {     // block-uniform: this candidate won nothing around the tile
-      if (threadIdx.x < 12) gp_out[threadIdx.x] = 0.0f;
-      continue;
-    }
-    const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
-    const float* pose_row = a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE;
-
-    // ---- phase W: clear the previous candidate's coefficients, list this candidate's winners, and
-    //      recompute the warped region.  Staging cell (r,c) holds the warped value AT the reflected
-    //      image pixel, exactly what ReflectionPad2d would have copied there.
-    if (!a.no_ssim) {
-#pragma unroll
-      for (int k = 0; k < NP_CELLS; ++k) {
-        if ((int)parg[k] == prev) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
-        }
-        if (parg[k] == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
-      }
-    }
-    prev = c;
-    BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds<BBD_BWD_WARP_BATCH>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
-    BBD_STAMP(5 + 8 * (c & 1));
-    __syncthreads();
-    BBD_STAMP(6 + 8 * (c & 1));
-
-    // ---- phases C/G, one colour channel at a time (three coefficient planes in LDS instead of nine:
-    //      LDS, not registers, is what caps this kernel's occupancy)
-#if defined(BBD_ABLATE_BWD_COEF)
-    const int nwin = 0;
-#else
-    const int nwin = a.no_ssim ? 0 : s_count;
-#endif
-    float gx[3][PPT];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      // C: SSIM partials A,B,C (d loss / d{mu_x, E[x^2], E[xy]}) of the loss pixels won by c
-      for (int idx = threadIdx.x; idx < nwin; idx += NT) {
-        const int cell = s_list[idx];
-        const int pr = cell / CS, pc = cell - pr * CS;
-        float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
-#pragma unroll
-        for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-          for (int dc = 0; dc < 3; ++dc) {
-            const float xv = s_x[ch][(pr + dr) * BS + pc + dc], yv = s_y[ch][(pr + dr) * BS + pc + dc];
-            sx_ += xv; sxx += xv * xv; sxy += xv * yv; sy_ += yv; syy += yv * yv;
-          }
-        float mu_y, sg_y, A, Bc, Cc;
-        bbd_ystats(sy_, syy, &mu_y, &sg_y);
-        bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
-        s_cf[0][cell] = A * w_ssim;
-        s_cf[1][cell] = Bc * w_ssim;
-        s_cf[2][cell] = Cc * w_ssim;
-      }
-      if (ch == 0) BBD_STAMP(7 + 8 * (c & 1));
-      __syncthreads();
-      if (ch == 0) BBD_STAMP(8 + 8 * (c & 1));
-      if (ch == 0 && threadIdx.x == 0) s_count = 0;   // everyone has read it; rewritten after the next barrier
-
-      // G: adjoint of reflect-pad + 3x3 mean at this thread's 4 texels
-      float xw[8], yw[8];
-      {
-        const float4* px4 = reinterpret_cast<const float4*>(s_x[ch]) + ((ly + 2) * (BS / 4) + (lx0 >> 2));
-        const float4* py4 = reinterpret_cast<const float4*>(s_y[ch]) + ((ly + 2) * (BS / 4) + (lx0 >> 2));
-        const float4 a0 = px4[0], a1 = px4[1], b0 = py4[0], b1 = py4[1];
-        xw[0] = a0.x; xw[1] = a0.y; xw[2] = a0.z; xw[3] = a0.w; xw[4] = a1.x; xw[5] = a1.y; xw[6] = a1.z; xw[7] = a1.w;
-        yw[0] = b0.x; yw[1] = b0.y; yw[2] = b0.z; yw[3] = b0.w; yw[4] = b1.x; yw[5] = b1.y; yw[6] = b1.z; yw[7] = b1.w;
-      }
-      // weighted 3x3 gathers of the three coefficient planes, one plane at a time (register pressure)
-      float S3[3][PPT];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) S3[pl][j] = 0.0f;
-      if (!a.no_ssim) {
-        if (interior) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            float cw[3][8];
-            load_window<CS>(s_cf[pl], ly, lx0, cw);
-            float col[PPT + 2];                 // column sums shared by the strip's 4 pixels
-#pragma unroll
-            for (int i = 0; i < PPT + 2; ++i) col[i] = (cw[0][i] + cw[1][i]) + cw[2][i];
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) S3[pl][j] = (col[j] + col[j + 1]) + col[j + 2];
-          }
-        } else {
-          // adjoint multiplicities of reflect-pad + 3x3 mean (0 where the loss pixel is outside the image)
-          float wy[3], wx[PPT][3];
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int py = qy + d - 1;
-            wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-              const int px = qx0 + j + d - 1;
-              wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
-            }
-          }
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            float cw[3][8];
-            load_window<CS>(s_cf[pl], ly, lx0, cw);
-#pragma unroll
-            for (int j = 0; j < PPT; ++j)
-#pragma unroll
-              for (int dr = 0; dr < 3; ++dr) {
-                float r = 0.0f;
-#pragma unroll
-                for (int dc = 0; dc < 3; ++dc) r = fmaf(wx[j][dc], cw[dr][j + dc], r);
-                S3[pl][j] = fmaf(wy[dr], r, S3[pl][j]);
-              }
-          }
-        }
-      }
-      const float (&SA)[PPT] = S3[0];
-      const float (&SB)[PPT] = S3[1];
-      const float (&SC)[PPT] = S3[2];
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        const float xq = xw[j + 2], yq = yw[j + 2];
-        float acc = (SA[j] + xq * SB[j] + yq * SC[j]) * (1.0f / 9.0f);
-        if (qarg[j] == (unsigned)c) {
-          const float df = xq - yq;
-          acc += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
-        }
-        gx[ch][j] = (q_row_ok && qx0 + j < W) ? acc : 0.0f;
-      }
-      if (ch < 2 && !a.no_ssim) __syncthreads();    // the planes are rewritten for the next channel
-    }
-
-    BBD_STAMP(9 + 8 * (c & 1));
-    // texel gradient -> sampling coordinates -> depth and P
-    float gP[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
-#if defined(BBD_ABLATE_BWD_SAMPLE)
-    gdepth[0] += gx[0][0] + gx[1][1] + gx[2][2] + gx[0][3];
-    if (false) {
-#else
-    if (q_row_ok) {
-#endif
-      float pj[21];
-#pragma unroll
-      for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
-      // coordinate derivatives of this thread's 4 pixels, left in LDS by the warp phase
-      float dxy[6][PPT];
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) {
-        const float4 q = *reinterpret_cast<const float4*>(&s_dv[pl][ly * TW + lx0]);
-        dxy[pl][0] = q.x; dxy[pl][1] = q.y; dxy[pl][2] = q.z; dxy[pl][3] = q.w;
-      }
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        const int qx = qx0 + j;
-        if (qx >= W) continue;
-        if (gx[0][j] == 0.0f && gx[1][j] == 0.0f && gx[2][j] == 0.0f) continue;
-        const float gix = gx[0][j] * dxy[0][j] + gx[1][j] * dxy[1][j] + gx[2][j] * dxy[2][j];
-        const float giy = gx[0][j] * dxy[3][j] + gx[1][j] * dxy[4][j] + gx[2][j] * dxy[5][j];
-        BbdSample sm;
-        bbd_sample_smooth(pj, qx, qy, qdepth[j], &sm);
-        float gd, gp1[12];
-        bbd_project_grad(pj, &sm, gix, giy, &gd, gp1);
-        gdepth[j] += gd;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gP[k] += gp1[k];
-      }
-    }
-    if (cd.kind & FLAG_NO_POSE_GRAD) {
-      if (threadIdx.x < 12) gp_out[threadIdx.x] = 0.0f;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const float ws = wave_sum63(gP[k]);
-        if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6][k] = ws;
-      }
-    }
-    BBD_STAMP(10 + 8 * (c & 1));
-    __syncthreads();   // s_red complete; every thread is done with s_x / s_cf of this candidate
-    BBD_STAMP(11 + 8 * (c & 1));
-    if (!(cd.kind & FLAG_NO_POSE_GRAD) && threadIdx.x < 12)
-      gp_out[threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) +
-                            s_red[3][threadIdx.x];
-  }
-
-  if (q_row_ok)
-    store_strip(a.grad_depth + sb * hw + qy * W + qx0, qx0, W, (qx0 + PPT <= W) && ((W & 3) == 0), gdepth);
-  BBD_STAMP(20);
-}
 
 // ------------------------------------------------------------------------------------------
 // Fused backward, narrow-tile form (the shipped one): the same LDS images and phases as above on a
@@ -1029,12 +690,7 @@ template <int STRIDE>
 __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0, float win[3][4]) {
   static_assert(STRIDE % 2 == 0, "rows must stay 8-byte aligned");
   typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef BBD_WINDOW_WHOLE
   const v2f* p2 = reinterpret_cast<const v2f*>(plane) + (r0 * (STRIDE / 2) + (c0 >> 1));
-#else
-  typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;     // whole ds_read_b64, see load_window
-  lds_v2f_ptr p2 = (lds_v2f_ptr)(plane) + (r0 * (STRIDE / 2) + (c0 >> 1));
-#endif
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const v2f a = p2[r * (STRIDE / 2)];
@@ -1067,7 +723,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   float (*s_x)[BPLANE2] = reinterpret_cast<float (*)[BPLANE2]>(s_xbuf);
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
-  int bid = blockIdx.x;
+  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int b = bid / (a.S * a.ntiles);
   bid -= b * a.S * a.ntiles;
   const int s = bid / a.ntiles;
@@ -1164,10 +820,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 
   const int nc = uniform_load(a.ncand + b);
   int prev = -1;
-#if defined(BBD_BWD2_PREFETCH)
-  float2 pre[CellsB::N];
-  int pre_c = -1;
-#endif
   for (int c = 0; c < nc; ++c) {
     const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
     if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
@@ -1194,32 +846,12 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     BBD_STAMP(4 + 8 * (c & 1));
     if (HANDOVER) {
       // the forward's clamped sampling coordinates of the staged cells (coalesced 8-byte loads); no projection
-#if defined(BBD_BWD2_PREFETCH)
-      if (pre_c != c) {
-        const float2* cp = a.coords + ((size_t)s * a.NP + cd.pose) * hw;
-#pragma unroll
-        for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
-      }
-      warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
-                                                                            s_dv, nullptr, pre);
-      for (int n = c + 1; n < nc; ++n) {        // next candidate to be processed: its coordinates travel meanwhile
-        const bbd_cand_t nd = load_cand(a.cand + b * BBD_MAX_CAND + n);
-        if ((nd.kind & KIND_MASK) == BBD_KIND_WARP && ((present >> n) & 1u)) {
-          const float2* cp = a.coords + ((size_t)s * a.NP + nd.pose) * hw;
-#pragma unroll
-          for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
-          pre_c = n;
-          break;
-        }
-      }
-#else
       float2 pre[CellsB::N];
       const float2* cp = a.coords + ((size_t)s * a.NP + cd.pose) * hw;
 #pragma unroll
       for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
       warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
                                                                             s_dv, nullptr, pre);
-#endif
     } else {
       warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
     }
@@ -1388,178 +1020,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   }
   BBD_STAMP(20);
 #undef BBD_PARG
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused forward, narrow-tile form (-DBBD_FWD_NARROW; NOT shipped): 32x16-pixel tile, 256 threads, a 2-pixel strip per
-// thread - the backward's geometry.  Measured (profiles/r02/fwd_narrow_variants.txt): MD2 0.246 vs 0.235 ms for the
-// shipped 64x16 form (in the training step 0.191 vs 0.178), boosted m=7 0.331 vs 0.343: the 4th wave per SIMD does not
-// pay for the larger halo share (1.195 vs 1.16 cells per pixel) and the per-strip statistics.  Per-thread state halves (3 staged cells, 2-pixel windows, 12 target statistics instead of 24), so the
-// kernel fits 128 VGPRs (4 waves per SIMD instead of 3) and every thread's gathers of a candidate are in flight
-// together (one batch instead of two).  Same per-pixel arithmetic, same bits; only the per-tile partial sums of the
-// scalar loss are grouped differently (240 tiles per image instead of 120).
-// ------------------------------------------------------------------------------------------
-constexpr int LS2 = TW2 + 4;          // 36: row stride of the staged (TH+2) x (TW2+2) regions
-constexpr int LW2 = TW2 + 2;
-constexpr int FPLANE2 = LH * LS2;
-
-__device__ __forceinline__ void strip_ystats2(const float (*sy)[FPLANE2], int ly, int lx0, float mu_y[3][PPT2],
-                                              float sg_y[3][PPT2]) {
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    float y[3][4];
-    load_window4<LS2>(sy[ch], ly, lx0, y);
-#pragma unroll
-    for (int j = 0; j < PPT2; ++j) {
-      float sm = 0.0f, ss = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float v = y[r][j + c];
-          sm += v;
-          ss += v * v;
-        }
-      bbd_ystats(sm, ss, &mu_y[ch][j], &sg_y[ch][j]);
-    }
-  }
-}
-
-__device__ __forceinline__ void strip_loss2(const float (*sx)[FPLANE2], const float (*sy)[FPLANE2], int ly, int lx0,
-                                            const float mu_y[3][PPT2], const float sg_y[3][PPT2], int no_ssim,
-                                            float out[PPT2]) {
-  float ssim[PPT2][3], l1[PPT2][3];
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    float x[3][4], y[3][4];
-    load_window4<LS2>(sx[ch], ly, lx0, x);
-    load_window4<LS2>(sy[ch], ly, lx0, y);
-#pragma unroll
-    for (int j = 0; j < PPT2; ++j) {
-      float sm = 0.0f, ss = 0.0f, sxy = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float v = x[r][j + c];
-          sm += v;
-          ss += v * v;
-          sxy += v * y[r][j + c];
-        }
-      ssim[j][ch] = no_ssim ? 0.0f : bbd_ssim(sm, ss, sxy, mu_y[ch][j], sg_y[ch][j]);
-      l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < PPT2; ++j) out[j] = bbd_combine(ssim[j], l1[j], no_ssim);
-}
-
-#ifndef BBD_FWD2_WAVES
-#define BBD_FWD2_WAVES 4
-#endif
-__global__ __launch_bounds__(NT2, BBD_FWD2_WAVES) void warp_ssim_min_fwd2_kernel(FwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE2];
-  __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE2];     // double-buffered: one barrier per candidate
-  __shared__ float s_red[4];
-  int buf = 0;
-  const BbdDims dm = a.dm;
-  const int H = dm.H, W = dm.W, hw = H * W;
-  int bid = blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
-  const size_t img = (size_t)3 * hw;
-  const size_t sb = (size_t)s * a.B + b;
-
-  BBD_STAMP(0);
-  typedef Cells<LH, LW2, LS2, 1, NT2> CellsF;
-  CellsF cl;
-  cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
-  float dcell[CellsF::N];
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  load_depth(dsrc, H, W, cl, dcell);
-  if (a.depth_out != nullptr) {
-#pragma unroll
-    for (int k = 0; k < CellsF::N; ++k)
-      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
-  }
-  BBD_STAMP(1);
-  __syncthreads();
-  BBD_STAMP(2);
-  const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
-  const int yy = tc.ty0 + ly, xx = tc.tx0 + lx0;
-  const bool row_ok = yy < H;
-  const bool vec_ok = (xx + PPT2 <= W) && ((W & 1) == 0);
-  const int pix = yy * W + xx;
-
-  float mu_y[3][PPT2], sg_y[3][PPT2];
-  strip_ystats2(s_y, ly, lx0, mu_y, sg_y);
-  float best[PPT2] = {INFINITY, INFINITY};
-  int arg[PPT2] = {0, 0};
-  BBD_STAMP(3);
-
-  const int nc = uniform_load(a.ncand + b);
-  for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
-    float loss[PPT2] = {0.0f, 0.0f};
-    if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
-      const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
-      float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
-      float2* cout = a.coords ? a.coords + ((size_t)s * a.NP + cd.pose) * hw : nullptr;
-      BBD_STAMP(4 + 4 * (c & 3));
-      warp_into_lds<CellsF::N, CellsF, FPLANE2, TH * TW2, false, 1>(src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE,
-                                                                    dm, hw, cl, s_xx[buf], wout, nullptr, cout);
-      BBD_STAMP(5 + 4 * (c & 3));
-      __syncthreads();
-      BBD_STAMP(6 + 4 * (c & 3));
-      strip_loss2(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
-      BBD_STAMP(7 + 4 * (c & 3));
-      buf ^= 1;
-    } else if (row_ok) {
-      const float* ip = a.ident + (size_t)cd.row * hw + pix;
-      const float* np = a.noise ? a.noise + (size_t)b * hw + pix : nullptr;
-      if (vec_ok) {
-        const float2 t = *reinterpret_cast<const float2*>(ip);
-        loss[0] = t.x; loss[1] = t.y;
-        if (np) {
-          const float2 z = *reinterpret_cast<const float2*>(np);
-          loss[0] += z.x; loss[1] += z.y;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < PPT2; ++j)
-          if (xx + j < W) loss[j] = ip[j] + (np ? np[j] : 0.0f);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < PPT2; ++j) bbd_min_update(loss[j], c, &best[j], &arg[j]);
-  }
-
-  float tsum = 0.0f;
-  if (row_ok) {
-    float* mo = a.min_loss + sb * hw + pix;
-    uint8_t* ao = a.argmin + sb * hw + pix;
-    if (vec_ok) {
-      *reinterpret_cast<float2*>(mo) = make_float2(best[0], best[1]);
-      *reinterpret_cast<uint16_t*>(ao) = (uint16_t)((unsigned)arg[0] | ((unsigned)arg[1] << 8));
-      tsum = best[0] + best[1];
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPT2; ++j)
-        if (xx + j < W) {
-          mo[j] = best[j];
-          ao[j] = (uint8_t)arg[j];
-          tsum += best[j];
-        }
-    }
-  }
-  const float wsum = wave_sum63(tsum);
-  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
-  __syncthreads();
-  if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-  BBD_STAMP(20);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2342,6 +1802,12 @@ int fill_frames(const void* const* frames, FramePtrs* out) {
   return 0;
 }
 
+// BBD_XCD_REMAP=0 restores the plain blockIdx order (A/B timing only)
+int xcd_remap_enabled() {
+  static const int on = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr || e[0] != '0'; }();
+  return on;
+}
+
 int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -2356,19 +1822,9 @@ int bbd_tile_w(void) { return TW; }
 int bbd_tile_h(void) { return TH; }
 int bbd_num_tiles(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 int bbd_num_tiles_fwd(int H, int W) {      /* tiles of the fused FORWARD launch: sizes partial [S, B, tiles] */
-#if !defined(BBD_FWD_NARROW)
   return bbd_num_tiles(H, W);
-#else
-  return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2);
-#endif
 }
-int bbd_num_tiles_bwd(int H, int W) {
-#if defined(BBD_BWD_256)
-  return bbd_num_tiles(H, W);
-#else
-  return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2);
-#endif
-}
+int bbd_num_tiles_bwd(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2); }
 
 int bbd_identity_loss_fwd(const void* const* frames, const float* target, const int32_t* items, int NI,
                           float* ident, int H, int W, int no_ssim, void* stream) {
@@ -2378,7 +1834,8 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   if (fill_frames(frames, &fp)) return BBD_E_BADARG;
   const int ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(identity_loss_kernel, dim3((unsigned)(NI * ntiles)), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim);
+                     static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim,
+                     xcd_remap_enabled());
   return launch_status();
 }
 
@@ -2419,13 +1876,9 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
   a.warped = warped; a.depth_out = depth_out; a.coords = reinterpret_cast<float2*>(coords); a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
-#if !defined(BBD_FWD_NARROW)    // shipped: 64x16 tile, 4-pixel strips, 3 waves per SIMD
+  a.remap = xcd_remap_enabled();
   hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
-#else
-  hipLaunchKernelGGL(warp_ssim_min_fwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
-                     static_cast<hipStream_t>(stream), a);
-#endif
   return launch_status();
 }
 
@@ -2450,18 +1903,13 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.coords = reinterpret_cast<const float2*>(coords);
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
-#if defined(BBD_BWD_256)        // the round-1 form (4 waves, 4-pixel strips, depth planes only): A/B timing builds
-  if (!depth || coords) return BBD_E_BADARG;
-  hipLaunchKernelGGL(warp_ssim_min_bwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), a);
-#else
+  a.remap = xcd_remap_enabled();
   if (coords)
     hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                        static_cast<hipStream_t>(stream), a);
   else
     hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<false>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                        static_cast<hipStream_t>(stream), a);
-#endif
   return launch_status();
 }
 

@@ -187,7 +187,7 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const Bb
   const float qz = bbd_dot4_hom(P + 8, o->X, o->Y, o->Z);
   o->zi = qz + BBD_EPS;                       /* layers.py:188 */
   const float wm1 = dm.wm1, hm1 = dm.hm1;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BBD_PROJECT_GUARD_EACH)
+#if defined(__HIP_DEVICE_COMPILE__)
   /* All four IEEE divisions through the refined-reciprocal sequence first, ONE validity test for the lot, and the
    * full IEEE sequence only for lanes outside the exponent window (identical results: both forms are correctly
    * rounded where the fast one is valid) - one rarely-taken branch per pixel instead of three with inlined
@@ -301,18 +301,9 @@ BBD_HD void bbd_taps(float ix, float iy, const BbdDims& dm, BbdTaps* t) {
 
 /* The four texel values (nw, ne, sw, se) of one channel plane. */
 BBD_HD void bbd_fetch4(const float* plane, const BbdTaps* t, float v[4]) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BBD_GATHER_SADDR)
-  /* NOT shipped (-DBBD_GATHER_SADDR): uniform plane pointer + zero-extended 32-bit byte offset, so hipcc selects the
-   * SGPR-base form of global_load_dwordx2 (one 32-bit shift per texel pair instead of sign-extend + 64-bit shift +
-   * 64-bit add per pair and channel: 73 -> 55 v_lshl_add_u64 in the backward).  Measured neutral to slower
-   * (profiles/r02/gather_saddr_variants.txt: MD2 bwd 0.282 -> 0.279 ms, m=7 fwd 0.329 -> 0.344, bwd 0.351 -> 0.357). */
-  const char* base = reinterpret_cast<const char*>(plane);
-  const float* r0 = reinterpret_cast<const float*>(base + ((unsigned)t->i0 << 2));
-  const float* r1 = reinterpret_cast<const float*>(base + ((unsigned)t->i1 << 2));
-#else
+  /* (SGPR-base + 32-bit-offset addressing measured neutral to slower: profiles/r02/gather_saddr_variants.txt) */
   const float* r0 = plane + t->i0;
   const float* r1 = plane + t->i1;
-#endif
   v[0] = r0[0]; v[1] = r0[1]; v[2] = r1[0]; v[3] = r1[1];
 }
 
@@ -347,21 +338,6 @@ BBD_HD float bbd_ssim(float sx, float sxx, float sxy, float mu_y, float sig_y) {
   bbd_ssim_nd(sx, sxx, sxy, mu_y, sig_y, &n, &d);
   return bbd_ssim_from_ratio(bbd_div(n, d));
 }
-/* four IEEE quotients n[j]/d[j] with ONE validity branch (see bbd_project) */
-BBD_HD void bbd_div_x4(const float n[4], const float d[4], float q[4]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  int ok = 1;
-  for (int j = 0; j < 4; ++j) {
-    q[j] = bbd_div_with(n[j], d[j], bbd_rcp_refined(d[j]));
-    ok &= bbd_exp_ok3(n[j], d[j], d[j]);
-  }
-  if (!ok)
-    for (int j = 0; j < 4; ++j) q[j] = n[j] / d[j];
-#else
-  for (int j = 0; j < 4; ++j) q[j] = n[j] / d[j];
-#endif
-}
-
 /* 0.85 * mean_c(ssim) + 0.15 * mean_c(|y - x|)   (trainer.py:477-486) */
 BBD_HD float bbd_combine(const float ssim[3], const float l1[3], int no_ssim) {
   const float l1m = bbd_div3(l1[0] + l1[1] + l1[2]);

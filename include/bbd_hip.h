@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define BBD_ABI_VERSION 1
+/* Bumped on EVERY incompatible change of a prototype or of a scratch-size contract; the Python binding refuses a
+ * library whose number differs (a stale build selected through BBD_HIP_LIB, or a C caller compiled against an older
+ * header, would otherwise mis-marshal pointers into a kernel).  1 = round 1; 2 = bbd_bn_act_bwd gained `beta`, BN
+ * scratch sizing changed (round 2, was not bumped then); 3 = round 3 (backward tiling / scratch contract). */
+#define BBD_ABI_VERSION 3
 
 /* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
  * trainer.py:428).  A "slot" indexes a host array of their base pointers. */

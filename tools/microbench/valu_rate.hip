@@ -1,57 +1,107 @@
-// How many cycles does one wave64 fp32 VALU instruction occupy a gfx950 SIMD for, as a function
-// of waves per SIMD?  (planning input for the fused kernels: are they VALU-issue-bound?)
+// How long does one wave64 vector instruction occupy a gfx950 SIMD, by instruction kind and by waves per SIMD?
+// (planning input for the fused kernels: their VALU floor = sum over kinds of count x cycles.)
+//
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -w -o valu_rate tools/microbench/valu_rate.hip && ./valu_rate > profiles/r03/valu_rate.txt
+//
+// Every kernel runs 8 independent dependency chains per lane so that one wave can issue back to back; blocks of 256
+// threads put one wave on each SIMD, blocks per CU = waves per SIMD.  Reported per (kind, waves/SIMD):
+//   ns per wave-instruction per SIMD (wall time / instructions issued on one SIMD),
+//   shader cycles per wave-instruction per SIMD = that x the clock the chip held in THIS launch, which is measured in
+//   the kernel as d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6),
+//   and the cycles one wave alone sees between its own consecutive instructions.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 
+enum Kind { FMA = 0, MULADD, CMPSEL, RCP, IMUL, ADD64, CVT, FLOOR, DPP, KINDS };
+static const char* kind_name[KINDS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_cmp+v_cndmask(+add,mul)", "v_rcp_f32",
+                                       "v_mul_lo_u32", "v_lshl_add_u64", "v_mul+v_cvt_i32_f32+v_cvt_f32_i32", "v_mul+v_floor_f32",
+                                       "v_add_f32 dpp row_shr"};
+
 template <int KIND>
-__global__ void chain(float* out, int iters, float b, float c) {
-  float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-  long long t0 = clock64();
-  for (int i = 0; i < iters; ++i) {
-    if (KIND == 0) {          // fma
-      a0 = fmaf(a0, b, c); a1 = fmaf(a1, b, c); a2 = fmaf(a2, b, c); a3 = fmaf(a3, b, c);
-      a4 = fmaf(a4, b, c); a5 = fmaf(a5, b, c); a6 = fmaf(a6, b, c); a7 = fmaf(a7, b, c);
-    } else if (KIND == 1) {   // separate mul + add (what -ffp-contract=off code looks like)
-      a0 = a0 * b; a1 = a1 + c; a2 = a2 * b; a3 = a3 + c; a4 = a4 * b; a5 = a5 + c; a6 = a6 * b; a7 = a7 + c;
-    } else {                  // compare + select
-      a0 = a0 > c ? a0 : b + a0; a1 = a1 > c ? a1 : b + a1; a2 = a2 > c ? a2 : b + a2; a3 = a3 > c ? a3 : b + a3;
-      a4 = a4 * b; a5 = a5 * b; a6 = a6 * b; a7 = a7 * b;
+__global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk, int iters, float b, float c) {
+  float a[8];
+  unsigned u[8];
+  unsigned long long w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x + i + 1.5f; u[i] = threadIdx.x * 7u + i + 3u; w[i] = (unsigned long long)out + u[i]; }
+  const unsigned ub = __float_as_uint(b) | 1u;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (KIND == FMA) a[i] = fmaf(a[i], b, c);
+      else if (KIND == MULADD) a[i] = (i & 1) ? a[i] + c : a[i] * b;
+      else if (KIND == CMPSEL) a[i] = (i & 1) ? a[i] * b : (a[i] > c ? a[i] : b + a[i]);
+      else if (KIND == RCP) a[i] = __builtin_amdgcn_rcpf(a[i]);
+      else if (KIND == IMUL) u[i] = u[i] * ub;
+      else if (KIND == ADD64) w[i] = (w[i] << 2) + (unsigned long long)u[i];
+      else if (KIND == CVT) a[i] = (float)(int)(a[i] * b);          // v_mul + v_cvt_i32_f32 + v_cvt_f32_i32
+      else if (KIND == FLOOR) a[i] = floorf(a[i] * b);               // v_mul + v_floor
+      else if (KIND == DPP)
+        a[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x111, 0xf, 0xf, false));
     }
   }
-  long long t1 = clock64();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (float)(t1 - t0);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += a[i] + (float)u[i] + (float)(unsigned)w[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int KIND>
+static void run_kind(float* out, unsigned long long* clk, int iters) {
+  // wave-instructions per loop body, per chain element (what the compiler emits; check with -save-temps if a kind changes)
+  const double per_elem = KIND == MULADD || KIND == IMUL || KIND == FMA || KIND == RCP || KIND == ADD64 || KIND == DPP ? 1.0
+                          : KIND == CMPSEL ? 2.0    // odd: 1 mul; even: add + cmp + cndmask
+                          : KIND == CVT ? 3.0 : 2.0;
+  for (int wps : {1, 2, 4, 8}) {
+    const int blocks = 256 * wps;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(chain<KIND>, dim3(blocks), dim3(256), 0, 0, out, clk, iters, 1.0001f, 0.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(chain<KIND>, dim3(blocks), dim3(256), 0, 0, out, clk, iters, 1.0001f, 0.5f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[2];
+    hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+    const double ghz = (double)h[0] / (double)h[1] * 0.1;           // s_memrealtime ticks at 100 MHz
+    const double instr_per_simd = (double)iters * 8 * per_elem * wps;
+    const double ns = ms * 1e6 / instr_per_simd;
+    printf("%-28s waves/SIMD %d: %8.3f ms  %.3f ns/wave-instr/SIMD  clock %.2f GHz -> %.2f cycles/instr/SIMD   (one wave: %.2f cycles between its instructions)\n",
+           kind_name[KIND], wps, ms, ns, ghz, ns * ghz, (double)h[0] / (iters * 8.0 * per_elem));
+  }
 }
 
 int main() {
   float* out;
-  hipMalloc(&out, 256 * 32 * 64 * sizeof(float) * 2);
+  unsigned long long* clk;
+  hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+  hipMalloc(&clk, 64);
+  hipDeviceProp_t p;
+  hipGetDeviceProperties(&p, 0);
+  printf("# %s, %d CUs, clockRate %d kHz; 8 independent chains per lane, 20000 iterations, 256-thread blocks (1 wave per SIMD each)\n",
+         p.gcnArchName, p.multiProcessorCount, p.clockRate);
   const int iters = 20000;
-  for (int kind = 0; kind < 3; ++kind)
-    for (int wps : {1, 2, 4, 8}) {
-      const int threads = 256;                      // 4 waves = 1 wave per SIMD per block
-      const int blocks = 256 * wps;                 // blocks per CU = waves per SIMD
-      hipEvent_t e0, e1;
-      hipEventCreate(&e0); hipEventCreate(&e1);
-      auto launch = [&]() {
-        if (kind == 0) hipLaunchKernelGGL(chain<0>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f);
-        if (kind == 1) hipLaunchKernelGGL(chain<1>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f);
-        if (kind == 2) hipLaunchKernelGGL(chain<2>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0001f, 0.5f);
-      };
-      launch();
-      hipDeviceSynchronize();
-      hipEventRecord(e0);
-      launch();
-      hipEventRecord(e1);
-      hipEventSynchronize(e1);
-      float ms;
-      hipEventElapsedTime(&ms, e0, e1);
-      float cyc;
-      hipMemcpy(&cyc, out, 4, hipMemcpyDeviceToHost);
-      const double instr_per_simd = (double)iters * 8 * wps;        // wave-instructions per SIMD
-      printf("kind %d waves/SIMD %d: %.3f ms  -> %.2f ns per wave-instr per SIMD  (clock64 ticks/instr for one wave: %.2f)\n",
-             kind, wps, ms, ms * 1e6 / instr_per_simd, cyc / (iters * 8.0));
-    }
+  run_kind<FMA>(out, clk, iters);
+  run_kind<MULADD>(out, clk, iters);
+  run_kind<CMPSEL>(out, clk, iters);
+  run_kind<RCP>(out, clk, iters);
+  run_kind<IMUL>(out, clk, iters);
+  run_kind<ADD64>(out, clk, iters);
+  run_kind<CVT>(out, clk, iters);
+  run_kind<FLOOR>(out, clk, iters);
+  run_kind<DPP>(out, clk, iters);
+  // a long run of the densest kind: the clock the chip settles at after ~2 s of back-to-back launches
+  for (int rep = 0; rep < 40; ++rep) hipLaunchKernelGGL(chain<FMA>, dim3(256 * 4), dim3(256), 0, 0, out, clk, 200000, 1.0001f, 0.5f);
+  hipDeviceSynchronize();
+  unsigned long long h[2];
+  hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+  printf("# after 40 x 200000-iteration v_fma launches at 4 waves/SIMD: clock %.2f GHz\n", (double)h[0] / (double)h[1] * 0.1);
   return 0;
 }
