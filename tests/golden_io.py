@@ -8,7 +8,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 DIRECT_CASES = ["md2_b2_32x64", "md2_mixed_b3_32x64", "md2_b1_192x640", "tri_3105_32x64",
                 "tri_7765_32x64", "tri_2102_32x64", "tri_nodecomp_3210_32x64", "tri_4444_16x32",
-                "tri_6123_16x32", "tri_0000_16x32", "tri_1357_16x32"]
+                "tri_6123_16x32", "tri_0000_16x32", "tri_1357_16x32", "tri_7_b1_192x640", "tri_2_b1_192x640"]
 POSE_CASES = ["pose_plain_3105_32x64", "pose_incr_3215_32x64", "pose_incr_partial_4327_32x64",
               "pose_md2_b2_32x64"]
 
@@ -35,6 +35,9 @@ class Case:
             if parts[0] == "in" and parts[1] in ("color", "color_aug"):
                 img = torch.from_numpy(z[k]).float().div(255)
                 self.inputs[(parts[1], _frame(parts[2]), int(parts[3]))] = img.to(device)
+        for key in [k for k in self.inputs if k[0] == "color" and k[1] != "s" and k[2] == 0]:
+            # lean fixtures drop color_aug (== color for every fixture: tools/make_golden.py builds it as a clone)
+            self.inputs.setdefault(("color_aug", key[1], 0), self.inputs[key])
         self.inputs[("K", 0)] = torch.from_numpy(z["in/K"]).to(device)
         self.inputs[("inv_K", 0)] = torch.from_numpy(z["in/inv_K"]).to(device)
         self.inputs["stereo_T"] = torch.from_numpy(z["in/stereo_T"]).to(device)

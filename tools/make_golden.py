@@ -179,8 +179,21 @@ def run_case(rt, rl, rn, spec):
              for i, m in enumerate(ms)]
     inputs = tr.custom_collate(items)
     rec = {}
+    lean = spec.get("lean", False)     # full-size cases: only what the hot path reads (color_aug == color is re-made
+    used = None                        # by the loader in tests/golden_io.py; frames no warp job samples are dropped)
+    if lean:
+        m_used = set()
+        for m in ms:
+            m_used |= {0, "s"} if m == 0 else set()
+            for k in (range(m, max(m - 3, 0), -1) if spec["trimin"] else [m]):
+                m_used |= {k, -k}
+            if spec["trimin"] and 0 < m <= 2:
+                m_used.add("s")
+        used = m_used | {0}
     for key, val in inputs.items():
         if isinstance(key, tuple) and key[0] in ("color", "color_aug"):
+            if lean and (key[0] == "color_aug" or key[1] not in used):
+                continue
             rec["in/%s/%s/%d" % (key[0], fkey(key[1]), key[2])] = torch.round(val * 255).to(torch.uint8).numpy()
     rec["in/K"] = inputs[("K", 0)].numpy()
     rec["in/inv_K"] = inputs[("inv_K", 0)].numpy()
@@ -386,6 +399,12 @@ CASES = [
          scales=[0, 1], seed=11, store_warps=False),
     dict(name="tri_1357_16x32", H=16, W=32, m=[1, 3, 5, 7], trimin=True, decomp=True, pose="direct",
          scales=[0], seed=12, store_warps=False),
+    # the boosted candidate sets at BASELINE size (trainer.py:983-1100): 18-way min (m = 7: frames +-5, +-6, +-7, each
+    # with T and T_error, + 6 identity) and 14-way min incl. stereo (m = 2), one sample, scale 0 (epoch >= 10 regime)
+    dict(name="tri_7_b1_192x640", H=192, W=640, m=[7], trimin=True, decomp=True, pose="direct", scales=[0], seed=17,
+         store_warps=False, store_depth=False, store_identity=False, lean=True),
+    dict(name="tri_2_b1_192x640", H=192, W=640, m=[2], trimin=True, decomp=True, pose="direct", scales=[0], seed=18,
+         store_warps=False, store_depth=False, store_identity=False, lean=True),
     # pose-net driven cases (predict_poses three modes, trainer.py:310-419)
     dict(name="pose_plain_3105_32x64", H=32, W=64, m=[3, 1, 0, 5], trimin=True, decomp=True, pose="net",
          cutt=0.3, seed=13, store_warps=False),
