@@ -25,6 +25,9 @@ def _frame_sort_key(item):
 
 
 class Trainer:
+    _local_only = False      # True only inside a graph capture's warm-up steps: gradients are not exchanged
+    max_graphs = 8
+
     def __init__(self, options, backend=None):
         self.opt = options
         opt = self.opt
@@ -73,6 +76,7 @@ class Trainer:
         # every parameter the optimizer steps, in group order (the gradient exchange packs exactly these)
         self.optimizer_parameters = [p for g in self.model_optimizer.param_groups for p in g["params"]]
         self._graphs = {}
+        self.max_graphs = int(os.environ.get("BBD_MAX_GRAPHS", "8"))
         self.model_lr_scheduler = optim.lr_scheduler.MultiStepLR(
             self.model_optimizer, milestones=[11, 13, 15, 16, 17, 18, 19], gamma=0.4)
         if getattr(opt, "load_weights_folder", "None") not in (None, "None"):
@@ -140,7 +144,13 @@ class Trainer:
         they keep the eager path; fixed-frame-set training - the MD2 baseline - replays)."""
         key = self._graph_key(inputs)
         entry = self._graphs.get(key)
+        if entry is not None:
+            self._graphs[key] = self._graphs.pop(key)       # most recently used last
         if entry is None:
+            # every captured signature keeps its own graph memory pool: bound the cache (boosted --rand batches
+            # draw new frame sets all the time; the least recently replayed signature goes first)
+            while len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
             static = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inputs.items()}
             # eager warm-up (allocator, MIOpen solutions, Adam state tensors) must not TRAIN: parameters,
             # BatchNorm buffers, the optimizer state and the step counter are restored afterwards, so the
@@ -156,8 +166,15 @@ class Trainer:
             warm = torch.cuda.Stream(device=self.device)
             warm.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(warm):
-                for _ in range(3):
-                    self._eager_step(dict(static))
+                # NO collective in the warm-up: a cache miss is a per-rank event (ranks draw different frame sets
+                # under --rand / the boosted recipe), so a rank that warms up must issue exactly the collectives of a
+                # rank that replays - the ONE exchange after the replay below - or the ranks' all-reduces mis-pair
+                self._local_only = True
+                try:
+                    for _ in range(3):
+                        self._eager_step(dict(static))
+                finally:
+                    self._local_only = False
                 with torch.no_grad():
                     for p, v in zip(params, snap_p):
                         p.copy_(v)
@@ -223,8 +240,10 @@ class Trainer:
         else:
             self.model_optimizer.zero_grad(set_to_none=True)
         losses["loss"].backward()
-        if self.grad_sync is not None:
+        if self.grad_sync is not None and not self._local_only:
             self.grad_sync()
+        elif self.flat_grads is not None:
+            self.flat_grads.pack()            # capture warm-up: same memory traffic, no exchange
         self.model_optimizer.step()
         self.step += 1
         return outputs, losses

@@ -73,3 +73,24 @@ def test_vit_process_batch_on_cpu_host_port():
     outputs, losses = tr.train_step(batch)
     assert torch.isfinite(losses["loss"]) and outputs[("disp", 0)].shape == (B, 1, H, W)
     assert any(not torch.equal(a, b) for a, b in zip(before, tr.models["encoder"].parameters()))
+
+
+def test_capture_warm_up_steps_issue_no_collective():
+    """a graph-cache miss is a per-rank event, so the warm-up steps of a capture must not exchange
+    gradients (a rank that warms up would otherwise issue 3 collectives more than a rank that replays)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    o = MonodepthOptions().parse(("--no_cuda --weights_init scratch --height %d --width %d --batch_size %d"
+                                  % (H, W, B)).split())
+    tr = Trainer(o, backend=HostPortBackend())
+    tr.set_train()
+    calls = []
+    tr.grad_sync = lambda: calls.append(1)
+    batch = synthetic.synthetic_batch([1] * B, H, W, o.scales, device="cpu", seed=1)
+    tr._local_only = True
+    tr._eager_step(dict(batch))
+    assert calls == []
+    tr._local_only = False
+    tr._eager_step(dict(batch))
+    assert calls == [1]
+    assert Trainer.max_graphs >= 1 and tr.max_graphs >= 1
