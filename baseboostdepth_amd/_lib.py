@@ -18,6 +18,7 @@ MAX_CAND = 20
 POSE_STRIDE = 40
 PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
+PAIR_SHIFT = 16        # bits 16-23 of bbd_cand_t.kind: 1 + index of the pass partner (hint), 0 = none
 ABI_VERSION = 3
 
 _p = ctypes.c_void_p

@@ -1023,6 +1023,463 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused backward, sparse-item form (round 3; the shipped one).
+//
+// The round-2 form above runs its whole pipeline once per candidate that won ANY pixel around the tile: with the
+// boosted recipe's 12 warp candidates that is 12 x (warp the 36x20 halo'd region, 9 barriers), although every pixel
+// has exactly ONE winner.  This form does only the work the arg-min map asks for:
+//   * an ITEM is a (staged cell, candidate) pair whose warped value some winner's 3x3 SSIM window needs, i.e. the
+//     candidate won at least one of the cell's 9 neighbouring loss pixels.  With 18 random winners that is 4.8 of 12
+//     warps per cell, with a coherent arg-min map ~1 - instead of "every present candidate everywhere";
+//   * candidates are taken two per PASS (the (T, T_error) pair of one source frame when the caller's table pairs them:
+//     same image, gathers side by side): both item lists are compacted - ballot + popcount, every list padded to whole
+//     64-lane chunks so that a chunk's pose row stays in SGPRs - and the chunks are dealt round-robin to the four waves;
+//   * W: a lane warps its item (projection with the forward's arithmetic, 6 x 8-byte gathers, blend) into that member's
+//     x planes and keeps d warped / d (ix, iy) and the depth in registers;
+//   * C: every wave owns a band of loss-pixel rows; its winners of the two members (wave-private compaction) read their
+//     3x3 x / y windows, form the SSIM partials (A, B, C per channel) and SCATTER (A + B x + C y) / 9 onto the window's
+//     texels - reflection at the image border folds in by scattering to the reflected texel - into accumulation planes
+//     PRIVATE to the wave (LDS float adds; the band planes of neighbouring waves overlap by two rows and are summed in
+//     wave order by the reader), so the result does not depend on timing: deterministic like the gather form, at a
+//     ninth of its loads;
+//   * G: the lane that warped an item of one of the tile's own texels reads its accumulated texel gradient, applies
+//     d warped / d (ix, iy) from its registers, chains to depth and to the 12 entries of P; one reduce-scatter per chunk.
+// Per pass: 4 barriers (list | x planes | accumulators | partials) instead of 9 per candidate.
+// LDS 52.5 KB -> three workgroups per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int B3_CELLS = BH * BS2;                  // 720 staged cells (20 x 36, halo 2)
+constexpr int B3_LPIX = CH * CW2;                   // 612 loss pixels (18 x 34, halo 1)
+constexpr int B3_MAXCH = 6;                         // chunks per wave and pass: 2 members x 720 cells -> 24 chunks / 4
+constexpr int B3_LIST = 4 * B3_MAXCH * 64;          // 1536 list entries
+constexpr int B3_NCELL = (B3_CELLS + NT2 - 1) / NT2;   // 3 cells per thread
+// loss-row bands of the four waves and the own-texel rows (cell rows 2..17) their winners' windows can reach
+__device__ __constant__ const int b3_band0[5] = {0, 5, 9, 14, 18};
+constexpr int B3_R0[4] = {2, 5, 9, 14};             // first own cell row of a band's accumulation planes
+constexpr int B3_ROWS[4] = {5, 6, 7, 4};            // rows of them
+constexpr int B3_BASE[4] = {0, 5 * 192, 11 * 192, 18 * 192};   // float offset of a band's planes [member][ch][row][32]
+constexpr int B3_ACC = 22 * 192;                    // 4224 floats
+
+__device__ __forceinline__ int lane_prefix(unsigned long long m) {    // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+struct PassCand {
+  int id;                // arg-min id of the candidate, -1 = no member
+  bbd_cand_t cd;
+};
+// Next pass: the lowest warp candidate not done yet and its partner - the table's pairing hint (bits 16-23 of `kind` =
+// 1 + index of the candidate that samples the same source image) if it names one that is still to do, else the next
+// lowest.  All scalar.
+__device__ __forceinline__ bool next_pass(const bbd_cand_t* cand, unsigned* todo, PassCand* m0, PassCand* m1) {
+  m0->id = m1->id = -1;
+  if (*todo == 0u) return false;
+  m0->id = __builtin_ctz(*todo);
+  *todo &= *todo - 1u;
+  m0->cd = load_cand(cand + m0->id);
+  const int hint = ((m0->cd.kind >> 16) & 0xff) - 1;
+  if (hint >= 0 && hint < 32 && ((*todo >> hint) & 1u)) m1->id = hint;
+  else if (*todo != 0u) m1->id = __builtin_ctz(*todo);
+  if (m1->id >= 0) {
+    *todo &= ~(1u << m1->id);
+    m1->cd = load_cand(cand + m1->id);
+  } else {
+    m1->cd = m0->cd;
+  }
+  return true;
+}
+
+#ifndef BBD_BWD3_WAVES
+#define BBD_BWD3_WAVES 3
+#endif
+__global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_y[3][B3_CELLS];
+  __shared__ __attribute__((aligned(16))) float s_x[2][3][B3_CELLS];
+  __shared__ __attribute__((aligned(16))) float s_acc[B3_ACC];
+  __shared__ __attribute__((aligned(16))) float s_gd[2][TH * TW2];
+  __shared__ uint16_t s_list[B3_LIST];
+  __shared__ uint16_t s_wlist[4][192];
+  __shared__ uint8_t s_id[640];
+  __shared__ float s_red[4][2][12];
+  __shared__ int s_cnt[4][2];
+  const BbdDims dm = a.dm;
+  const int H = dm.H, W = dm.W, hw = H * W;
+  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = bid / (a.S * a.ntiles);
+  bid -= b * a.S * a.ntiles;
+  const int s = bid / a.ntiles;
+  const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
+  const size_t img = (size_t)3 * hw;
+  const size_t sb = (size_t)s * a.B + b;
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  const uint8_t* am = a.argmin + sb * hw;
+  const float g = uniform_load(a.gscale + s);
+  const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
+  const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- set-up: arg-min ids of the loss pixels, target cells, accumulators
+  {
+    const float* tg = a.target + (size_t)b * img;
+    float tv[B3_NCELL][3];
+    unsigned idw = 0u;
+#pragma unroll
+    for (int k = 0; k < B3_NCELL; ++k) {
+      const int i = k * NT2 + tid;
+      const int ii = i < B3_LPIX ? i : B3_LPIX - 1;
+      const int lr = ii / CW2, lc = ii - lr * CW2;
+      const int py = tc.ty0 + lr - 1, px = tc.tx0 + lc - 1;
+      const bool in = py >= 0 && py < H && px >= 0 && px < W;
+      idw |= (in ? (unsigned)am[py * W + px] : 255u) << (8 * k);
+      const int ci = i < B3_CELLS ? i : B3_CELLS - 1;
+      const int r = ci / BS2, c = ci - r * BS2;
+      const int yy = min(max(tc.ty0 + r - 2, 0), H - 1), xx = min(max(tc.tx0 + c - 2, 0), W - 1);
+      tv[k][0] = tg[yy * W + xx];
+      tv[k][1] = tg[yy * W + xx + hw];
+      tv[k][2] = tg[yy * W + xx + 2 * hw];
+    }
+#pragma unroll
+    for (int k = 0; k < B3_NCELL; ++k) {
+      const int i = k * NT2 + tid;
+      if (i < B3_LPIX) s_id[i] = (uint8_t)(idw >> (8 * k));
+      if (i < B3_CELLS) {
+        s_y[0][i] = tv[k][0];
+        s_y[1][i] = tv[k][1];
+        s_y[2][i] = tv[k][2];
+      }
+    }
+    for (int i = tid; i < B3_ACC / 4; i += NT2) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 2 * TH * TW2 / 4; i += NT2) reinterpret_cast<float4*>(&s_gd[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // own pixels of this thread (2-pixel strip): depth and gradient accumulators
+  const int ly = tid / SPR2, lx0 = (tid % SPR2) * PPT2;
+  const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
+  const bool q_row_ok = qy < H;
+  float gdepth[PPT2] = {0.0f, 0.0f};
+  // warp candidates of this sample (uniform)
+  const int nc = uniform_load(a.ncand + b);
+  const bbd_cand_t* ctab = a.cand + b * BBD_MAX_CAND;
+  unsigned warpmask = 0u;
+  for (int c = 0; c < nc; ++c)
+    if ((uniform_load(&ctab[c].kind) & KIND_MASK) == BBD_KIND_WARP) warpmask |= 1u << c;
+  __syncthreads();
+
+  // ---- per-cell candidate masks (which candidates' warps the cell's neighbourhood needs) and this wave's band ids
+  unsigned cmask[B3_NCELL];
+#pragma unroll
+  for (int k = 0; k < B3_NCELL; ++k) {
+    const int i = k * NT2 + tid;
+    const int ci = i < B3_CELLS ? i : B3_CELLS - 1;
+    const int r = ci / BS2, c = ci - r * BS2;
+    const int py = tc.ty0 + r - 2, px = tc.tx0 + c - 2;
+    unsigned m = 0u;
+    if (i < B3_CELLS && py >= 0 && py < H && px >= 0 && px < W) {
+#pragma unroll
+      for (int dr = 0; dr < 3; ++dr) {
+        const int lr = r - 2 + dr;             // loss row of image row py - 1 + dr
+        if (lr < 0 || lr >= CH) continue;
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) {
+          const int lc = c - 2 + dc;
+          if (lc < 0 || lc >= CW2) continue;
+          const unsigned id = s_id[lr * CW2 + lc];
+          if (id < 32u) m |= 1u << id;
+        }
+      }
+    }
+    cmask[k] = m & warpmask;
+  }
+  const int band0 = b3_band0[wv], band_n = (b3_band0[wv + 1] - band0) * CW2;      // this wave's loss pixels
+  unsigned bidw = 0xffffffu;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int idx = lane + 64 * k;
+    if (idx < band_n) bidw = (bidw & ~(0xffu << (8 * k))) | ((unsigned)s_id[band0 * CW2 + idx] << (8 * k));
+  }
+  const int acc_r0 = B3_R0[0] * (wv == 0) + B3_R0[1] * (wv == 1) + B3_R0[2] * (wv == 2) + B3_R0[3] * (wv == 3);
+  const int acc_rows = B3_ROWS[0] * (wv == 0) + B3_ROWS[1] * (wv == 1) + B3_ROWS[2] * (wv == 2) + B3_ROWS[3] * (wv == 3);
+  const int acc_base = B3_BASE[0] * (wv == 0) + B3_BASE[1] * (wv == 1) + B3_BASE[2] * (wv == 2) + B3_BASE[3] * (wv == 3);
+
+  // item counts of a pass's two members in this wave -> s_cnt
+  auto publish_counts = [&](const PassCand& m0, const PassCand& m1) {
+    int n0 = 0, n1 = 0;
+#pragma unroll
+    for (int k = 0; k < B3_NCELL; ++k) {
+      n0 += __popcll(__ballot(m0.id >= 0 && ((cmask[k] >> m0.id) & 1u)));
+      n1 += __popcll(__ballot(m1.id >= 0 && ((cmask[k] >> m1.id) & 1u)));
+    }
+    if (lane == 0) { s_cnt[wv][0] = n0; s_cnt[wv][1] = n1; }
+  };
+
+  unsigned todo = warpmask;
+  PassCand m0, m1;
+  bool more = next_pass(ctab, &todo, &m0, &m1);
+  if (more) publish_counts(m0, m1);
+  __syncthreads();
+
+  while (more) {
+    // ---- item lists of the pass: [member 0 | pad to 64][member 1 | pad to 64]
+    int n0 = 0, n1 = 0, before0 = 0, before1 = 0;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) {
+      const int c0 = s_cnt[w4][0], c1 = s_cnt[w4][1];
+      before0 += w4 < wv ? c0 : 0;
+      before1 += w4 < wv ? c1 : 0;
+      n0 += c0;
+      n1 += c1;
+    }
+    const int n0p = (n0 + 63) & ~63, n1p = (n1 + 63) & ~63;
+    const int nchunk = (n0p + n1p) >> 6;
+    float* gp0 = a.grad_proj + (((size_t)s * a.NP + m0.cd.pose) * a.ntiles + tc.tile) * 12;
+    float* gp1 = a.grad_proj + (((size_t)s * a.NP + m1.cd.pose) * a.ntiles + tc.tile) * 12;
+    const PassCand c0 = m0, c1 = m1;
+    more = next_pass(ctab, &todo, &m0, &m1);
+    if (nchunk == 0) {
+      // nobody's window needs these candidates here: their pose gradient of this tile is zero
+      if (tid < 12) gp0[tid] = 0.0f;
+      if (c1.id >= 0 && tid >= 64 && tid < 76) gp1[tid - 64] = 0.0f;
+      __syncthreads();                     // every wave has read s_cnt
+      if (more) publish_counts(m0, m1);
+      __syncthreads();
+      continue;
+    }
+    {
+      int p0 = before0, p1 = n0p + before1;
+#pragma unroll
+      for (int k = 0; k < B3_NCELL; ++k) {
+        const int i = k * NT2 + tid;
+        const bool f0 = (cmask[k] >> c0.id) & 1u;
+        const bool f1 = c1.id >= 0 && ((cmask[k] >> c1.id) & 1u);
+        const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+        if (f0) s_list[p0 + lane_prefix(b0)] = (uint16_t)i;
+        if (f1) s_list[p1 + lane_prefix(b1)] = (uint16_t)i;
+        p0 += __popcll(b0);
+        p1 += __popcll(b1);
+      }
+      if (tid < n0p - n0) s_list[n0 + tid] = (uint16_t)0xffff;
+      if (tid >= 64 && tid - 64 < n1p - n1) s_list[n0p + n1 + tid - 64] = (uint16_t)0xffff;
+    }
+    __syncthreads();
+
+    // ---- W: warp the items.  Chunk j (64 items of ONE member) goes to wave j % 4; slot i of a wave = chunk wv + 4 i.
+    const int nslot = nchunk > wv ? (nchunk - wv + 3) >> 2 : 0;
+    float dvx[B3_MAXCH][3], dvy[B3_MAXCH][3], idep[B3_MAXCH];
+    int icell[B3_MAXCH];
+    const float* src0 = a.frames.base[c0.cd.slot] + (size_t)c0.cd.row * img;
+    const float* src1 = a.frames.base[c1.cd.slot] + (size_t)c1.cd.row * img;
+    const float* prow0 = a.pose + (size_t)c0.cd.pose * BBD_PROJ_STRIDE;
+    const float* prow1 = a.pose + (size_t)c1.cd.pose * BBD_PROJ_STRIDE;
+#pragma unroll
+    for (int i = 0; i < B3_MAXCH; ++i) {
+      icell[i] = -1;
+      if (i >= nslot) continue;
+      const int j = wv + 4 * i;
+      const int mem = (j << 6) >= n0p;
+      const float* src = mem ? src1 : src0;
+      const float* prow = mem ? prow1 : prow0;
+      float pj[21];
+#pragma unroll
+      for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
+      const unsigned e = s_list[(j << 6) + lane];
+      const bool valid = e != 0xffffu;
+      const int cell = valid ? (int)e : 2 * BS2 + 2;          // padding lanes: the tile's first own texel (never stored)
+      const int r = cell / BS2, c = cell - r * BS2;
+      const int py = tc.ty0 + r - 2, px = tc.tx0 + c - 2;
+      const float dep = depth_at(dsrc, py, px, H, W);
+      BbdSample sm;
+      bbd_project_bwd(pj, px, py, dep, dm, &sm);
+      BbdTaps t;
+      bbd_taps(sm.ix, sm.iy, dm, &t);
+      float v[3][4];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) bbd_fetch4(src + ch * hw, &t, v[ch]);
+      const bool own = valid && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2;
+      icell[i] = own ? cell : -1;
+      idep[i] = dep;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float val = bbd_bilerp(v[ch], &t);
+        if (valid) s_x[mem][ch][cell] = val;
+        dvx[i][ch] = sm.clipx ? 0.0f : (v[ch][1] - v[ch][0]) * t.s + (v[ch][3] - v[ch][2]) * t.n;
+        dvy[i][ch] = sm.clipy ? 0.0f : (v[ch][2] - v[ch][0]) * t.e + (v[ch][3] - v[ch][1]) * t.w;
+      }
+    }
+    __syncthreads();
+
+    // ---- C: this wave's winners of the two members -> SSIM partials -> scatter onto the window texels
+    {
+      int nwin = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const unsigned id = (bidw >> (8 * k)) & 0xffu;
+        const int memb = id == (unsigned)c0.id ? 0 : ((c1.id >= 0 && id == (unsigned)c1.id) ? 1 : -1);
+        const unsigned long long bm = __ballot(memb >= 0);
+        if (memb >= 0) s_wlist[wv][nwin + lane_prefix(bm)] = (uint16_t)((lane + 64 * k) | (memb << 15));
+        nwin += __popcll(bm);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int base = 0; base < nwin; base += 64) {
+        if (base + lane >= nwin) continue;
+        const unsigned e = s_wlist[wv][base + lane];
+        const int memb = (int)(e >> 15), idx = (int)(e & 0x7fffu);
+        const int lrr = idx / CW2;
+        const int lr = band0 + lrr, lc = idx - lrr * CW2;
+        const int py = tc.ty0 + lr - 1, px = tc.tx0 + lc - 1;
+        int rr[3], cc[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          rr[d] = bbd_reflect(py + d - 1, H) - tc.ty0 + 2;
+          cc[d] = bbd_reflect(px + d - 1, W) - tc.tx0 + 2;
+        }
+        const float* xp = &s_x[0][0][0] + memb * 3 * B3_CELLS;
+        float* ap = s_acc + acc_base + memb * 3 * acc_rows * 32;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          float xv[3][3], yv[3][3];
+#pragma unroll
+          for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) {
+              xv[dr][dc] = xp[ch * B3_CELLS + rr[dr] * BS2 + cc[dc]];
+              yv[dr][dc] = s_y[ch][rr[dr] * BS2 + cc[dc]];
+            }
+          float A = 0.0f, Bc = 0.0f, Cc = 0.0f;
+          if (!a.no_ssim) {
+            float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+              for (int dc = 0; dc < 3; ++dc) {
+                const float xq = xv[dr][dc], yq = yv[dr][dc];
+                sx_ += xq; sxx += xq * xq; sxy += xq * yq; sy_ += yq; syy += yq * yq;
+              }
+            float mu_y, sg_y;
+            bbd_ystats(sy_, syy, &mu_y, &sg_y);
+            bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
+            A *= w_ssim * (1.0f / 9.0f); Bc *= w_ssim * (1.0f / 9.0f); Cc *= w_ssim * (1.0f / 9.0f);
+          }
+#pragma unroll
+          for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) {
+              float val = A + Bc * xv[dr][dc] + Cc * yv[dr][dc];
+              if (dr == 1 && dc == 1) {
+                const float df = xv[1][1] - yv[1][1];
+                val += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
+              } else if (a.no_ssim) {
+                continue;
+              }
+              const int r = rr[dr], c = cc[dc];
+              if (r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2)
+                atomicAdd(&ap[(ch * acc_rows + (r - acc_r0)) * 32 + (c - 2)], val);
+            }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- G: own-texel items: accumulated texel gradient -> sampling coordinates -> depth and P
+    {
+      float tot0[3] = {0.f, 0.f, 0.f}, tot1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < B3_MAXCH; ++i) {
+        if (i >= nslot) continue;
+        const int j = wv + 4 * i;
+        const int mem = (j << 6) >= n0p;
+        const float* prow = mem ? prow1 : prow0;
+        const int nopose = (mem ? c1.cd.kind : c0.cd.kind) & FLAG_NO_POSE_GRAD;
+        float gP[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
+        const int cell = icell[i];
+        if (cell >= 0) {
+          const int r = cell / BS2, c = cell - r * BS2;
+          float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) {
+            if (r < B3_R0[w4] || r >= B3_R0[w4] + B3_ROWS[w4]) continue;
+            float* ap = s_acc + B3_BASE[w4] + (mem * 3 * B3_ROWS[w4] + (r - B3_R0[w4])) * 32 + (c - 2);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              gx[ch] += ap[ch * B3_ROWS[w4] * 32];
+              ap[ch * B3_ROWS[w4] * 32] = 0.0f;
+            }
+          }
+          if (gx[0] != 0.0f || gx[1] != 0.0f || gx[2] != 0.0f) {
+            float pj[21];
+#pragma unroll
+            for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
+            const float gix = gx[0] * dvx[i][0] + gx[1] * dvx[i][1] + gx[2] * dvx[i][2];
+            const float giy = gx[0] * dvy[i][0] + gx[1] * dvy[i][1] + gx[2] * dvy[i][2];
+            BbdSample sm;
+            bbd_sample_smooth(pj, tc.tx0 + c - 2, tc.ty0 + r - 2, idep[i], &sm);
+            float gd;
+            bbd_project_grad(pj, &sm, gix, giy, &gd, gP);
+            s_gd[mem][(r - 2) * TW2 + (c - 2)] = gd;
+          }
+        }
+        if (!nopose) {
+          float t3[3];
+          wave_sum12(gP, t3);
+          if (mem) { tot1[0] += t3[0]; tot1[1] += t3[1]; tot1[2] += t3[2]; }
+          else { tot0[0] += t3[0]; tot0[1] += t3[1]; tot0[2] += t3[2]; }
+        }
+      }
+      if ((lane & 15) == 15) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          s_red[wv][0][wave_sum12_index(k, lane)] = tot0[k];
+          s_red[wv][1][wave_sum12_index(k, lane)] = tot1[k];
+        }
+      }
+    }
+    if (more) publish_counts(m0, m1);
+    __syncthreads();
+
+    // ---- end of pass: pose-gradient partials of the tile, depth gradient of the own pixels
+    if (tid < 24) {
+      const int mem = tid >= 12, k = tid - 12 * mem;
+      if (mem == 0 || c1.id >= 0) {
+        const int nopose = (mem ? c1.cd.kind : c0.cd.kind) & FLAG_NO_POSE_GRAD;
+        float t = 0.0f;
+        if (!nopose) t = ((s_red[0][mem][k] + s_red[1][mem][k]) + s_red[2][mem][k]) + s_red[3][mem][k];
+        (mem ? gp1 : gp0)[k] = t;
+      }
+    }
+    {
+      float2* g0 = reinterpret_cast<float2*>(&s_gd[0][ly * TW2 + lx0]);
+      float2* g1 = reinterpret_cast<float2*>(&s_gd[1][ly * TW2 + lx0]);
+      const float2 u = *g0, v2 = *g1;
+      gdepth[0] += u.x + v2.x;
+      gdepth[1] += u.y + v2.y;
+      *g0 = make_float2(0.f, 0.f);
+      *g1 = make_float2(0.f, 0.f);
+    }
+  }
+
+  if (q_row_ok) {
+    if (a.ds.grad_wrt_disp) {
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j)
+        if (qx0 + j < W) {
+          const float qd = depth_at(dsrc, qy, qx0 + j, H, W);
+          gdepth[j] *= -dsrc.span * qd * qd;
+        }
+    }
+    float* o = a.grad_depth + sb * hw + qy * W + qx0;
+    if ((qx0 + PPT2 <= W) && ((W & 1) == 0)) {
+      *reinterpret_cast<float2*>(o) = make_float2(gdepth[0], gdepth[1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT2; ++j)
+        if (qx0 + j < W) o[j] = gdepth[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // disp -> depth (bilinear upsample + reciprocal affine), forward and adjoint.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void disp_to_depth_fwd_kernel(const float* __restrict__ disp,
@@ -1802,9 +2259,12 @@ int fill_frames(const void* const* frames, FramePtrs* out) {
   return 0;
 }
 
-// BBD_XCD_REMAP=0 restores the plain blockIdx order (A/B timing only)
+// BBD_XCD_REMAP=1 turns the XCD-aware work order on.  Measured (profiles/r03/xcd_remap_ab.txt): with per-pixel random
+// disparities (scattered gathers, tools/kernel_bench.py boost7) forward -11 %, backward -3 %; inside the training step
+// (smooth network disparities: neighbouring tiles' gathers already hit L1/L2) boosted 0.2143 -> 0.2133 ms, MD2 forward
+// 0.1744 -> 0.1789 ms (the four scales of a sample no longer run side by side on all XCDs).  Off by default.
 int xcd_remap_enabled() {
-  static const int on = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr || e[0] != '0'; }();
+  static const int on = [] { const char* e = getenv("BBD_XCD_REMAP"); return e != nullptr && e[0] == '1'; }();
   return on;
 }
 
@@ -1904,6 +2364,12 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
   a.remap = xcd_remap_enabled();
+  static const int form = [] { const char* e = getenv("BBD_BWD"); return e ? atoi(e) : 3; }();
+  if (!coords && form == 3) {
+    hipLaunchKernelGGL(warp_ssim_min_bwd3_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return launch_status();
+  }
   if (coords)
     hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                        static_cast<hipStream_t>(stream), a);

@@ -13,7 +13,7 @@ so no gathered image copies and no concatenated loss stacks are ever materialise
 import numpy as np
 import torch
 
-from ._lib import MAX_CAND, MAX_FRAME_SLOTS, KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD
+from ._lib import MAX_CAND, MAX_FRAME_SLOTS, KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD, PAIR_SHIFT
 
 STEREO = "s"
 
@@ -105,6 +105,15 @@ class ReprojectionPlan:
                 names.append(("I", f))
             if len(entries) > MAX_CAND:
                 raise ValueError("too many candidates")
+            # pairing hint for the kernels (bits 16-23 of `kind` = 1 + index of the candidate to take in the same
+            # pass): the error-induced warp of a frame samples the same source image as its true-pose warp, a few
+            # pixels apart, so the pair's gathers share cache lines (include/bbd_hip.h, bbd_cand_t)
+            index = {nm: k for k, nm in enumerate(names)}
+            entries = [list(e) for e in entries]
+            for k, (kind, f) in enumerate(names):
+                other = index.get(("E" if kind == "T" else "T", f)) if kind in ("T", "E") else None
+                if other is not None:
+                    entries[k][0] |= (other + 1) << PAIR_SHIFT
             cand[b, :len(entries)] = np.array(entries, dtype=np.int32)
             ncand[b] = len(entries)
             self.cand_names.append(names)

@@ -39,6 +39,12 @@ extern "C" {
 #define BBD_KIND_WARP 0          /* reprojection or error-induced candidate */
 #define BBD_KIND_IDENT 1         /* identity candidate (+ noise) */
 #define BBD_FLAG_NO_POSE_GRAD 0x100 /* warp row whose pose is a constant (stereo_T, T_error) */
+/* Optional pairing hint of a WARP candidate, bits 16-23 of `kind`: 1 + the index (arg-min id) of another warp
+ * candidate of the same sample that samples the SAME source image (the error-induced warp of a frame and its true-pose
+ * warp, trainer.py:439-442).  The backward takes two candidates per pass and prefers the hinted partner (their gathers
+ * share cache lines); 0 = no hint (the next candidate in id order is taken).  A speed hint only: results do not depend
+ * on it. */
+#define BBD_PAIR_SHIFT 16
 
 #define BBD_E_BADARG (-1)
 #define BBD_E_TOOMANY (-2)

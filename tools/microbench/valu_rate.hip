@@ -18,6 +18,9 @@ static const char* kind_name[KINDS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_cm
                                        "v_mul_lo_u32", "v_lshl_add_u64", "v_mul+v_cvt_i32_f32+v_cvt_f32_i32", "v_mul+v_floor_f32",
                                        "v_add_f32 dpp row_shr"};
 
+constexpr int REPS = 16;     // 128 vector instructions per loop iteration: the loop's own s_add / s_cmp / taken branch
+                             // (~28 cycles per iteration for one wave) is < 6 % of an iteration; with 8 per iteration
+                             // (round 2's form) it was 47 % and every kind read ~2x too slow
 template <int KIND>
 __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk, int iters, float b, float c) {
   float a[8];
@@ -28,6 +31,8 @@ __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk
   const unsigned ub = __float_as_uint(b) | 1u;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < REPS; ++rep)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (KIND == FMA) a[i] = fmaf(a[i], b, c);
@@ -71,10 +76,10 @@ static void run_kind(float* out, unsigned long long* clk, int iters) {
     unsigned long long h[2];
     hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
     const double ghz = (double)h[0] / (double)h[1] * 0.1;           // s_memrealtime ticks at 100 MHz
-    const double instr_per_simd = (double)iters * 8 * per_elem * wps;
+    const double instr_per_simd = (double)iters * 8 * REPS * per_elem * wps;
     const double ns = ms * 1e6 / instr_per_simd;
     printf("%-28s waves/SIMD %d: %8.3f ms  %.3f ns/wave-instr/SIMD  clock %.2f GHz -> %.2f cycles/instr/SIMD   (one wave: %.2f cycles between its instructions)\n",
-           kind_name[KIND], wps, ms, ns, ghz, ns * ghz, (double)h[0] / (iters * 8.0 * per_elem));
+           kind_name[KIND], wps, ms, ns, ghz, ns * ghz, (double)h[0] / (iters * 8.0 * REPS * per_elem));
   }
 }
 
@@ -85,9 +90,9 @@ int main() {
   hipMalloc(&clk, 64);
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, 0);
-  printf("# %s, %d CUs, clockRate %d kHz; 8 independent chains per lane, 20000 iterations, 256-thread blocks (1 wave per SIMD each)\n",
+  printf("# %s, %d CUs, clockRate %d kHz; 8 independent chains per lane, 2000 iterations x 128 instructions, 256-thread blocks (1 wave per SIMD each)\n",
          p.gcnArchName, p.multiProcessorCount, p.clockRate);
-  const int iters = 20000;
+  const int iters = 2000;
   run_kind<FMA>(out, clk, iters);
   run_kind<MULADD>(out, clk, iters);
   run_kind<CMPSEL>(out, clk, iters);
@@ -98,10 +103,10 @@ int main() {
   run_kind<FLOOR>(out, clk, iters);
   run_kind<DPP>(out, clk, iters);
   // a long run of the densest kind: the clock the chip settles at after ~2 s of back-to-back launches
-  for (int rep = 0; rep < 40; ++rep) hipLaunchKernelGGL(chain<FMA>, dim3(256 * 4), dim3(256), 0, 0, out, clk, 200000, 1.0001f, 0.5f);
+  for (int rep = 0; rep < 40; ++rep) hipLaunchKernelGGL(chain<FMA>, dim3(256 * 4), dim3(256), 0, 0, out, clk, 20000, 1.0001f, 0.5f);
   hipDeviceSynchronize();
   unsigned long long h[2];
   hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
-  printf("# after 40 x 200000-iteration v_fma launches at 4 waves/SIMD: clock %.2f GHz\n", (double)h[0] / (double)h[1] * 0.1);
+  printf("# after 40 x 20000-iteration v_fma launches at 4 waves/SIMD: clock %.2f GHz\n", (double)h[0] / (double)h[1] * 0.1);
   return 0;
 }
