@@ -1118,6 +1118,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  BBD_STAMP(0);
+  int pass_no = 0;
   // ---- set-up: arg-min ids of the loss pixels, target cells, accumulators
   {
     const float* tg = a.target + (size_t)b * img;
@@ -1163,6 +1165,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
   for (int c = 0; c < nc; ++c)
     if ((uniform_load(&ctab[c].kind) & KIND_MASK) == BBD_KIND_WARP) warpmask |= 1u << c;
   __syncthreads();
+  BBD_STAMP(1);
 
   // ---- per-cell candidate masks (which candidates' warps the cell's neighbourhood needs) and this wave's band ids
   unsigned cmask[B3_NCELL];
@@ -1216,8 +1219,12 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
   bool more = next_pass(ctab, &todo, &m0, &m1);
   if (more) publish_counts(m0, m1);
   __syncthreads();
+  BBD_STAMP(2);
 
   while (more) {
+    const int sp = 3 + 6 * pass_no;      // stamps of the first two passes only
+    const bool stamp_pass = pass_no < 2;
+    ++pass_no;
     // ---- item lists of the pass: [member 0 | pad to 64][member 1 | pad to 64]
     int n0 = 0, n1 = 0, before0 = 0, before1 = 0;
 #pragma unroll
@@ -1260,6 +1267,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
       if (tid >= 64 && tid - 64 < n1p - n1) s_list[n0p + n1 + tid - 64] = (uint16_t)0xffff;
     }
     __syncthreads();
+    if (stamp_pass) BBD_STAMP(sp);
 
     // ---- W: warp the items.  Chunk j (64 items of ONE member) goes to wave j % 4; slot i of a wave = chunk wv + 4 i.
     const int nslot = nchunk > wv ? (nchunk - wv + 3) >> 2 : 0;
@@ -1304,7 +1312,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         dvy[i][ch] = sm.clipy ? 0.0f : (v[ch][2] - v[ch][0]) * t.e + (v[ch][3] - v[ch][1]) * t.w;
       }
     }
+    if (stamp_pass) BBD_STAMP(sp + 1);
     __syncthreads();
+    if (stamp_pass) BBD_STAMP(sp + 2);
 
     // ---- C: this wave's winners of the two members -> SSIM partials -> scatter onto the window texels
     {
@@ -1378,7 +1388,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         }
       }
     }
+    if (stamp_pass) BBD_STAMP(sp + 3);
     __syncthreads();
+    if (stamp_pass) BBD_STAMP(sp + 4);
 
     // ---- G: own-texel items: accumulated texel gradient -> sampling coordinates -> depth and P
     {
@@ -1436,6 +1448,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
       }
     }
     if (more) publish_counts(m0, m1);
+    if (stamp_pass) BBD_STAMP(sp + 5);
     __syncthreads();
 
     // ---- end of pass: pose-gradient partials of the tile, depth gradient of the own pixels
@@ -1477,6 +1490,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         if (qx0 + j < W) o[j] = gdepth[j];
     }
   }
+  BBD_STAMP(20);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -131,6 +131,15 @@ BBD_HD BbdDims bbd_dims(int H, int W) {
   return d;
 }
 
+/* Two-operation expressions of the reference whose second operation is an exact scaling by 2 or 1/2: one FMA gives
+ * the same bits, because scaling by a power of two commutes with rounding (no overflow / subnormal in range):
+ *   (n - 0.5) * 2      == RN(2 n - 1)      = fma(n, 2, -1)        layers.py:193
+ *   (g + 1) / 2        == RN(g / 2 + 1/2)  = fma(g, 0.5, 0.5)     ATen grid_sampler_unnormalize (align_corners)
+ *   2 * a * b + C      == RN(2 (a b) + C)  = fma(RN(a b), 2, C)   layers.py:244 (2 a is exact, so (2a) b == 2 (a b))
+ * Checked bit for bit against the reference's golden vectors on both tiers. */
+BBD_HD float bbd_norm_to_grid(float n) { return fmaf(n, 2.0f, -1.0f); }
+BBD_HD float bbd_grid_to_unit(float g) { return fmaf(g, 0.5f, 0.5f); }
+
 /* ---------------------------------------------------------------- projection (A2, A3, A4) */
 struct BbdSample {
   float ix, iy;      /* clamped source coordinates in pixels */
@@ -201,16 +210,16 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const Bb
     nu = o->u / wm1;
     nv = o->v / hm1;
   }
-  const float gx = (nu - 0.5f) * 2.0f;
-  const float gy = (nv - 0.5f) * 2.0f;
+  const float gx = bbd_norm_to_grid(nu);
+  const float gy = bbd_norm_to_grid(nv);
 #else
   bbd_div2(qx, qy, o->zi, &o->u, &o->v);
   /* layers.py:191-193 normalise, then ATen grid_sampler unnormalise (align_corners=True) */
-  const float gx = (bbd_div_const(o->u, wm1, dm.rw) - 0.5f) * 2.0f;
-  const float gy = (bbd_div_const(o->v, hm1, dm.rh) - 0.5f) * 2.0f;
+  const float gx = bbd_norm_to_grid(bbd_div_const(o->u, wm1, dm.rw));
+  const float gy = bbd_norm_to_grid(bbd_div_const(o->v, hm1, dm.rh));
 #endif
-  float ix = ((gx + 1.0f) / 2.0f) * wm1;
-  float iy = ((gy + 1.0f) / 2.0f) * hm1;
+  float ix = bbd_grid_to_unit(gx) * wm1;
+  float iy = bbd_grid_to_unit(gy) * hm1;
   /* border padding: clip_coordinates; gradient is zeroed when the clamp is active */
   o->clipx = !(ix > 0.0f && ix < wm1);
   o->clipy = !(iy > 0.0f && iy < hm1);
@@ -237,10 +246,10 @@ BBD_HD void bbd_project_bwd(const float* proj, int xx, int yy, float depth, cons
   o->zi = qz + BBD_EPS;
   bbd_div2_unguarded(qx, qy, o->zi, &o->u, &o->v);
   const float wm1 = dm.wm1, hm1 = dm.hm1;
-  const float gx = (bbd_div_const_unguarded(o->u, wm1, dm.rw) - 0.5f) * 2.0f;
-  const float gy = (bbd_div_const_unguarded(o->v, hm1, dm.rh) - 0.5f) * 2.0f;
-  float ix = ((gx + 1.0f) / 2.0f) * wm1;
-  float iy = ((gy + 1.0f) / 2.0f) * hm1;
+  const float gx = bbd_norm_to_grid(bbd_div_const_unguarded(o->u, wm1, dm.rw));
+  const float gy = bbd_norm_to_grid(bbd_div_const_unguarded(o->v, hm1, dm.rh));
+  float ix = bbd_grid_to_unit(gx) * wm1;
+  float iy = bbd_grid_to_unit(gy) * hm1;
   o->clipx = !(ix > 0.0f && ix < wm1);
   o->clipy = !(iy > 0.0f && iy < hm1);
   ix = ix > 0.0f ? ix : 0.0f;
@@ -324,10 +333,11 @@ BBD_HD void bbd_ystats(float sy, float syy, float* mu_y, float* sig_y) {
 /* numerator and denominator of the SSIM ratio (layers.py:241-246), then the clamp of (1 - n/d)/2 */
 BBD_HD void bbd_ssim_nd(float sx, float sxx, float sxy, float mu_y, float sig_y, float* n, float* d) {
   const float mu_x = bbd_div9(sx);
-  const float sig_x = bbd_div9(sxx) - mu_x * mu_x;
-  const float sig_xy = bbd_div9(sxy) - mu_x * mu_y;
-  *n = (2.0f * mu_x * mu_y + BBD_C1) * (2.0f * sig_xy + BBD_C2);
-  *d = (mu_x * mu_x + mu_y * mu_y + BBD_C1) * (sig_x + sig_y + BBD_C2);
+  const float mxx = mu_x * mu_x, mxy = mu_x * mu_y;
+  const float sig_x = bbd_div9(sxx) - mxx;
+  const float sig_xy = bbd_div9(sxy) - mxy;
+  *n = fmaf(mxy, 2.0f, BBD_C1) * fmaf(sig_xy, 2.0f, BBD_C2);      /* (2 mu_x mu_y + C1)(2 sig_xy + C2), see above */
+  *d = (mxx + mu_y * mu_y + BBD_C1) * (sig_x + sig_y + BBD_C2);
 }
 BBD_HD float bbd_ssim_from_ratio(float q) {
   const float v = (1.0f - q) / 2.0f;

@@ -13,10 +13,13 @@
 #include <cstdio>
 #include <vector>
 
-enum Kind { FMA = 0, MULADD, CMPSEL, RCP, IMUL, ADD64, CVT, FLOOR, DPP, KINDS };
+enum Kind { FMA = 0, MULADD, CMPSEL, RCP, IMUL, ADD64, CVT, FLOOR, DPP, PKFMA, PKADD, PKMUL, IADD, MOVXOR, FMA_IADD, FMA_FLOOR, MAXMIN, KINDS };
 static const char* kind_name[KINDS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_cmp+v_cndmask(+add,mul)", "v_rcp_f32",
                                        "v_mul_lo_u32", "v_lshl_add_u64", "v_mul+v_cvt_i32_f32+v_cvt_f32_i32", "v_mul+v_floor_f32",
-                                       "v_add_f32 dpp row_shr"};
+                                       "v_add_f32 dpp row_shr", "v_pk_fma_f32 (2 fp32 per lane)", "v_pk_add_f32", "v_pk_mul_f32",
+                                       "v_add_u32", "v_xor_b32", "v_fma_f32 / v_add_u32 alternating", "v_fma_f32 / v_floor_f32 alternating",
+                                       "v_max_f32 / v_min_f32"};
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int REPS = 16;     // 128 vector instructions per loop iteration: the loop's own s_add / s_cmp / taken branch
                              // (~28 cycles per iteration for one wave) is < 6 % of an iteration; with 8 per iteration
@@ -24,10 +27,12 @@ constexpr int REPS = 16;     // 128 vector instructions per loop iteration: the 
 template <int KIND>
 __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk, int iters, float b, float c) {
   float a[8];
+  v2f pk[8];
   unsigned u[8];
   unsigned long long w[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x + i + 1.5f; u[i] = threadIdx.x * 7u + i + 3u; w[i] = (unsigned long long)out + u[i]; }
+  for (int i = 0; i < 8; ++i) { a[i] = threadIdx.x + i + 1.5f; u[i] = threadIdx.x * 7u + i + 3u; w[i] = (unsigned long long)out + u[i]; pk[i] = v2f{a[i], a[i] + 0.25f}; }
+  const v2f pb = {b, b * 1.0001f}, pc = {c, c + 0.125f};
   const unsigned ub = __float_as_uint(b) | 1u;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
@@ -39,7 +44,15 @@ __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk
       else if (KIND == MULADD) a[i] = (i & 1) ? a[i] + c : a[i] * b;
       else if (KIND == CMPSEL) a[i] = (i & 1) ? a[i] * b : (a[i] > c ? a[i] : b + a[i]);
       else if (KIND == RCP) a[i] = __builtin_amdgcn_rcpf(a[i]);
-      else if (KIND == IMUL) u[i] = u[i] * ub;
+      else if (KIND == IMUL) u[i] = u[i] * (u[(i + 1) & 7] | ub);
+      else if (KIND == PKFMA) pk[i] = __builtin_elementwise_fma(pk[i], pb, pc);
+      else if (KIND == PKADD) pk[i] = pk[i] + pc;
+      else if (KIND == PKMUL) pk[i] = pk[i] * pb;
+      else if (KIND == IADD) u[i] = u[i] + u[(i + 1) & 7];            // (partner operands: nothing for the compiler to fold)
+      else if (KIND == MOVXOR) u[i] = u[i] ^ u[(i + 3) & 7];
+      else if (KIND == FMA_IADD) { if (i & 1) u[i] = u[i] + u[(i + 2) & 7]; else a[i] = fmaf(a[i], b, c); }
+      else if (KIND == FMA_FLOOR) { if (i & 1) a[i] = floorf(a[i - 1]); else a[i] = fmaf(a[i], b, a[i + 1]); }
+      else if (KIND == MAXMIN) a[i] = (i & 1) ? fmaxf(a[i], a[(i + 1) & 7]) : fminf(a[i], a[(i + 3) & 7]);
       else if (KIND == ADD64) w[i] = (w[i] << 2) + (unsigned long long)u[i];
       else if (KIND == CVT) a[i] = (float)(int)(a[i] * b);          // v_mul + v_cvt_i32_f32 + v_cvt_f32_i32
       else if (KIND == FLOOR) a[i] = floorf(a[i] * b);               // v_mul + v_floor
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += a[i] + (float)u[i] + (float)(unsigned)w[i];
+  for (int i = 0; i < 8; ++i) s += a[i] + (float)u[i] + (float)(unsigned)w[i] + pk[i].x + pk[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
@@ -58,9 +71,9 @@ __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk
 template <int KIND>
 static void run_kind(float* out, unsigned long long* clk, int iters) {
   // wave-instructions per loop body, per chain element (what the compiler emits; check with -save-temps if a kind changes)
-  const double per_elem = KIND == MULADD || KIND == IMUL || KIND == FMA || KIND == RCP || KIND == ADD64 || KIND == DPP ? 1.0
-                          : KIND == CMPSEL ? 2.0    // odd: 1 mul; even: add + cmp + cndmask
-                          : KIND == CVT ? 3.0 : 2.0;
+  const double per_elem = KIND == CMPSEL ? 2.0        // odd: 1 mul; even: add + cmp + cndmask
+                          : KIND == CVT ? 3.0 : KIND == FLOOR ? 2.0 : KIND == IMUL ? 2.0 /* v_or + v_mul_lo */
+                          : KIND == MOVXOR ? 110.0 / 128 : KIND == MAXMIN ? 136.0 / 128 /* counted in the .s */ : 1.0;
   for (int wps : {1, 2, 4, 8}) {
     const int blocks = 256 * wps;
     hipEvent_t e0, e1;
@@ -102,6 +115,14 @@ int main() {
   run_kind<CVT>(out, clk, iters);
   run_kind<FLOOR>(out, clk, iters);
   run_kind<DPP>(out, clk, iters);
+  run_kind<PKFMA>(out, clk, iters);
+  run_kind<PKADD>(out, clk, iters);
+  run_kind<PKMUL>(out, clk, iters);
+  run_kind<IADD>(out, clk, iters);
+  run_kind<MOVXOR>(out, clk, iters);
+  run_kind<FMA_IADD>(out, clk, iters);
+  run_kind<FMA_FLOOR>(out, clk, iters);
+  run_kind<MAXMIN>(out, clk, iters);
   // a long run of the densest kind: the clock the chip settles at after ~2 s of back-to-back launches
   for (int rep = 0; rep < 40; ++rep) hipLaunchKernelGGL(chain<FMA>, dim3(256 * 4), dim3(256), 0, 0, out, clk, 20000, 1.0001f, 0.5f);
   hipDeviceSynchronize();
