@@ -1065,25 +1065,34 @@ __device__ __forceinline__ int lane_prefix(unsigned long long m) {    // set bit
 
 struct PassCand {
   int id;                // arg-min id of the candidate, -1 = no member
-  bbd_cand_t cd;
+  int kind, slot, row, pose;
 };
 // Next pass: the lowest warp candidate not done yet and its partner - the table's pairing hint (bits 16-23 of `kind` =
 // 1 + index of the candidate that samples the same source image) if it names one that is still to do, else the next
-// lowest.  All scalar.
-__device__ __forceinline__ bool next_pass(const bbd_cand_t* cand, unsigned* todo, PassCand* m0, PassCand* m1) {
+// lowest.  The sample's candidate table sits in LDS (staged once per workgroup): no scalar-memory round trips per pass.
+__device__ __forceinline__ void load_pass_cand(const int* s_cand, int id, PassCand* m) {
+  m->id = id;
+  m->kind = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 0]);
+  m->slot = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 1]);
+  m->row = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 2]);
+  m->pose = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 3]);
+}
+__device__ __forceinline__ bool next_pass(const int* s_cand, unsigned* todo, PassCand* m0, PassCand* m1) {
   m0->id = m1->id = -1;
   if (*todo == 0u) return false;
-  m0->id = __builtin_ctz(*todo);
+  const int a0 = __builtin_ctz(*todo);
   *todo &= *todo - 1u;
-  m0->cd = load_cand(cand + m0->id);
-  const int hint = ((m0->cd.kind >> 16) & 0xff) - 1;
-  if (hint >= 0 && hint < 32 && ((*todo >> hint) & 1u)) m1->id = hint;
-  else if (*todo != 0u) m1->id = __builtin_ctz(*todo);
-  if (m1->id >= 0) {
-    *todo &= ~(1u << m1->id);
-    m1->cd = load_cand(cand + m1->id);
+  load_pass_cand(s_cand, a0, m0);
+  const int hint = ((m0->kind >> 16) & 0xff) - 1;
+  int a1 = -1;
+  if (hint >= 0 && hint < 32 && ((*todo >> hint) & 1u)) a1 = hint;
+  else if (*todo != 0u) a1 = __builtin_ctz(*todo);
+  if (a1 >= 0) {
+    *todo &= ~(1u << a1);
+    load_pass_cand(s_cand, a1, m1);
   } else {
-    m1->cd = m0->cd;
+    *m1 = *m0;
+    m1->id = -1;
   }
   return true;
 }
@@ -1101,6 +1110,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
   __shared__ uint8_t s_id[640];
   __shared__ float s_red[4][2][12];
   __shared__ int s_cnt[4][2];
+  __shared__ int s_cand[BBD_MAX_CAND * 4];
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
   int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -1117,11 +1127,18 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
   const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // image borders inside the staged region: reflected window taps may then land on ONE texel from two winners
+  const bool interior = tc.tx0 >= 2 && tc.tx0 + TW2 + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
 
   BBD_STAMP(0);
   int pass_no = 0;
-  // ---- set-up: arg-min ids of the loss pixels, target cells, accumulators
+  // ---- set-up: candidate table, arg-min ids of the loss pixels, target cells, accumulators
+  const int nc = uniform_load(a.ncand + b);
+  unsigned warpmask;
   {
+    const int* ctab = reinterpret_cast<const int*>(a.cand + b * BBD_MAX_CAND);
+    int cw = 0;
+    if (tid < BBD_MAX_CAND * 4) cw = ctab[tid];
     const float* tg = a.target + (size_t)b * img;
     float tv[B3_NCELL][3];
     unsigned idw = 0u;
@@ -1140,6 +1157,23 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
       tv[k][1] = tg[yy * W + xx + hw];
       tv[k][2] = tg[yy * W + xx + 2 * hw];
     }
+    for (int i = tid; i < B3_ACC / 4; i += NT2) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 2 * TH * TW2 / 4; i += NT2) reinterpret_cast<float4*>(&s_gd[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < BBD_MAX_CAND * 4) s_cand[tid] = cw;
+    // warp candidates: lanes 4 c of wave 0 hold `kind` of candidate c
+    const unsigned long long wb = __ballot(tid < 4 * nc && (tid & 3) == 0 && (cw & KIND_MASK) == BBD_KIND_WARP);
+    if (tid == 0) s_cnt[0][0] = 0;
+    unsigned wm = 0u;
+    if (wv == 0) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) wm |= (unsigned)((wb >> (4 * c)) & 1ull) << c;
+    }
+    // candidates 16..19 sit in wave 1 (lanes 0, 4, 8, 12 of tid 64..79)
+    if (wv == 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wm |= (unsigned)((wb >> (4 * c)) & 1ull) << (16 + c);
+    }
+    if (lane == 0 && wv < 2) reinterpret_cast<unsigned*>(&s_red[0][0][0])[wv] = wm;
 #pragma unroll
     for (int k = 0; k < B3_NCELL; ++k) {
       const int i = k * NT2 + tid;
@@ -1150,22 +1184,16 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         s_y[2][i] = tv[k][2];
       }
     }
-    for (int i = tid; i < B3_ACC / 4; i += NT2) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < 2 * TH * TW2 / 4; i += NT2) reinterpret_cast<float4*>(&s_gd[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // own pixels of this thread (2-pixel strip): depth and gradient accumulators
+  // own pixels of this thread (2-pixel strip): gradient accumulators
   const int ly = tid / SPR2, lx0 = (tid % SPR2) * PPT2;
   const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
   const bool q_row_ok = qy < H;
   float gdepth[PPT2] = {0.0f, 0.0f};
-  // warp candidates of this sample (uniform)
-  const int nc = uniform_load(a.ncand + b);
-  const bbd_cand_t* ctab = a.cand + b * BBD_MAX_CAND;
-  unsigned warpmask = 0u;
-  for (int c = 0; c < nc; ++c)
-    if ((uniform_load(&ctab[c].kind) & KIND_MASK) == BBD_KIND_WARP) warpmask |= 1u << c;
   __syncthreads();
   BBD_STAMP(1);
+  warpmask = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(&s_red[0][0][0])[0] |
+                                            reinterpret_cast<const unsigned*>(&s_red[0][0][0])[1]);
 
   // ---- per-cell candidate masks (which candidates' warps the cell's neighbourhood needs) and this wave's band ids
   unsigned cmask[B3_NCELL];
@@ -1216,7 +1244,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
 
   unsigned todo = warpmask;
   PassCand m0, m1;
-  bool more = next_pass(ctab, &todo, &m0, &m1);
+  bool more = next_pass(s_cand, &todo, &m0, &m1);
   if (more) publish_counts(m0, m1);
   __syncthreads();
   BBD_STAMP(2);
@@ -1235,12 +1263,14 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
       n0 += c0;
       n1 += c1;
     }
+    n0 = __builtin_amdgcn_readfirstlane(n0);
+    n1 = __builtin_amdgcn_readfirstlane(n1);
     const int n0p = (n0 + 63) & ~63, n1p = (n1 + 63) & ~63;
     const int nchunk = (n0p + n1p) >> 6;
-    float* gp0 = a.grad_proj + (((size_t)s * a.NP + m0.cd.pose) * a.ntiles + tc.tile) * 12;
-    float* gp1 = a.grad_proj + (((size_t)s * a.NP + m1.cd.pose) * a.ntiles + tc.tile) * 12;
     const PassCand c0 = m0, c1 = m1;
-    more = next_pass(ctab, &todo, &m0, &m1);
+    float* gp0 = a.grad_proj + (((size_t)s * a.NP + c0.pose) * a.ntiles + tc.tile) * 12;
+    float* gp1 = a.grad_proj + (((size_t)s * a.NP + c1.pose) * a.ntiles + tc.tile) * 12;
+    more = next_pass(s_cand, &todo, &m0, &m1);
     if (nchunk == 0) {
       // nobody's window needs these candidates here: their pose gradient of this tile is zero
       if (tid < 12) gp0[tid] = 0.0f;
@@ -1269,47 +1299,62 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
     __syncthreads();
     if (stamp_pass) BBD_STAMP(sp);
 
-    // ---- W: warp the items.  Chunk j (64 items of ONE member) goes to wave j % 4; slot i of a wave = chunk wv + 4 i.
+    // ---- W: warp the items.  Chunk j (64 items of ONE member) goes to wave j % 4; slot i of a wave = chunk wv + 4 i:
+    //      a wave's member-0 chunks come first, so each member's projection row is read (scalar loads) once per phase.
     const int nslot = nchunk > wv ? (nchunk - wv + 3) >> 2 : 0;
+    const int nslot0 = (n0p >> 6) > wv ? ((n0p >> 6) - wv + 3) >> 2 : 0;      // slots that hold member-0 chunks
     float dvx[B3_MAXCH][3], dvy[B3_MAXCH][3], idep[B3_MAXCH];
     int icell[B3_MAXCH];
-    const float* src0 = a.frames.base[c0.cd.slot] + (size_t)c0.cd.row * img;
-    const float* src1 = a.frames.base[c1.cd.slot] + (size_t)c1.cd.row * img;
-    const float* prow0 = a.pose + (size_t)c0.cd.pose * BBD_PROJ_STRIDE;
-    const float* prow1 = a.pose + (size_t)c1.cd.pose * BBD_PROJ_STRIDE;
+    const float* src0 = a.frames.base[c0.slot] + (size_t)c0.row * img;
+    const float* src1 = a.frames.base[c1.slot] + (size_t)c1.row * img;
+    const float* prow0 = a.pose + (size_t)c0.pose * BBD_PROJ_STRIDE;
+    const float* prow1 = a.pose + (size_t)c1.pose * BBD_PROJ_STRIDE;
+    // first the list entries and the depths of every slot (independent loads, all in flight together) ...
 #pragma unroll
     for (int i = 0; i < B3_MAXCH; ++i) {
-      icell[i] = -1;
+      icell[i] = 2 * BS2 + 2;
+      idep[i] = 1.0f;
       if (i >= nslot) continue;
-      const int j = wv + 4 * i;
-      const int mem = (j << 6) >= n0p;
+      const unsigned e = s_list[((wv + 4 * i) << 6) + lane];
+      const int cell = e != 0xffffu ? (int)e : -1;
+      icell[i] = cell;
+      const int cc = cell >= 0 ? cell : 2 * BS2 + 2;          // padding lanes: the tile's first own texel (never stored)
+      const int r = cc / BS2, c = cc - r * BS2;
+      idep[i] = depth_at(dsrc, tc.ty0 + r - 2, tc.tx0 + c - 2, H, W);
+    }
+    // ... then one member at a time: projection with the forward's arithmetic, gathers, blend
+#pragma unroll
+    for (int mem = 0; mem < 2; ++mem) {
+      const int lo = mem ? nslot0 : 0, hi = mem ? nslot : nslot0;
+      if (lo >= hi) continue;
       const float* src = mem ? src1 : src0;
       const float* prow = mem ? prow1 : prow0;
       float pj[21];
 #pragma unroll
       for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
-      const unsigned e = s_list[(j << 6) + lane];
-      const bool valid = e != 0xffffu;
-      const int cell = valid ? (int)e : 2 * BS2 + 2;          // padding lanes: the tile's first own texel (never stored)
-      const int r = cell / BS2, c = cell - r * BS2;
-      const int py = tc.ty0 + r - 2, px = tc.tx0 + c - 2;
-      const float dep = depth_at(dsrc, py, px, H, W);
-      BbdSample sm;
-      bbd_project_bwd(pj, px, py, dep, dm, &sm);
-      BbdTaps t;
-      bbd_taps(sm.ix, sm.iy, dm, &t);
-      float v[3][4];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) bbd_fetch4(src + ch * hw, &t, v[ch]);
-      const bool own = valid && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2;
-      icell[i] = own ? cell : -1;
-      idep[i] = dep;
+      for (int i = 0; i < B3_MAXCH; ++i) {
+        if (i < lo || i >= hi) continue;
+        const bool valid = icell[i] >= 0;
+        const int cell = valid ? icell[i] : 2 * BS2 + 2;
+        const int r = cell / BS2, c = cell - r * BS2;
+        const int py = tc.ty0 + r - 2, px = tc.tx0 + c - 2;
+        BbdSample sm;
+        bbd_project_bwd(pj, px, py, idep[i], dm, &sm);
+        BbdTaps t;
+        bbd_taps(sm.ix, sm.iy, dm, &t);
+        float v[3][4];
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float val = bbd_bilerp(v[ch], &t);
-        if (valid) s_x[mem][ch][cell] = val;
-        dvx[i][ch] = sm.clipx ? 0.0f : (v[ch][1] - v[ch][0]) * t.s + (v[ch][3] - v[ch][2]) * t.n;
-        dvy[i][ch] = sm.clipy ? 0.0f : (v[ch][2] - v[ch][0]) * t.e + (v[ch][3] - v[ch][1]) * t.w;
+        for (int ch = 0; ch < 3; ++ch) bbd_fetch4(src + ch * hw, &t, v[ch]);
+        const bool own = valid && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2;
+        icell[i] = own ? cell : -1;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float val = bbd_bilerp(v[ch], &t);
+          if (valid) s_x[mem][ch][cell] = val;
+          dvx[i][ch] = sm.clipx ? 0.0f : (v[ch][1] - v[ch][0]) * t.s + (v[ch][3] - v[ch][2]) * t.n;
+          dvy[i][ch] = sm.clipy ? 0.0f : (v[ch][2] - v[ch][0]) * t.e + (v[ch][3] - v[ch][1]) * t.w;
+        }
       }
     }
     if (stamp_pass) BBD_STAMP(sp + 1);
@@ -1331,8 +1376,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       for (int base = 0; base < nwin; base += 64) {
-        if (base + lane >= nwin) continue;
-        const unsigned e = s_wlist[wv][base + lane];
+        const bool act = base + lane < nwin;
+        const unsigned e = s_wlist[wv][act ? base + lane : 0];
         const int memb = (int)(e >> 15), idx = (int)(e & 0x7fffu);
         const int lrr = idx / CW2;
         const int lr = band0 + lrr, lc = idx - lrr * CW2;
@@ -1345,6 +1390,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         }
         const float* xp = &s_x[0][0][0] + memb * 3 * B3_CELLS;
         float* ap = s_acc + acc_base + memb * 3 * acc_rows * 32;
+        float val[3][9];                 // this winner's contribution to the 9 texels of its window, per channel
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
           float xv[3][3], yv[3][3];
@@ -1373,19 +1419,41 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
 #pragma unroll
           for (int dr = 0; dr < 3; ++dr)
 #pragma unroll
-            for (int dc = 0; dc < 3; ++dc) {
-              float val = A + Bc * xv[dr][dc] + Cc * yv[dr][dc];
-              if (dr == 1 && dc == 1) {
-                const float df = xv[1][1] - yv[1][1];
-                val += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
-              } else if (a.no_ssim) {
-                continue;
-              }
-              const int r = rr[dr], c = cc[dc];
-              if (r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2)
-                atomicAdd(&ap[(ch * acc_rows + (r - acc_r0)) * 32 + (c - 2)], val);
-            }
+            for (int dc = 0; dc < 3; ++dc) val[ch][dr * 3 + dc] = A + Bc * xv[dr][dc] + Cc * yv[dr][dc];
+          const float df = xv[1][1] - yv[1][1];
+          val[ch][4] += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
         }
+        // scatter.  The planes are private to this wave and LDS operations of a wave execute in program order: in a
+        // tile without image borders the 64 winners of a step (one window offset) hit 64 different texels, so a plain
+        // read-add-write per offset - the three channels of an offset in flight together - is exact and
+        // deterministic (a ds_add_f32 costs several plain accesses, profiles/r03/lds_rate.txt); with reflected
+        // borders two winners of a step can share a texel: LDS float adds there.
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+          for (int dc = 0; dc < 3; ++dc) {
+            if (a.no_ssim && !(dr == 1 && dc == 1)) continue;
+            const int r = rr[dr], c = cc[dc];
+            if (act && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2) {
+              float* q = &ap[(r - acc_r0) * 32 + (c - 2)];
+              if (interior) {
+#if defined(BBD_BWD3_SERIAL_SCATTER)      // timing A/B: one channel in flight per step
+                q[0] = q[0] + val[0][dr * 3 + dc];
+                q[acc_rows * 32] = q[acc_rows * 32] + val[1][dr * 3 + dc];
+                q[2 * acc_rows * 32] = q[2 * acc_rows * 32] + val[2][dr * 3 + dc];
+#else
+                const float q0 = q[0], q1 = q[acc_rows * 32], q2 = q[2 * acc_rows * 32];
+                q[0] = q0 + val[0][dr * 3 + dc];
+                q[acc_rows * 32] = q1 + val[1][dr * 3 + dc];
+                q[2 * acc_rows * 32] = q2 + val[2][dr * 3 + dc];
+#endif
+              } else {
+                atomicAdd(q, val[0][dr * 3 + dc]);
+                atomicAdd(q + acc_rows * 32, val[1][dr * 3 + dc]);
+                atomicAdd(q + 2 * acc_rows * 32, val[2][dr * 3 + dc]);
+              }
+            }
+          }
       }
     }
     if (stamp_pass) BBD_STAMP(sp + 3);
@@ -1394,56 +1462,58 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
 
     // ---- G: own-texel items: accumulated texel gradient -> sampling coordinates -> depth and P
     {
-      float tot0[3] = {0.f, 0.f, 0.f}, tot1[3] = {0.f, 0.f, 0.f};
+      float tot[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int i = 0; i < B3_MAXCH; ++i) {
-        if (i >= nslot) continue;
-        const int j = wv + 4 * i;
-        const int mem = (j << 6) >= n0p;
+      for (int mem = 0; mem < 2; ++mem) {
+        const int lo = mem ? nslot0 : 0, hi = mem ? nslot : nslot0;
+        if (lo >= hi) continue;
         const float* prow = mem ? prow1 : prow0;
-        const int nopose = (mem ? c1.cd.kind : c0.cd.kind) & FLAG_NO_POSE_GRAD;
-        float gP[12];
+        const int nopose = (mem ? c1.kind : c0.kind) & FLAG_NO_POSE_GRAD;
+        float pj[21];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
-        const int cell = icell[i];
-        if (cell >= 0) {
-          const int r = cell / BS2, c = cell - r * BS2;
-          float gx[3] = {0.f, 0.f, 0.f};
+        for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
 #pragma unroll
-          for (int w4 = 0; w4 < 4; ++w4) {
-            if (r < B3_R0[w4] || r >= B3_R0[w4] + B3_ROWS[w4]) continue;
-            float* ap = s_acc + B3_BASE[w4] + (mem * 3 * B3_ROWS[w4] + (r - B3_R0[w4])) * 32 + (c - 2);
+        for (int i = 0; i < B3_MAXCH; ++i) {
+          if (i < lo || i >= hi) continue;
+          float gP[12];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-              gx[ch] += ap[ch * B3_ROWS[w4] * 32];
-              ap[ch * B3_ROWS[w4] * 32] = 0.0f;
+          for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
+          const int cell = icell[i];
+          if (cell >= 0) {
+            const int r = cell / BS2, c = cell - r * BS2;
+            float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) {
+              if (r < B3_R0[w4] || r >= B3_R0[w4] + B3_ROWS[w4]) continue;
+              float* ap = s_acc + B3_BASE[w4] + (mem * 3 * B3_ROWS[w4] + (r - B3_R0[w4])) * 32 + (c - 2);
+#pragma unroll
+              for (int ch = 0; ch < 3; ++ch) {
+                gx[ch] += ap[ch * B3_ROWS[w4] * 32];
+                ap[ch * B3_ROWS[w4] * 32] = 0.0f;
+              }
+            }
+            if (gx[0] != 0.0f || gx[1] != 0.0f || gx[2] != 0.0f) {
+              const float gix = gx[0] * dvx[i][0] + gx[1] * dvx[i][1] + gx[2] * dvx[i][2];
+              const float giy = gx[0] * dvy[i][0] + gx[1] * dvy[i][1] + gx[2] * dvy[i][2];
+              BbdSample sm;
+              bbd_sample_smooth(pj, tc.tx0 + c - 2, tc.ty0 + r - 2, idep[i], &sm);
+              float gd;
+              bbd_project_grad(pj, &sm, gix, giy, &gd, gP);
+              s_gd[mem][(r - 2) * TW2 + (c - 2)] = gd;
             }
           }
-          if (gx[0] != 0.0f || gx[1] != 0.0f || gx[2] != 0.0f) {
-            float pj[21];
-#pragma unroll
-            for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
-            const float gix = gx[0] * dvx[i][0] + gx[1] * dvx[i][1] + gx[2] * dvx[i][2];
-            const float giy = gx[0] * dvy[i][0] + gx[1] * dvy[i][1] + gx[2] * dvy[i][2];
-            BbdSample sm;
-            bbd_sample_smooth(pj, tc.tx0 + c - 2, tc.ty0 + r - 2, idep[i], &sm);
-            float gd;
-            bbd_project_grad(pj, &sm, gix, giy, &gd, gP);
-            s_gd[mem][(r - 2) * TW2 + (c - 2)] = gd;
+          if (!nopose) {
+            float t3[3];
+            wave_sum12(gP, t3);
+            tot[mem][0] += t3[0]; tot[mem][1] += t3[1]; tot[mem][2] += t3[2];
           }
-        }
-        if (!nopose) {
-          float t3[3];
-          wave_sum12(gP, t3);
-          if (mem) { tot1[0] += t3[0]; tot1[1] += t3[1]; tot1[2] += t3[2]; }
-          else { tot0[0] += t3[0]; tot0[1] += t3[1]; tot0[2] += t3[2]; }
         }
       }
       if ((lane & 15) == 15) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          s_red[wv][0][wave_sum12_index(k, lane)] = tot0[k];
-          s_red[wv][1][wave_sum12_index(k, lane)] = tot1[k];
+          s_red[wv][0][wave_sum12_index(k, lane)] = tot[0][k];
+          s_red[wv][1][wave_sum12_index(k, lane)] = tot[1][k];
         }
       }
     }
@@ -1455,7 +1525,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
     if (tid < 24) {
       const int mem = tid >= 12, k = tid - 12 * mem;
       if (mem == 0 || c1.id >= 0) {
-        const int nopose = (mem ? c1.cd.kind : c0.cd.kind) & FLAG_NO_POSE_GRAD;
+        const int nopose = (mem ? c1.kind : c0.kind) & FLAG_NO_POSE_GRAD;
         float t = 0.0f;
         if (!nopose) t = ((s_red[0][mem][k] + s_red[1][mem][k]) + s_red[2][mem][k]) + s_red[3][mem][k];
         (mem ? gp1 : gp0)[k] = t;
