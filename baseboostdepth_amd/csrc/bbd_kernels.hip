@@ -515,7 +515,7 @@ struct FwdArgs {
   float2* coords;       // optional [S,NP,H,W]: clamped sampling coordinates + clamp flags, for the backward
   DispSrc ds;
   BbdDims dm;
-  int S, B, NP, ntiles, no_ssim, remap;
+  int S, B, NP, ntiles, no_ssim, remap, scale_loop;
 };
 
 #ifndef BBD_FWD_WAVES
@@ -530,27 +530,22 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   int buf = 0;
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
-  // grid order: sample-major, then scale, then tile
+  // grid order: sample-major, then scale, then tile - or, with the scale loop (S > 1), one workgroup per (sample, tile)
+  // that walks the scales itself: everything that does not depend on the scale (cell tables, the staged target tile,
+  // its window statistics - a quarter of a workgroup's life, profiles/r02/phase_stamps_final.txt) is set up once.
   int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
+  const int per_sample = a.scale_loop ? a.ntiles : a.S * a.ntiles;
+  const int b = bid / per_sample;
+  bid -= b * per_sample;
+  const int s_first = a.scale_loop ? 0 : bid / a.ntiles;
+  const int s_end = a.scale_loop ? a.S : s_first + 1;
+  const TileCoord tc = decode_tile(bid - (a.scale_loop ? 0 : s_first * a.ntiles), W);
   const size_t img = (size_t)3 * hw;
-  const size_t sb = (size_t)s * a.B + b;
 
   BBD_STAMP(0);
   Cells<LH, LW, LS, 1> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
   stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
-  float dcell[Cells<LH, LW, LS, 1>::N];
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  load_depth(dsrc, H, W, cl, dcell);
-  if (a.depth_out != nullptr) {
-#pragma unroll
-    for (int k = 0; k < Cells<LH, LW, LS, 1>::N; ++k)
-      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
-  }
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
@@ -563,6 +558,18 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
 
   float mu_y[3][PPT], sg_y[3][PPT];
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
+  const int nc = uniform_load(a.ncand + b);
+
+  for (int s = s_first; s < s_end; ++s) {
+  const size_t sb = (size_t)s * a.B + b;
+  float dcell[Cells<LH, LW, LS, 1>::N];
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  load_depth(dsrc, H, W, cl, dcell);
+  if (a.depth_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < Cells<LH, LW, LS, 1>::N; ++k)
+      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
+  }
 
   // (register budget: this kernel sat on the 168-VGPR line of 3 waves per SIMD, 154 now - the four arg-min ids share one
   // word and the identity noise is fetched where an identity candidate needs it, not held across the loop)
@@ -572,7 +579,6 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
-  const int nc = uniform_load(a.ncand + b);
   for (int c = 0; c < nc; ++c) {
     const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
     float loss[PPT];
@@ -627,6 +633,320 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
     }
   }
   // deterministic per-tile sum: DPP wave reduction, then the four wave totals in fixed order
+  const float wsum = wave_sum63(tsum);
+  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+  }     // scales
+  BBD_STAMP(20);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused forward, paired-candidate form (round 3; the shipped one).
+//
+// Plain fp32 vector instructions issue once per 4 cycles per SIMD on gfx950 whatever the occupancy, and the packed forms
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 values per lane) issue at the same rate
+// (profiles/r03/valu_rate.txt) - the kernel's floor is its fp32 instruction count, and packing halves it where the two
+// halves of a register pair want the SAME operation.  The SSIM + L1 arithmetic of two candidates at one pixel is that
+// case: same target window, same statistics, same operation sequence.  So the warp candidates are taken two at a time
+// (the table's pairing hint: the true-pose and the error-induced warp of one source frame; otherwise the next one in id
+// order), both warped images are staged as ONE set of float2 planes (.x = first, .y = second candidate), every window
+// read delivers register pairs, and the whole photometric chain of strip_loss runs on pairs: same operations, same
+// rounding per component, half the instructions.  The running minimum compares ids on ties, so the order in which
+// candidates are visited does not matter (torch.min: first index wins, a NaN wins and sticks).
+// ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f pk1(float a) { v2f r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_div9(v2f x) {               // bbd_div9 per component
+  const v2f r = pk1(1.0f / 9.0f);
+  const v2f q = x * r;
+  return pk_fma(pk_fma(pk1(-9.0f), q, x), r, q);
+}
+__device__ __forceinline__ v2f pk_div3(v2f x) {
+  const v2f r = pk1(1.0f / 3.0f);
+  const v2f q = x * r;
+  return pk_fma(pk_fma(pk1(-3.0f), q, x), r, q);
+}
+__device__ __forceinline__ v2f pk_div(v2f n, v2f d) {         // bbd_div per component (IEEE-correct quotient)
+  v2f r0;
+  r0.x = __builtin_amdgcn_rcpf(d.x);
+  r0.y = __builtin_amdgcn_rcpf(d.y);
+  const v2f one = pk1(1.0f);
+  const v2f r = pk_fma(pk_fma(-d, r0, one), r0, r0);
+  v2f q = n * r;
+  q = pk_fma(pk_fma(-d, q, n), r, q);
+  q = pk_fma(pk_fma(-d, q, n), r, q);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!bbd_exp_ok3(n.x, d.x, d.x)) q.x = n.x / d.x;
+  if (!bbd_exp_ok3(n.y, d.y, d.y)) q.y = n.y / d.y;
+#endif
+  return q;
+}
+
+// torch.min(dim) as an order-free update: smaller wins, on equal values the smaller id, a NaN wins over numbers and
+// among NaNs the smaller id (= "first index", "NaN wins and sticks" of the sequential form bbd_min_update)
+__device__ __forceinline__ void min_update_any_order(float cand, int id, float* best, int* arg) {
+  const bool cn = cand != cand, bn = *best != *best;
+  const bool take = (cand < *best) || ((cand == *best || (cn && bn)) && id < *arg) || (cn && !bn);
+  *best = take ? cand : *best;
+  *arg = take ? id : *arg;
+}
+
+// 3 rows x 8 columns (6 used) of a float2 plane starting at row r0, column c0 (c0 % 4 == 0): ds_read_b128 x 4 per row
+__device__ __forceinline__ void load_window_pair(const v2f* plane, int r0, int c0, v2f win[3][6]) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* p4 = reinterpret_cast<const v4f*>(plane + r0 * LS + c0);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const v4f q0 = p4[r * (LS / 2)], q1 = p4[r * (LS / 2) + 1], q2 = p4[r * (LS / 2) + 2];
+    win[r][0] = pk2(q0.x, q0.y); win[r][1] = pk2(q0.z, q0.w);
+    win[r][2] = pk2(q1.x, q1.y); win[r][3] = pk2(q1.z, q1.w);
+    win[r][4] = pk2(q2.x, q2.y); win[r][5] = pk2(q2.z, q2.w);
+  }
+}
+
+// strip_loss for two candidates at once: sx holds (.x, .y) = the two warped images.  Component for component the
+// operations (and roundings) of strip_loss / bbd_ssim_nd / bbd_ssim_from_ratio / bbd_combine.
+__device__ __forceinline__ void strip_loss_pair(const v2f (*sx)[FPLANE], const float (*sy)[FPLANE], int ly, int lx0,
+                                                const float mu_y[3][PPT], const float sg_y[3][PPT], int no_ssim,
+                                                v2f out[PPT]) {
+  v2f ssum[PPT], lsum[PPT];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    // (one channel's windows live at a time: without the fence hipcc hoists all three channels' 54 window registers
+    // above the arithmetic and spills a hundred registers)
+    __builtin_amdgcn_sched_barrier(0);
+    v2f x[3][6];
+    float y[3][8];
+    load_window_pair(sx[ch], ly, lx0, x);
+    load_window<LS>(sy[ch], ly, lx0, y);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      v2f s = pk1(0.0f), ss = pk1(0.0f), sxy = pk1(0.0f);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const v2f v = x[r][j + c];
+          s = s + v;
+          ss = ss + v * v;
+          sxy = sxy + v * pk1(y[r][j + c]);
+        }
+      v2f ssim = pk1(0.0f);
+      if (!no_ssim) {
+        // (opaque copies: hipcc otherwise hoists the splatted statistics and muy * muy of all 12 pixel-channels out
+        // of the candidate loop - 72 registers that it then spills)
+        float my1 = mu_y[ch][j], sg1 = sg_y[ch][j];
+        asm volatile("" : "+v"(my1), "+v"(sg1));
+        const v2f muy = pk1(my1), sgy = pk1(sg1);
+        const v2f mu_x = pk_div9(s);
+        const v2f mxx = mu_x * mu_x, mxy = mu_x * muy;
+        const v2f sig_x = pk_div9(ss) - mxx;
+        const v2f sig_xy = pk_div9(sxy) - mxy;
+        const v2f n = pk_fma(mxy, pk1(2.0f), pk1(BBD_C1)) * pk_fma(sig_xy, pk1(2.0f), pk1(BBD_C2));
+        const v2f d = (mxx + muy * muy + pk1(BBD_C1)) * (sig_x + sgy + pk1(BBD_C2));
+        const v2f q = pk_div(n, d);
+        const v2f v = (pk1(1.0f) - q) * pk1(0.5f);
+        ssim.x = v.x < 0.0f ? 0.0f : (v.x > 1.0f ? 1.0f : v.x);
+        ssim.y = v.y < 0.0f ? 0.0f : (v.y > 1.0f ? 1.0f : v.y);
+      }
+      const v2f df = pk1(y[1][j + 1]) - x[1][j + 1];
+      const v2f l1 = pk2(fabsf(df.x), fabsf(df.y));
+      ssum[j] = ch == 0 ? ssim : ssum[j] + ssim;
+      lsum[j] = ch == 0 ? l1 : lsum[j] + l1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const v2f l1m = pk_div3(lsum[j]);
+    out[j] = no_ssim ? l1m : pk1(0.85f) * pk_div3(ssum[j]) + pk1(0.15f) * l1m;
+  }
+}
+
+// Warp the staged cells for TWO pose rows (member .x from srcA / rowA, member .y from srcB / rowB; `both` false = only
+// the first) into one set of float2 planes.  Per cell the two projections share the camera point depth * inv_K (x, y, 1)
+// when the rows carry the same inv_K (always, for one target sample); both candidates' gathers are in flight together.
+template <int BATCH, typename CellsT>
+__device__ __forceinline__ void warp_pair_into_lds(const float* __restrict__ srcA, const float* __restrict__ srcB, bool both,
+                                                   const float (&d)[CellsT::N], const float* __restrict__ rowA,
+                                                   const float* __restrict__ rowB, const BbdDims dm, int hw,
+                                                   const CellsT& cl, v2f (*s)[FPLANE], float* __restrict__ woutA,
+                                                   float* __restrict__ woutB) {
+  float pa[21], pb[21];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) { pa[i] = uniform_load(rowA + i); pb[i] = uniform_load(rowB + i); }
+#pragma unroll
+  for (int k0 = 0; k0 < CellsT::N; k0 += BATCH) {
+    BbdTaps ta[BATCH], tb[BATCH];
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk) {
+      const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
+      BbdSample sm;
+      bbd_project(pa, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+      bbd_taps(sm.ix, sm.iy, dm, &ta[kk]);
+      bbd_project(pb, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
+      bbd_taps(sm.ix, sm.iy, dm, &tb[kk]);
+    }
+    float va[BATCH][3][4], vb[BATCH][3][4];
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        bbd_fetch4(srcA + ch * hw, &ta[kk], va[kk][ch]);
+        bbd_fetch4(srcB + ch * hw, &tb[kk], vb[kk][ch]);
+      }
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk) {
+      if (k0 + kk >= CellsT::N) break;
+      const int k = k0 + kk;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float xa = bbd_bilerp(va[kk][ch], &ta[kk]), xb = bbd_bilerp(vb[kk][ch], &tb[kk]);
+        s[ch][cl.lds[k]] = pk2(xa, xb);
+        if (cl.own(k)) {
+          if (woutA != nullptr) woutA[cl.pix(k, dm.W) + ch * hw] = xa;
+          if (both && woutB != nullptr) woutB[cl.pix(k, dm.W) + ch * hw] = xb;
+        }
+      }
+    }
+  }
+}
+
+#ifndef BBD_FWDP_WAVES
+#define BBD_FWDP_WAVES 3
+#endif
+#ifndef BBD_FWDP_BATCH
+#define BBD_FWDP_BATCH 2
+#endif
+__global__ __launch_bounds__(NT, BBD_FWDP_WAVES) void warp_ssim_min_fwdp_kernel(FwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
+  __shared__ __attribute__((aligned(16))) v2f s_xp[3][FPLANE];
+  __shared__ float s_red[4];
+  const BbdDims dm = a.dm;
+  const int H = dm.H, W = dm.W, hw = H * W;
+  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = bid / (a.S * a.ntiles);
+  bid -= b * a.S * a.ntiles;
+  const int s = bid / a.ntiles;
+  const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
+  const size_t img = (size_t)3 * hw;
+  const size_t sb = (size_t)s * a.B + b;
+
+  BBD_STAMP(0);
+  typedef Cells<LH, LW, LS, 1> CellsF;
+  CellsF cl;
+  cl.init(H, W, tc.tx0, tc.ty0);
+  stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
+  float dcell[CellsF::N];
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  load_depth(dsrc, H, W, cl, dcell);
+  if (a.depth_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < CellsF::N; ++k)
+      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
+  }
+  BBD_STAMP(1);
+  __syncthreads();
+  BBD_STAMP(2);
+  int ly, lx0;
+  strip_of_thread(&ly, &lx0);
+  const int yy = tc.ty0 + ly, xx = tc.tx0 + lx0;
+  const bool row_ok = yy < H;
+  const bool vec_ok = (xx + PPT <= W) && ((W & 3) == 0);
+  const int pix = yy * W + xx;
+
+  float mu_y[3][PPT], sg_y[3][PPT];
+  strip_ystats(s_y, ly, lx0, mu_y, sg_y);
+  float best[PPT];
+  int arg[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) { best[j] = INFINITY; arg[j] = 0; }
+
+  const int nc = uniform_load(a.ncand + b);
+  const bbd_cand_t* ctab = a.cand + b * BBD_MAX_CAND;
+  unsigned todo = 0u;
+  for (int c = 0; c < nc; ++c) {
+    const bbd_cand_t cd = load_cand(ctab + c);
+    if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
+      todo |= 1u << c;
+    } else {
+      // identity candidate (+ noise): a stored map
+      float loss[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) loss[j] = 0.0f;
+      if (row_ok) {
+        load_strip(a.ident + (size_t)cd.row * hw + pix, xx, W, vec_ok, loss);
+        if (a.noise != nullptr) {
+          float nz[PPT];
+          load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
+#pragma unroll
+          for (int j = 0; j < PPT; ++j) loss[j] += nz[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) min_update_any_order(loss[j], c, &best[j], &arg[j]);
+    }
+  }
+  BBD_STAMP(3);
+  // warp candidates, two per step
+  bool first = true;
+  int pno = 0;
+  while (todo != 0u) {
+    const int ia = __builtin_ctz(todo);
+    todo &= todo - 1u;
+    const bbd_cand_t ca = load_cand(ctab + ia);
+    const int hint = ((ca.kind >> 16) & 0xff) - 1;
+    int ib = -1;
+    if (hint >= 0 && hint < 32 && ((todo >> hint) & 1u)) ib = hint;
+    else if (todo != 0u) ib = __builtin_ctz(todo);
+    bbd_cand_t cb = ca;
+    if (ib >= 0) {
+      todo &= ~(1u << ib);
+      cb = load_cand(ctab + ib);
+    }
+    const bool both = ib >= 0;
+    const float* srcA = a.frames.base[ca.slot] + (size_t)ca.row * img;
+    const float* srcB = a.frames.base[cb.slot] + (size_t)cb.row * img;
+    float* woutA = a.warped ? a.warped + ((size_t)s * a.NP + ca.pose) * img : nullptr;
+    float* woutB = a.warped ? a.warped + ((size_t)s * a.NP + cb.pose) * img : nullptr;
+    if (!first) __syncthreads();          // every wave has read the previous pair's planes
+    first = false;
+    const int sp = 4 + 4 * (pno & 3);
+    ++pno;
+    BBD_STAMP(sp);
+    warp_pair_into_lds<BBD_FWDP_BATCH, CellsF>(srcA, srcB, both, dcell, a.pose + (size_t)ca.pose * BBD_PROJ_STRIDE,
+                                               a.pose + (size_t)cb.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xp, woutA, woutB);
+    BBD_STAMP(sp + 1);
+    __syncthreads();
+    BBD_STAMP(sp + 2);
+    v2f loss[PPT];
+    strip_loss_pair(s_xp, s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+    BBD_STAMP(sp + 3);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      min_update_any_order(loss[j].x, ia, &best[j], &arg[j]);
+      if (both) min_update_any_order(loss[j].y, ib, &best[j], &arg[j]);
+    }
+  }
+
+  float tsum = 0.0f;
+  if (row_ok) {
+    store_strip(a.min_loss + sb * hw + pix, xx, W, vec_ok, best);
+    uint8_t* ao = a.argmin + sb * hw + pix;
+    if (vec_ok) {
+      *reinterpret_cast<uint32_t*>(ao) = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+      tsum = ((best[0] + best[1]) + best[2]) + best[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j)
+        if (xx + j < W) {
+          ao[j] = (uint8_t)arg[j];
+          tsum += best[j];
+        }
+    }
+  }
   const float wsum = wave_sum63(tsum);
   if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
   __syncthreads();
@@ -1383,10 +1703,14 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         const int lr = band0 + lrr, lc = idx - lrr * CW2;
         const int py = tc.ty0 + lr - 1, px = tc.tx0 + lc - 1;
         int rr[3], cc[3];
+        unsigned refl = 0u;              // bit d: row tap d is a reflected one; bit 4 + d: column tap d
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          rr[d] = bbd_reflect(py + d - 1, H) - tc.ty0 + 2;
-          cc[d] = bbd_reflect(px + d - 1, W) - tc.tx0 + 2;
+          const int ry = bbd_reflect(py + d - 1, H), rx = bbd_reflect(px + d - 1, W);
+          refl |= (unsigned)(ry != py + d - 1) << d;
+          refl |= (unsigned)(rx != px + d - 1) << (4 + d);
+          rr[d] = ry - tc.ty0 + 2;
+          cc[d] = rx - tc.tx0 + 2;
         }
         const float* xp = &s_x[0][0][0] + memb * 3 * B3_CELLS;
         float* ap = s_acc + acc_base + memb * 3 * acc_rows * 32;
@@ -1423,34 +1747,41 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
           const float df = xv[1][1] - yv[1][1];
           val[ch][4] += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
         }
-        // scatter.  The planes are private to this wave and LDS operations of a wave execute in program order: in a
-        // tile without image borders the 64 winners of a step (one window offset) hit 64 different texels, so a plain
-        // read-add-write per offset - the three channels of an offset in flight together - is exact and
-        // deterministic (a ds_add_f32 costs several plain accesses, profiles/r03/lds_rate.txt); with reflected
-        // borders two winners of a step can share a texel: LDS float adds there.
+        // scatter.  The planes are private to this wave and LDS operations of a wave execute in program order.  For one
+        // window offset the winners of a step hit DIFFERENT texels (distinct pixels, one translation), so a plain
+        // read-add-write per offset - the three channels in flight together - is exact and deterministic; a
+        // ds_add_f32 costs 192 cycles per wave-instruction against ~6 for the three plain instructions
+        // (profiles/r03/lds_rate.txt).  At an image border a reflected tap folds onto the texel of an unreflected one:
+        // there the step runs once per reflection class (row reflected / column reflected), inside a class the map
+        // winner -> texel is a translation again.
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr)
 #pragma unroll
           for (int dc = 0; dc < 3; ++dc) {
             if (a.no_ssim && !(dr == 1 && dc == 1)) continue;
             const int r = rr[dr], c = cc[dc];
-            if (act && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2) {
-              float* q = &ap[(r - acc_r0) * 32 + (c - 2)];
-              if (interior) {
-#if defined(BBD_BWD3_SERIAL_SCATTER)      // timing A/B: one channel in flight per step
-                q[0] = q[0] + val[0][dr * 3 + dc];
-                q[acc_rows * 32] = q[acc_rows * 32] + val[1][dr * 3 + dc];
-                q[2 * acc_rows * 32] = q[2 * acc_rows * 32] + val[2][dr * 3 + dc];
-#else
+            const bool ok = act && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2;
+            float* q = &ap[(r - acc_r0) * 32 + (c - 2)];
+            if (interior) {
+              if (ok) {
                 const float q0 = q[0], q1 = q[acc_rows * 32], q2 = q[2 * acc_rows * 32];
                 q[0] = q0 + val[0][dr * 3 + dc];
                 q[acc_rows * 32] = q1 + val[1][dr * 3 + dc];
                 q[2 * acc_rows * 32] = q2 + val[2][dr * 3 + dc];
-#endif
-              } else {
-                atomicAdd(q, val[0][dr * 3 + dc]);
-                atomicAdd(q + acc_rows * 32, val[1][dr * 3 + dc]);
-                atomicAdd(q + 2 * acc_rows * 32, val[2][dr * 3 + dc]);
+              }
+            } else {
+              const int cls = (int)(((refl >> dr) & 1u) << 1 | ((refl >> (4 + dc)) & 1u));
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if ((dr == 1 && (k & 2)) || (dc == 1 && (k & 1))) continue;      // the centre tap never reflects
+                const bool mine = ok && cls == k;
+                if (__ballot(mine) == 0ull) continue;
+                if (mine) {
+                  const float q0 = q[0], q1 = q[acc_rows * 32], q2 = q[2 * acc_rows * 32];
+                  q[0] = q0 + val[0][dr * 3 + dc];
+                  q[acc_rows * 32] = q1 + val[1][dr * 3 + dc];
+                  q[2 * acc_rows * 32] = q2 + val[2][dr * 3 + dc];
+                }
               }
             }
           }
@@ -1472,12 +1803,12 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
         float pj[21];
 #pragma unroll
         for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
+        float gP[12];                      // summed over this member's items of the lane, reduced once per member
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
 #pragma unroll
         for (int i = 0; i < B3_MAXCH; ++i) {
           if (i < lo || i >= hi) continue;
-          float gP[12];
-#pragma unroll
-          for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
           const int cell = icell[i];
           if (cell >= 0) {
             const int r = cell / BS2, c = cell - r * BS2;
@@ -1497,17 +1828,15 @@ __global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel
               const float giy = gx[0] * dvy[i][0] + gx[1] * dvy[i][1] + gx[2] * dvy[i][2];
               BbdSample sm;
               bbd_sample_smooth(pj, tc.tx0 + c - 2, tc.ty0 + r - 2, idep[i], &sm);
-              float gd;
-              bbd_project_grad(pj, &sm, gix, giy, &gd, gP);
+              float gd, g1[12];
+              bbd_project_grad(pj, &sm, gix, giy, &gd, g1);
               s_gd[mem][(r - 2) * TW2 + (c - 2)] = gd;
+#pragma unroll
+              for (int k = 0; k < 12; ++k) gP[k] += g1[k];
             }
           }
-          if (!nopose) {
-            float t3[3];
-            wave_sum12(gP, t3);
-            tot[mem][0] += t3[0]; tot[mem][1] += t3[1]; tot[mem][2] += t3[2];
-          }
         }
+        if (!nopose) wave_sum12(gP, tot[mem]);
       }
       if ((lane & 15) == 15) {
 #pragma unroll
@@ -2421,8 +2750,18 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.warped = warped; a.depth_out = depth_out; a.coords = reinterpret_cast<float2*>(coords); a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
   a.remap = xcd_remap_enabled();
-  hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), a);
+  // BBD_FWD=2: the paired-candidate / packed-SSIM form (experimental, slower so far: profiles/r03/fwdp_ab.txt)
+  static const int form = [] { const char* e = getenv("BBD_FWD"); return e ? atoi(e) : 1; }();
+  static const int scale_loop = [] { const char* e = getenv("BBD_FWD_SCALE_LOOP"); return e ? atoi(e) : 1; }();
+  a.scale_loop = 0;
+  if (form == 2 && a.coords == nullptr) {
+    hipLaunchKernelGGL(warp_ssim_min_fwdp_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), a);
+  } else {
+    a.scale_loop = (S > 1 && scale_loop) ? 1 : 0;
+    hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)((a.scale_loop ? 1 : S) * B * a.ntiles)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), a);
+  }
   return launch_status();
 }
 
