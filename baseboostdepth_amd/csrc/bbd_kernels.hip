@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused forward, paired-candidate form (round 3; the shipped one).
+// Fused forward, paired-candidate form (round 3; experimental, BBD_FWD=2 - NOT the default).
 //
 // Plain fp32 vector instructions issue once per 4 cycles per SIMD on gfx950 whatever the occupancy, and the packed forms
 // (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 values per lane) issue at the same rate
@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused backward, sparse-item form (round 3; the shipped one).
+// Fused backward, sparse-item form (round 3; experimental, BBD_BWD=3 - NOT the default, see the end of this comment).
 //
 // The round-2 form above runs its whole pipeline once per candidate that won ANY pixel around the tile: with the
 // boosted recipe's 12 warp candidates that is 12 x (warp the 36x20 halo'd region, 9 barriers), although every pixel
@@ -1366,6 +1366,12 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 //     d warped / d (ix, iy) from its registers, chains to depth and to the 12 entries of P; one reduce-scatter per chunk.
 // Per pass: 4 barriers (list | x planes | accumulators | partials) instead of 9 per candidate.
 // LDS 52.5 KB -> three workgroups per CU.
+// Measured (profiles/r03/bwd3_v*_*.txt, phase_stamps_bwd3_*.txt): bit-identical gradients to the dense form within the
+// tests' bars on all 128 GPU tests, but NOT faster - m = 7 with per-pixel random disparities 0.339 vs 0.353 ms, inside
+// the training step 0.316 vs 0.262 ms, MD2 0.386 vs 0.283 ms: the item machinery (lists, padding, per-item index
+// arithmetic, a C phase at 17 of 64 lanes) issues as many instructions per tile as the dense form's twelve warps, and
+// with fp32 issue at 4 cycles per wave-instruction per SIMD (valu_rate.txt) instructions are the currency.  Kept as
+// the starting point for a packed (two-candidates-per-register-pair) form.
 // ------------------------------------------------------------------------------------------
 constexpr int B3_CELLS = BH * BS2;                  // 720 staged cells (20 x 36, halo 2)
 constexpr int B3_LPIX = CH * CW2;                   // 612 loss pixels (18 x 34, halo 1)
@@ -2752,7 +2758,10 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.remap = xcd_remap_enabled();
   // BBD_FWD=2: the paired-candidate / packed-SSIM form (experimental, slower so far: profiles/r03/fwdp_ab.txt)
   static const int form = [] { const char* e = getenv("BBD_FWD"); return e ? atoi(e) : 1; }();
-  static const int scale_loop = [] { const char* e = getenv("BBD_FWD_SCALE_LOOP"); return e ? atoi(e) : 1; }();
+  // BBD_FWD_SCALE_LOOP=1: one workgroup per (sample, tile) walks the scales (set-up once).  Measured neutral inside the
+  // training step (0.1760 vs 0.1761 ms) and 15 % slower on the micro-benchmark (4x fewer, 4x longer workgroups: the
+  // set-up it saves was already hidden by the other resident workgroups) - off (profiles/r03/fwd_scale_loop_ab.txt)
+  static const int scale_loop = [] { const char* e = getenv("BBD_FWD_SCALE_LOOP"); return e ? atoi(e) : 0; }();
   a.scale_loop = 0;
   if (form == 2 && a.coords == nullptr) {
     hipLaunchKernelGGL(warp_ssim_min_fwdp_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
@@ -2787,7 +2796,9 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
   a.remap = xcd_remap_enabled();
-  static const int form = [] { const char* e = getenv("BBD_BWD"); return e ? atoi(e) : 3; }();
+  // BBD_BWD=3: the sparse-item form (experimental: equal on per-pixel random disparities, slower inside the training
+  // step - profiles/r03/bwd3_*.txt)
+  static const int form = [] { const char* e = getenv("BBD_BWD"); return e ? atoi(e) : 2; }();
   if (!coords && form == 3) {
     hipLaunchKernelGGL(warp_ssim_min_bwd3_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                        static_cast<hipStream_t>(stream), a);
