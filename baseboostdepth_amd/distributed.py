@@ -65,14 +65,37 @@ class GradientAverager:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.use_avg = True
+        # diagnostics for the first multi-GPU runs (bench.py prints them): which reduction ran, and how long the step
+        # waited for the exchange - HIP events around the exposed part (the whole all-reduce in the split-graph loop, the
+        # flush + waits of the overlapped loop), enabled by `timing = True`
+        self.timing = False
+        self._events = []
 
     def _reduce(self, tensor, async_op=False):
         if self.backend == "nccl" and self.use_avg:      # RCCL: average in the collective
             try:
                 return dist.all_reduce(tensor, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
             except RuntimeError:                          # a build without ncclAvg: sum, divide afterwards
-                self.use_avg = False
+                self.use_avg = False                      # (a synchronous failure only; `reduce_op` reports what ran)
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    @property
+    def reduce_op(self):
+        return "AVG" if (self.backend == "nccl" and self.use_avg) else "SUM+div"
+
+    def _mark(self):
+        if self.timing and self.flat.flat.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return None
+
+    def exchange_ms(self):
+        """Mean exposed exchange time per step (ms) over the steps taken since `timing` was switched on."""
+        if not self._events:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._events) / len(self._events)
 
     @property
     def divide_after(self):
@@ -83,9 +106,13 @@ class GradientAverager:
         (Trainer._graph_step_dp): forward+backward+pack and the optimizer are hipGraphs, this stays a plain call."""
         if self.world == 1:
             return
+        t0 = self._mark()
         self._reduce(self.flat.flat)
         if self.divide_after:               # gloo (CPU tests) has no AVG
             self.flat.flat.div_(self.world)
+        t1 = self._mark()
+        if t0 is not None:
+            self._events.append((t0, t1))
 
     def __call__(self):
         self.flat.pack()
@@ -188,11 +215,15 @@ class OverlappedGradientAverager(GradientAverager):
 
     def __call__(self):
         self.launched_in_backward = self.launched      # diagnostics: buckets whose exchange overlapped backward
+        t0 = self._mark()
         self._launch_ready(force=True)
         for w in self.works:
             w.wait()
         if self.divide_after:
             self.flat.flat.div_(self.world)
+        t1 = self._mark()
+        if t0 is not None:
+            self._events.append((t0, t1))
         self._reset()
 
 

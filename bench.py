@@ -259,6 +259,10 @@ def main(argv=None):
                          "the bottleneck (measured: 480 vs 575 images/s on two boxes with identical GPU time).  auto = on for "
                          "every run, falling back to the eager loop if capture fails; multi-rank runs replay two graphs "
                          "per step (forward+backward+gradient pack | eager RCCL all-reduce | optimizer)")
+    ap.add_argument("--dp-mode", default="graph", choices=["graph", "overlap"],
+                    help="multi-rank loop: graph = two hipGraphs around ONE eager all-reduce of the flat gradient buffer (host "
+                         "out of the loop, exchange exposed); overlap = eager loop, 32 MB buckets all-reduced from autograd "
+                         "hooks while backward still runs.  Both print `exchange_ms` (exposed wait) so one node can compare them")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -311,6 +315,8 @@ def main(argv=None):
         return tr, opt
 
     want_graph = args.step_graph == "on" or (args.step_graph == "auto" and not args.no_fused_adam)
+    if world > 1 and args.dp_mode == "overlap":
+        want_graph = False
     trainer, opt = build_trainer(want_graph)
     import random as _random
     draw = _random.Random(1234 + rank)
@@ -356,6 +362,8 @@ def main(argv=None):
             trainer, opt = build_trainer(False)
     for _ in range(args.warmup):
         trainer.train_step(inputs)
+    if trainer.grad_sync is not None:
+        trainer.grad_sync.timing = True
     timer = ops.KernelTimer()
     backend.timer = None if trainer.use_graph else timer
     # per-step durations for the median: one event at every step boundary on the main stream (no host sync)
@@ -369,6 +377,11 @@ def main(argv=None):
     sync_all()
     elapsed = time.perf_counter() - t0
     backend.timer = None
+    exchange_ms, reduce_op, overlapped = 0.0, None, None
+    if trainer.grad_sync is not None:
+        trainer.grad_sync.timing = False
+        exchange_ms, reduce_op = trainer.grad_sync.exchange_ms(), trainer.grad_sync.reduce_op
+        overlapped = getattr(trainer.grad_sync, "launched_in_backward", None)
     kernel_timing = "HIP events around each C-ABI launch inside the timed steps"
     if trainer.use_graph:
         # a replayed graph's nodes cannot be bracketed by events: the SAME kernels on the same inputs are timed over
@@ -384,9 +397,9 @@ def main(argv=None):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = per_step[len(per_step) // 2] if per_step else 0.0
     if world > 1:
-        t = torch.tensor([elapsed, median_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, median_ms, exchange_ms], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed, median_ms = float(t[0].item()), float(t[1].item())
+        elapsed, median_ms, exchange_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
     if rank == 0:
         S = len(opt.scales)
@@ -433,6 +446,9 @@ def main(argv=None):
                       "training images/sec at 640x192, MonoViT",
             "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/sec",
             "n_gpus": world, "ranks": world, "collective": collective,
+            "dp_mode": ("single" if world == 1 else ("graph" if trainer.use_graph else "overlap")),
+            "exchange_ms": round(exchange_ms, 4), "reduce_op": reduce_op,
+            "buckets_launched_in_backward": overlapped,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
             "higher_is_better": True,

@@ -133,11 +133,21 @@ def test_loss_goes_down_on_a_fixed_batch():
     assert sum(hist[-5:]) / 5 < sum(hist[:5]) / 5 - 1e-3, (hist[:5], hist[-5:])
 
 
+def _deterministic_convolutions(monkeypatch):
+    """MIOpen's split-K weight-gradient solvers accumulate with atomics (run-to-run different bits); with
+    `cudnn.deterministic` PyTorch-ROCm sets MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC and those solvers are not chosen.
+    Everything else of the step (the HIP kernels here, fused Adam) is deterministic by construction."""
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
+
+
 def test_pose_stream_on_off_same_step(monkeypatch):
     """The pose network runs on a second HIP stream by default; with it disabled the step computes the
-    same loss and (up to MIOpen's atomically accumulated weight gradients) the same gradients."""
+    same loss and the same gradients (deterministic convolution solvers: a missing stream dependency or a dropped
+    update cannot hide under solver noise)."""
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
+    _deterministic_convolutions(monkeypatch)
     H, W, B = 96, 320, 4
     opt = make_opt(H, W, B, [0, 1, 2, 3], False)
     torch.manual_seed(3)
@@ -155,15 +165,16 @@ def test_pose_stream_on_off_same_step(monkeypatch):
         losses["loss"].backward()
         torch.cuda.synchronize()
         g = torch.cat([p.grad.flatten() for p in tr.parameters_to_train if p.grad is not None])
-        return float(losses["loss"].detach()), g
+        bufs = {"%s.%s" % (k, n): b.detach().clone() for k, m in tr.models.items() for n, b in m.named_buffers()}
+        return float(losses["loss"].detach()), g, bufs
 
-    l1, g1 = run("1")
-    l0, g0 = run("0")
+    l1, g1, b1 = run("1")
+    l0, g0, b0 = run("0")
     assert abs(l1 - l0) < 1e-6
-    # run-to-run noise of MIOpen's split-K weight-gradient kernels (atomic accumulation; which solver runs depends on
-    # the performance database): 1.0e-4 of the maximum observed between two identical runs - a missing stream
-    # dependency shows up as O(1) differences
-    assert float((g1 - g0).abs().max()) < 5e-4 * float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 1e-5 * float(g0.abs().max())
+    for k in b0:                                  # BatchNorm running statistics and batch counters
+        assert torch.equal(b0[k], b1[k]) if not b0[k].is_floating_point() else \
+            float((b0[k] - b1[k]).abs().max()) <= 1e-6 * (1.0 + float(b0[k].abs().max())), k
 
 
 def test_two_ranks_on_one_gpu_exchange_gradients():
@@ -212,16 +223,27 @@ def test_bench_two_ranks_sharing_this_gpu_print_one_split_graph_line():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["collective"] == "gloo" and line["value"] > 0
     assert line["config"]["global_batch"] == 4 and str(line["step_graph"]).startswith("split")
+    # diagnostics of the exchange: which loop, which reduction, how long the step waited for it
+    assert line["dp_mode"] == "graph" and line["reduce_op"] == "SUM+div" and line["exchange_ms"] > 0
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline", "--dp-mode", "overlap"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["dp_mode"] == "overlap" and line["step_graph"] is False and line["exchange_ms"] > 0
+    assert line["buckets_launched_in_backward"] is not None
 
 
-def test_step_graph_replay_matches_eager():
+def test_step_graph_replay_matches_eager(monkeypatch):
     """Opt-in whole-step hipGraph (`opt.step_graph`): capture after an eager warm-up that must NOT train
     (parameters, BatchNorm buffers, Adam state and the step counter are restored), then every batch with
-    the same signature is one graph launch.  Same parameters as the eager loop on the SAME batch sequence
-    (up to MIOpen's atomically accumulated weight gradients)."""
+    the same signature is one graph launch.  Same parameters AND BatchNorm running statistics as the eager loop on
+    the SAME batch sequence, with deterministic convolution solvers so that the bar is rounding, not solver noise."""
     import warnings
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
+    _deterministic_convolutions(monkeypatch)
     H, W, B = 96, 320, 4
     batches = [synthetic_batch([1] * B, H, W, [0, 1, 2, 3], device=DEV, seed=20 + i) for i in range(3)]
 
@@ -239,13 +261,18 @@ def test_step_graph_replay_matches_eager():
         torch.cuda.synchronize()
         return torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"]), tr
 
-    pe, le, _ = run(False)
+    pe, le, tre = run(False)
     pg, lg, trg = run(True)
     assert trg.use_graph and len(trg._graphs) == 1 and trg.step == 4
-    # 4 Adam steps from a random initialisation amplify MIOpen's atomically accumulated (run-to-run
-    # different) weight gradients: the two trajectories agree to a few per cent, not to rounding
-    assert abs(le - lg) < 5e-2 * abs(le)
-    assert float((pe - pg).abs().max()) < 5e-3 * float(pe.abs().max())
+    assert abs(le - lg) <= 1e-5 * abs(le)
+    assert float((pe - pg).abs().max()) <= 1e-5 * float(pe.abs().max())
+    for k, m in tre.models.items():               # a dropped running-statistics update would show here
+        bg = dict(trg.models[k].named_buffers())
+        for n, be in m.named_buffers():
+            if be.is_floating_point():
+                assert float((be - bg[n]).abs().max()) <= 1e-5 * (1.0 + float(be.abs().max())), (k, n)
+            else:
+                assert torch.equal(be, bg[n]), (k, n)
 
 
 @pytest.mark.parametrize("name", ["pose_plain_3105_32x64", "pose_incr_3215_32x64", "pose_incr_partial_4327_32x64",
