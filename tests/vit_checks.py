@@ -74,14 +74,14 @@ def check_forward_and_gradients(device, rel_eval, rel_train, rel_grad):
     w = loss_weights(2, 64, 128)
     loss = sum((disp[("disp", s)] * w[s].to(device)).mean() for s in range(4))
     loss.backward()
-    if on_cpu:
+    def compare(prefix, gkey):
         for i, f in enumerate(feats):
-            want = z["small/train/featsum/%d" % i]
+            want = z["small/%s/featsum/%d" % (prefix, i)]
             assert abs(f.double().sum().item() - want[0]) <= rel_train * want[1], "train feature %d" % i
         for s in range(4):
-            _close(disp[("disp", s)], z["small/train/disp/%d" % s], 10 * rel_train, "train disp %d" % s)
+            _close(disp[("disp", s)], z["small/%s/disp/%d" % (prefix, s)], 10 * rel_train, "train disp %d" % s)
         for tag, m in (("enc", enc), ("dec", dec)):
-            names, rows = list(z["gradnames/" + tag]), z["grad/" + tag]
+            names, rows = list(z["gradnames/" + tag]), z["%s/%s" % (gkey, tag)]
             params = dict(m.named_parameters())
             assert list(params.keys()) == names
             for name, (gsum, gabs) in zip(names, rows):
@@ -93,11 +93,25 @@ def check_forward_and_gradients(device, rel_eval, rel_train, rel_grad):
                 # parameters whose gradient is zero in exact arithmetic (a per-channel shift in front of a
                 # train-mode BatchNorm: fc2.bias of every path, InvRes.conv2.bn.bias) hold pure round-off
                 # (|g| ~ 1e-9 and below); hence an absolute floor (median |g| mass of a parameter is 3e-3)
-                floor = 1e-6
+                floor = 1e-6 if on_cpu else 1e-5
                 assert abs(g.double().sum().item() - gsum) <= rel_grad * gabs + floor, (tag, name)
                 assert abs(g.double().abs().sum().item() - gabs) <= rel_grad * gabs + floor, (tag, name)
-    else:
-        assert all(torch.isfinite(p.grad).all() for p in enc.parameters() if p.grad is not None)
+
+    if on_cpu:
+        compare("train", "grad")
+    # stochastic depth off: the assembled network's outputs AND every parameter's gradient against the reference's,
+    # on whichever device this runs (the GPU tier's HIP token kernels included)
+    for m in enc.modules():
+        if type(m).__name__ == "DropPath":
+            m.drop_prob = 0.0
+    for m in (enc, dec):
+        for q in m.parameters():
+            q.grad = None
+    feats = enc(x)
+    disp = dec(feats)
+    loss = sum((disp[("disp", s)] * w[s].to(device)).mean() for s in range(4))
+    loss.backward()
+    compare("train0", "grad0")
     # the decoder's never-used blocks (reference hr_decoder.py builds X_0j_Conv_0 and never calls them)
     free = sorted(n for n, p in dec.named_parameters() if p.grad is None)
     assert free == sorted("convs.X_0%d_Conv_0.conv.conv.%s" % (j, t) for j in range(4) for t in ("weight", "bias"))

@@ -16,6 +16,7 @@ multi-MB state dict is stored) and executed.  Written to tests/golden/vit_small.
     small/train/featsum/<i>   (sum, abs-sum) of every train-mode encoder feature
     grad/enc, grad/dec        per state-dict-unique parameter (sum, abs-sum) of d loss / d parameter for
                               loss = sum_s mean(disp_s * w_s) in train mode; NaN rows = no gradient reached it
+    small/train0/..., grad0/  the same train-mode pass with stochastic depth off (drop_prob = 0): reproducible on the GPU
     full/x, full/disp/<s>     one 192x640 sample, train mode, stochastic depth off (disp 0/1: every 4th row)
 """
 import os
@@ -99,6 +100,27 @@ def main():
                         [p.grad.double().sum().item(), p.grad.double().abs().sum().item()])
         out["grad/" + tag] = np.array(rows)
         out["gradnames/" + tag] = np.array(names)
+    # the same train-mode pass with stochastic depth OFF: what the GPU tier can reproduce (DropPath draws come from the
+    # device generator there) - pins the ASSEMBLED network's gradients, every parameter, on the GPU
+    for m in enc.modules():
+        if type(m).__name__ == "DropPath":
+            m.drop_prob = 0.0
+    for m in (enc, dec):
+        for q in m.parameters():
+            q.grad = None
+    feats = enc(x)
+    disp = dec(feats)
+    sum((disp[("disp", s)] * w[s]).mean() for s in range(4)).backward()
+    for i, f in enumerate(feats):
+        out["small/train0/featsum/%d" % i] = np.array([f.double().sum().item(), f.double().abs().sum().item()])
+    for s in range(4):
+        out["small/train0/disp/%d" % s] = disp[("disp", s)].detach().numpy()
+    for tag, m in (("enc", enc), ("dec", dec)):
+        rows = []
+        for name, q in unique_named_parameters(m):
+            rows.append([float("nan")] * 2 if q.grad is None else
+                        [q.grad.double().sum().item(), q.grad.double().abs().sum().item()])
+        out["grad0/" + tag] = np.array(rows)
     # full size in TRAIN mode: with closed-form weights the eval-mode network (running statistics ~N(0,1),
     # i.e. no normalisation) saturates its sigmoids at 192x640 and the comparison would be ill-conditioned
     # (stochastic depth off for this one: its draws come from the device generator and the GPU tier
