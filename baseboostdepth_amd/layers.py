@@ -119,7 +119,9 @@ class ConvBlock(nn.Module):
         out_hw = (xp.shape[2] - 2) * (xp.shape[3] - 2)
         if xp.is_cuda and xp.dtype == torch.float32 and ops.FUSED_NN and conv.bias is not None and out_hw % 4 == 0:
             y = torch.nn.functional.conv2d(xp, conv.weight, None)
-            return ops.bias_elu_(y, conv.bias)
+            if y.is_contiguous():        # channels-last inputs / NHWC policies can hand back a strided result
+                return ops.bias_elu_(y, conv.bias)
+            return self.nonlin(y + conv.bias.view(1, -1, 1, 1))
         return self.nonlin(conv(xp))
 
 

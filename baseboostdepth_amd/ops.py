@@ -374,9 +374,12 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
                     float(min_depth), float(max_depth), ptr(ptab), ptr(ident), ptr(noise), ptr(tb["cand"]),
                     ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), ptr(coords), S, B,
                     plan.NP, H, W, int(no_ssim))
-        ctx.save_for_backward(proj, target, argmin, ptab, *disps)
+        # the depth by-product is handed to the caller (outputs[("depth",0,s)], NOT differentiable: a depth-based
+        # regulariser must use disp_to_depth / opt.fused_disp=False) AND read by the backward: saving it
+        # through autograd makes an in-place edit by the caller an error instead of a silently corrupted gradient
+        ctx.has_depth = depth is not None
+        ctx.save_for_backward(proj, target, argmin, ptab, *([depth] if depth is not None else []), *disps)
         ctx.coords = coords
-        ctx.depth = depth         # by-product of the forward (or None): the backward reads it instead of re-deriving it
         ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, float(min_depth), float(max_depth))
         ctx.mark_non_differentiable(min_loss, argmin)
         if materialize:
@@ -388,7 +391,8 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sum, *_unused):
         proj, target, argmin, ptab = ctx.saved_tensors[:4]
-        disps = ctx.saved_tensors[4:]
+        depth = ctx.saved_tensors[4] if ctx.has_depth else None
+        disps = ctx.saved_tensors[5:] if ctx.has_depth else ctx.saved_tensors[4:]
         plan, frame_tensors, frames, no_ssim, backend, lo, hi = ctx.meta
         S, B = len(disps), disps[0].shape[0]
         H, W = target.shape[-2:]
@@ -399,7 +403,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         ntb = backend.num_tiles_bwd(H, W)
         gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
         backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
-                    ptr(ctx.depth), ptr(ctx.coords), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
+                    ptr(depth), ptr(ctx.coords), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
                     S, B, plan.NP, H, W, no_ssim)
         # a scale at full resolution: grad_up IS its disparity gradient; the reduced ones share one adjoint launch
         grads, small, small_g, small_up = [None] * S, [], [], []

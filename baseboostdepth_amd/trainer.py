@@ -31,6 +31,9 @@ class Trainer:
     def __init__(self, options, backend=None):
         self.opt = options
         opt = self.opt
+        if not getattr(opt, "no_cuda", False):
+            from . import tuning
+            tuning.use_shipped_db()      # MIOpen reads its database path at the first convolution (explicit, not at import)
         self.log_path = os.path.join(getattr(opt, "log_dir", "."), getattr(opt, "model_name", "mdp"))
         assert opt.height % 32 == 0, "'height' must be a multiple of 32"
         assert opt.width % 32 == 0, "'width' must be a multiple of 32"

@@ -295,6 +295,7 @@ def main(argv=None):
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
 
+    tuning.use_shipped_db()            # explicit (the Trainer would do it too): before the first convolution
     torch.manual_seed(42)
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
@@ -461,7 +462,7 @@ def main(argv=None):
                                    % (args.config, ms, args.batch, S),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "miopen": {"user_db": ("shipped (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh)"
-                                              if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "")) == "miopen_db" else
+                                              if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "")).startswith("miopen_db") else
                                               os.environ.get("MIOPEN_USER_DB_PATH")),
                                   "find": bool(torch.backends.cudnn.benchmark)}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,

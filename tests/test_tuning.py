@@ -1,12 +1,14 @@
-"""The shipped MIOpen performance database (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh) is wired in by
-environment only, never over a caller's own setting, and covers every configuration bench.py names."""
+"""The shipped MIOpen performance database (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh) is wired in by an explicit
+call (never at import, never over a caller's own setting, never writing into the checkout) and covers every configuration
+bench.py names."""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROBE = ("import os, baseboostdepth_amd; "
-         "print(os.environ.get('MIOPEN_USER_DB_PATH'), os.environ.get('MIOPEN_CUSTOM_CACHE_DIR'))")
+PROBE = ("import os, baseboostdepth_amd; before = os.environ.get('MIOPEN_USER_DB_PATH'); "
+         "from baseboostdepth_amd import tuning; tuning.use_shipped_db(); "
+         "print(before, os.environ.get('MIOPEN_USER_DB_PATH'), os.environ.get('MIOPEN_CUSTOM_CACHE_DIR'))")
 
 
 def _probe(**env):
@@ -17,14 +19,19 @@ def _probe(**env):
     return out.stdout.strip().split()
 
 
-def test_import_points_miopen_at_the_shipped_database():
-    db, cache = _probe()
-    assert db == os.path.join(ROOT, "baseboostdepth_amd", "miopen_db") and cache == os.path.join(db, "cache")
+def test_explicit_call_points_miopen_at_a_private_copy_of_the_shipped_database(tmp_path):
+    before, db, cache = _probe(BBD_MIOPEN_CACHE=str(tmp_path))
+    assert before == "None"                                   # importing the package does not touch the environment
+    assert db.startswith(str(tmp_path)) and cache == os.path.join(db, "cache")
+    shipped = os.path.join(ROOT, "baseboostdepth_amd", "miopen_db")
+    assert sorted(f for f in os.listdir(db) if f.endswith(".txt")) == sorted(f for f in os.listdir(shipped) if f.endswith(".txt"))
+    again = _probe(BBD_MIOPEN_CACHE=str(tmp_path))
+    assert again[1] == db and len(os.listdir(str(tmp_path))) == 1       # reused, not re-copied
 
 
 def test_caller_settings_win_and_the_switch_disables():
-    assert _probe(MIOPEN_USER_DB_PATH="/tmp/mine")[0] == "/tmp/mine"
-    assert _probe(BBD_MIOPEN_DB="0") == ["None", "None"]
+    assert _probe(MIOPEN_USER_DB_PATH="/tmp/mine")[1] == "/tmp/mine"
+    assert _probe(BBD_MIOPEN_DB="0") == ["None", "None", "None"]
 
 
 def test_database_holds_forward_backward_and_weight_gradient_records_for_md2_shapes():
