@@ -18,6 +18,7 @@ MAX_CAND = 20
 POSE_STRIDE = 40
 PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
+COMPOSE_STRIDE, COMPOSE_ERROR, COMPOSE_REPLACE = 12, 1, 2
 PAIR_SHIFT = 16        # bits 16-23 of bbd_cand_t.kind: 1 + index of the pass partner (hint), 0 = none
 ABI_VERSION = 3
 
@@ -44,6 +45,8 @@ SIGNATURES = {
     "bbd_disp_to_depth_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
     "bbd_pose_matrix_fwd": [_p, _p, _p, _i, _i, _p],
     "bbd_pose_matrix_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "bbd_pose_compose_fwd": [_p, _p, _p, _i, _d, _p],
+    "bbd_pose_compose_bwd": [_p, _p, _p, _p, _p, _p, _i, _p],
     "bbd_smooth_chunks": [],
     "bbd_smooth_loss_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "bbd_smooth_loss_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

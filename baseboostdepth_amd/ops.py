@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import POSE_STRIDE, PROJ_STRIDE, MAX_FRAME_SLOTS, ptr
+from ._lib import COMPOSE_STRIDE, COMPOSE_ERROR, COMPOSE_REPLACE, POSE_STRIDE, PROJ_STRIDE, MAX_FRAME_SLOTS, ptr
 from .plan import frame_slot
 
 
@@ -238,6 +238,73 @@ class _SmoothLoss(torch.autograd.Function):
 def normalised_smooth_loss(disp, img, backend=None):
     """layers.get_smooth_loss(disp / (disp.mean(2,True).mean(3,True) + 1e-7), img)  (trainer.py:560-563)."""
     return _SmoothLoss.apply(disp, img, backend or default_backend())
+
+
+# ---------------------------------------------------------------------------- pose composition (SURVEY 8f-2)
+FUSED_POSE_COMPOSE = os.environ.get("BBD_FUSED_POSE_COMPOSE", "1") != "0"
+
+
+class ComposeTable:
+    """Host-built description of every composed 4x4 of a step (include/bbd_hip.h, bbd_pose_compose_fwd): rows =
+    [(chain of step-row indices, direct row | -1, flags)], plus the inverse table the backward walks."""
+
+    def __init__(self, rows, n_steps):
+        import numpy as np
+        self.NO, self.R = len(rows), n_steps
+        tab = np.zeros((max(self.NO, 1), COMPOSE_STRIDE), dtype=np.int32)
+        refs = [[] for _ in range(n_steps)]
+        for o, (chain, direct, flags) in enumerate(rows):
+            assert len(chain) <= 7
+            tab[o, 0] = len(chain)
+            tab[o, 1:1 + len(chain)] = chain
+            tab[o, 8], tab[o, 9] = direct, flags
+            for k, r in enumerate(chain):
+                refs[r].append((o, k))
+            if direct >= 0 and (flags & COMPOSE_REPLACE):
+                refs[direct].append((o, -1))
+        off = np.zeros(n_steps + 1, dtype=np.int32)
+        for r in range(n_steps):
+            off[r + 1] = off[r] + len(refs[r])
+        flat = np.array([e for rr in refs for e in rr], dtype=np.int32).reshape(-1, 2)
+        if flat.shape[0] == 0:
+            flat = np.zeros((1, 2), dtype=np.int32)
+        self.np = (tab, off, flat)
+        self._dev = {}
+
+    def device(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(torch.from_numpy(a).to(device).contiguous() for a in self.np)
+        return self._dev[key]
+
+
+class _PoseCompose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, steps, table, pose_error, backend):
+        steps = steps.contiguous()
+        tab, off, refs = table.device(steps.device)
+        out = torch.empty(table.NO, 4, 4, device=steps.device, dtype=torch.float32)
+        backend._check(steps)
+        backend.run("bbd_pose_compose_fwd", steps, ptr(steps), ptr(tab), ptr(out), table.NO, float(pose_error))
+        ctx.save_for_backward(steps)
+        ctx.meta = (table, backend)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (steps,) = ctx.saved_tensors
+        table, backend = ctx.meta
+        tab, off, refs = table.device(steps.device)
+        gout = gout.contiguous()
+        gsteps = torch.empty_like(steps)
+        backend.run("bbd_pose_compose_bwd", steps, ptr(steps), ptr(tab), ptr(off), ptr(refs), ptr(gout), ptr(gsteps),
+                    table.R)
+        return gsteps, None, None, None
+
+
+def pose_compose(steps, table, pose_error, backend=None):
+    """steps [R,4,4] -> [NO,4,4]: every chained / error-induced / partially swapped pose of the step, one launch."""
+    return _PoseCompose.apply(steps, table, pose_error, backend or default_backend())
 
 
 # ---------------------------------------------------------------------------- identity pre-pass

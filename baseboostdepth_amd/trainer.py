@@ -540,6 +540,9 @@ class Trainer:
                 want(("direct", f), *((cur, mid, True) if f < 0 else (mid, cur, False)))
         Ts = self._pose_pairs(requests)
 
+        if ops.FUSED_POSE_COMPOSE and Ts and Ts[0].is_cuda and (incremental or opt.decomp):
+            return self._compose_poses(Ts, slot, temporal, incremental, partial)
+
         if incremental:
             for f in temporal:
                 step = Ts[slot[("step", f)]]
@@ -583,6 +586,87 @@ class Trainer:
                 keep = self._index([abs(f) == nonstereo[r] - 2 for r in range(chained.shape[0])], self.device,
                                    torch.bool).view(-1, 1, 1)
                 outputs[("cam_T_cam", 0, f)] = torch.where(keep, chained, replaced)
+        return outputs
+
+    def _compose_poses(self, Ts, slot, temporal, incremental, partial):
+        """GPU form of the loops above: the incremental chain, the error-induced poses and the partial
+        swap of the whole step as ONE launch each way (`ops.pose_compose`).  The integer table is a function of the
+        batch signature only and is cached; the composed matrices are views of one [NO,4,4] buffer."""
+        plan, opt = self.plan, self.opt
+        rows_of = [t.shape[0] for t in Ts]
+        base, acc = [], 0
+        for n in rows_of:
+            base.append(acc)
+            acc += n
+        key = (tuple(plan.ms), plan.trimin, plan.decomp, bool(opt.decomp), incremental, partial, tuple(temporal),
+               tuple(self.valid_frames), tuple(self.valid_frames_pose), tuple(rows_of),
+               tuple(sorted((str(k), v) for k, v in slot.items())))
+        cache = self.__dict__.setdefault("_compose_cache", {})
+        if key not in cache:
+            if len(cache) > 256:
+                cache.clear()
+            rows, views, passthrough = [], [], []       # views: (output key, first row, count)
+
+            def emit(okey, per_row):
+                views.append((okey, len(rows), len(per_row)))
+                rows.extend(per_row)
+
+            ERR, REP = ops.COMPOSE_ERROR, ops.COMPOSE_REPLACE
+            if incremental:
+                step_rows = {}                          # (k-1, k) -> (request slot, owners of k)
+                chains = {}
+                for f in temporal:
+                    i = slot[("step", f)]
+                    if abs(f) == 1:
+                        passthrough.append((("cam_T_cam", 0, f), i))
+                        passthrough.append((("cam_T_cam_step", 0, f), i))
+                        step_rows[(0, f)] = i
+                        chains[f] = [[base[i] + j] for j in range(rows_of[i])]
+                    else:
+                        nb = f + 1 if f < 0 else f - 1
+                        passthrough.append((("cam_T_cam_step", nb, f), i))
+                        step_rows[(nb, f)] = i
+                        if f not in self.valid_frames_pose:
+                            continue
+                        own_f = plan.owners(f)
+                        per = []
+                        for b in own_f:
+                            # the reference chains with range(f, 0, -1): EMPTY for negative f (identity pose, kept)
+                            per.append([base[step_rows[(k - 1, k)]] + plan.owners(k).index(b) for k in range(f, 0, -1)])
+                        chains[f] = per
+                    if opt.decomp:
+                        emit(("cam_T_cam_error", 0, f), [(c, -1, ERR) for c in chains[f]])
+                nonstereo = [m for m in plan.ms if m != 0]
+                for f in temporal:
+                    if abs(f) == 1 or f not in chains:
+                        continue
+                    swap = partial and f in self.valid_frames and f != STEREO
+                    per = []
+                    for j, c in enumerate(chains[f]):
+                        if swap and not (abs(f) == nonstereo[j] - 2):      # reference quirk: indexed by ROW number
+                            per.append((c, base[slot[("direct", f)]] + j, REP))
+                        else:
+                            per.append((c, -1, 0))
+                    emit(("cam_T_cam", 0, f), per)
+            else:
+                for f in self.valid_frames:
+                    if f == STEREO:
+                        continue
+                    i = slot[("job", f)]
+                    passthrough.append((("cam_T_cam", 0, f), i))
+                    if opt.decomp:
+                        emit(("cam_T_cam_error", 0, f), [([base[i] + j], -1, ERR) for j in range(rows_of[i])])
+            cache[key] = (ops.ComposeTable(rows, acc), views, passthrough)
+        table, views, passthrough = cache[key]
+        outputs = {}
+        for okey, i in passthrough:
+            outputs[okey] = Ts[i]
+        if table.NO:
+            out = ops.pose_compose(torch.cat(list(Ts), 0), table, float(opt.pose_error), self._backend())
+            for okey, o0, n in views:
+                view = out[o0:o0 + n]
+                # the reference's T_error is a detached clone (trainer.py:376): the kernel's backward skips those rows
+                outputs[okey] = view.detach() if okey[0] == "cam_T_cam_error" else view
         return outputs
 
     # ------------------------------------------------------------------ warp + loss (trainer.py:444-570)

@@ -82,6 +82,23 @@ int bbd_num_tiles_fwd(int H, int W);
 /* tiles of the BACKWARD launch: sizes grad_proj [S, NP, bbd_num_tiles_bwd(H,W), 12] */
 int bbd_num_tiles_bwd(int H, int W);
 
+/* Pose composition of a step in one launch each way (replaces the per-frame Python loops of
+ * trainer.py:359-388 (incremental chain), :376-377 / :403-405 (T_error) and :415-418 (partial swap)).
+ *   steps  [R,4,4]   every pose-network result of the step (transformation_from_parameters output), row-major
+ *   table  int32 [NO][BBD_COMPOSE_STRIDE]: {n, i0..i6, direct, flags, 0, 0} per composed matrix:
+ *            out = steps[i0] @ steps[i1] @ ... @ steps[i(n-1)]   (n = 0: identity; products rounded like torch.matmul
+ *            on the reference's CPU path); flags & BBD_COMPOSE_REPLACE: the 4th column is then taken from
+ *            steps[direct]; flags & BBD_COMPOSE_ERROR: out[:3,3] /= pose_error and the row carries no gradient
+ *   out    [NO,4,4]
+ * Backward: refs_off int32 [R+1], refs int32 [.][2] = for each step row the (output row, chain position | -1 = direct)
+ * pairs that read it; grad_steps [R,4,4] is written whole (zeros for unreferenced rows).  Deterministic. */
+#define BBD_COMPOSE_STRIDE 12
+#define BBD_COMPOSE_ERROR 1
+#define BBD_COMPOSE_REPLACE 2
+int bbd_pose_compose_fwd(const float* steps, const int32_t* table, float* out, int NO, double pose_error, void* stream);
+int bbd_pose_compose_bwd(const float* steps, const int32_t* table, const int32_t* refs_off, const int32_t* refs,
+                         const float* grad_out, float* grad_steps, int R, void* stream);
+
 /* Pose table [NP,40] -> projection table [NP,24]: P = (K@T)[:3,:] formed with the rounding order of
  * the reference's CPU torch.matmul (layers.py:182), inv_K[:3,:3] copied. */
 int bbd_pose_expand(const float* pose, float* proj, int NP, void* stream);

@@ -313,3 +313,49 @@ def test_bench_line_with_step_graph_and_fallback(capsys, monkeypatch):
     monkeypatch.setattr(Trainer, "_graph_step", broken)
     fb = _run_bench_inline(capsys, argv)
     assert isinstance(fb["step_graph"], str) and "capture failed" in fb["step_graph"] and fb["value"] > 0
+
+
+@pytest.mark.parametrize("ms,partial", [([7, 5, 4, 3], True), ([3, 1, 2, 5], False), ([2, 1, 2, 1], True)])
+def test_pose_composition_kernel_equals_the_torch_loops(ms, partial, monkeypatch):
+    """the incremental chain, T_error and the partial swap as one launch each way
+    (`bbd_pose_compose_fwd/bwd`) against the per-frame torch loops of `predict_poses` (reference trainer.py:359-388,
+    403-405, 415-418): same key set, same matrices, same gradients into the pose networks."""
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, B = 96, 160, len(ms)
+    torch.manual_seed(1)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.partial_skip = partial
+    tr = Trainer(opt)
+    tr.opt.scales = [0]
+    tr.set_eval()                               # no BatchNorm statistics in the way of an exact comparison
+    inputs = synthetic_batch(ms, H, W, [0], device=DEV, seed=5)
+    inputs["cutt"] = torch.tensor(1.35)         # epoch >= 10: incremental (+ partial) pose modes
+    tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+    tr.valid_frames_trimin(inputs)
+    params = [p for k in ("pose_encoder", "pose") for p in tr.models[k].parameters()]
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSED_POSE_COMPOSE", fused)
+        for p in params:
+            p.grad = None
+        out = tr.predict_poses(inputs)
+        gen = torch.Generator().manual_seed(9)
+        loss = 0.0
+        for k in sorted(out, key=str):
+            loss = loss + (out[k] * torch.rand(out[k].shape, generator=gen).to(DEV)).sum()
+        loss.backward()
+        return out, [p.grad.clone() if p.grad is not None else None for p in params]
+
+    a, ga = run(True)
+    b, gb = run(False)
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].shape == b[k].shape, k
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6, k
+        assert a[k].requires_grad == b[k].requires_grad, k
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert float((x - y).abs().max()) <= 1e-5 * (float(y.abs().max()) + 1e-12)

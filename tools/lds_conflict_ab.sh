@@ -7,7 +7,7 @@ set -u
 OUT=$1
 export TMPDIR=/tmp
 mkdir -p "$OUT" /tmp/bbdvar
-SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hip baseboostdepth_amd/csrc/bbd_image.hip baseboostdepth_amd/csrc/bbd_nn.hip baseboostdepth_amd/csrc/bbd_vit.hip"
+SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hip baseboostdepth_amd/csrc/bbd_image.hip baseboostdepth_amd/csrc/bbd_nn.hip baseboostdepth_amd/csrc/bbd_vit.hip baseboostdepth_amd/csrc/bbd_pose.hip"
 for spec in "whole:" "plain:-DBBD_WINDOW_PLAIN" ${BBD_EXTRA_SPECS:-}; do
   name="${spec%%:*}"; flags="${spec#*:}"
   lib=/tmp/bbdvar/libbbd_lds_$name.so
