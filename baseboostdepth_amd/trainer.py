@@ -608,7 +608,10 @@ class Trainer:
             rows, views, passthrough = [], [], []       # views: (output key, first row, count)
 
             def emit(okey, per_row):
-                views.append((okey, len(rows), len(per_row)))
+                # constant rows (empty chain, nothing swapped in; T_error) carry no gradient, like the reference's
+                const = all((flags & ops.COMPOSE_ERROR) or (not chain and not (flags & ops.COMPOSE_REPLACE))
+                            for chain, _, flags in per_row)
+                views.append((okey, len(rows), len(per_row), const))
                 rows.extend(per_row)
 
             ERR, REP = ops.COMPOSE_ERROR, ops.COMPOSE_REPLACE
@@ -663,10 +666,10 @@ class Trainer:
             outputs[okey] = Ts[i]
         if table.NO:
             out = ops.pose_compose(torch.cat(list(Ts), 0), table, float(opt.pose_error), self._backend())
-            for okey, o0, n in views:
+            for okey, o0, n, const in views:
                 view = out[o0:o0 + n]
                 # the reference's T_error is a detached clone (trainer.py:376): the kernel's backward skips those rows
-                outputs[okey] = view.detach() if okey[0] == "cam_T_cam_error" else view
+                outputs[okey] = view.detach() if const else view
         return outputs
 
     # ------------------------------------------------------------------ warp + loss (trainer.py:444-570)

@@ -323,6 +323,7 @@ def test_pose_composition_kernel_equals_the_torch_loops(ms, partial, monkeypatch
     from baseboostdepth_amd import ops
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
+    _deterministic_convolutions(monkeypatch)    # the comparison reaches the pose networks' weight gradients
     H, W, B = 96, 160, len(ms)
     torch.manual_seed(1)
     opt = make_opt(H, W, B, [0, 1, 2, 3], True)
