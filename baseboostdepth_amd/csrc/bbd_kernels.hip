@@ -26,6 +26,12 @@
 #ifndef BBD_WARP_BATCH
 #define BBD_WARP_BATCH 3
 #endif
+#ifndef BBD_PAIR_PROJECT_FWD
+#define BBD_PAIR_PROJECT_FWD 0
+#endif
+#ifndef BBD_PAIR_PROJECT_BWD
+#define BBD_PAIR_PROJECT_BWD 1
+#endif
 #ifndef BBD_BWD_WARP_BATCH
 #define BBD_BWD_WARP_BATCH 2
 #endif
@@ -279,6 +285,81 @@ __device__ __forceinline__ float2 pack_coords(const BbdSample& sm) {
                      __uint_as_float(__float_as_uint(sm.iy) | ((unsigned)sm.clipy << 31)));
 }
 
+// ---- packed fp32 (two values per lane) ------------------------------------------------------------------------
+// Plain fp32 vector instructions issue once per ~4 cycles per SIMD on gfx950 at any occupancy; v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 carry two fp32 values per lane at the same rate (profiles/r03/valu_rate.txt).  Each
+// component is an IEEE fp32 operation, so a packed evaluation of the SAME operation sequence gives the same bits.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f pk1(float a) { v2f r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// bbd_project / bbd_project_bwd for TWO staged cells at once (components .x / .y), operation for operation: only what the
+// warp phases consume comes out (clamped coordinates + clamp flags).  GUARDED = the forward's form (a component whose
+// operands leave the exponent window of the refined-reciprocal divisions is redone with the scalar function).
+template <bool GUARDED>
+__device__ __forceinline__ void project_pair(const float* pj, int xy0, int xy1, float d0, float d1, const BbdDims& dm,
+                                             BbdSample* s0, BbdSample* s1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const v2f fx = pk2((float)(xy0 & 0xffff), (float)(xy1 & 0xffff)), fy = pk2((float)(xy0 >> 16), (float)(xy1 >> 16));
+  const v2f dep = pk2(d0, d1), one = pk1(1.0f);
+  const float* iK = pj + 12;
+  // bbd_dot3_hom: fma(a2, 1, fma(a1, y, a0 * x))
+  const v2f cx = pk_fma(pk1(iK[2]), one, pk_fma(pk1(iK[1]), fy, pk1(iK[0]) * fx));
+  const v2f cy = pk_fma(pk1(iK[5]), one, pk_fma(pk1(iK[4]), fy, pk1(iK[3]) * fx));
+  const v2f cz = pk_fma(pk1(iK[8]), one, pk_fma(pk1(iK[7]), fy, pk1(iK[6]) * fx));
+  const v2f X = dep * cx, Y = dep * cy, Z = dep * cz;
+  // bbd_dot4_hom: fma(a3, 1, fma(a2, z, fma(a1, y, a0 * x)))
+  const v2f qx = pk_fma(pk1(pj[3]), one, pk_fma(pk1(pj[2]), Z, pk_fma(pk1(pj[1]), Y, pk1(pj[0]) * X)));
+  const v2f qy = pk_fma(pk1(pj[7]), one, pk_fma(pk1(pj[6]), Z, pk_fma(pk1(pj[5]), Y, pk1(pj[4]) * X)));
+  const v2f qz = pk_fma(pk1(pj[11]), one, pk_fma(pk1(pj[10]), Z, pk_fma(pk1(pj[9]), Y, pk1(pj[8]) * X)));
+  const v2f zi = qz + pk1(BBD_EPS);
+  v2f r0;
+  r0.x = __builtin_amdgcn_rcpf(zi.x);
+  r0.y = __builtin_amdgcn_rcpf(zi.y);
+  const v2f r = pk_fma(pk_fma(-zi, r0, one), r0, r0);                    // bbd_rcp_refined
+  v2f u = qx * r, v = qy * r;                                            // bbd_div_with x 2
+  u = pk_fma(pk_fma(-zi, u, qx), r, u);
+  u = pk_fma(pk_fma(-zi, u, qx), r, u);
+  v = pk_fma(pk_fma(-zi, v, qy), r, v);
+  v = pk_fma(pk_fma(-zi, v, qy), r, v);
+  const v2f wm1 = pk1(dm.wm1), hm1 = pk1(dm.hm1), rw = pk1(dm.rw), rh = pk1(dm.rh);
+  v2f nu = u * rw, nv = v * rh;                                          // bbd_div_const (divisor known on the host)
+  nu = pk_fma(pk_fma(-wm1, nu, u), rw, nu);
+  nu = pk_fma(pk_fma(-wm1, nu, u), rw, nu);
+  nv = pk_fma(pk_fma(-hm1, nv, v), rh, nv);
+  nv = pk_fma(pk_fma(-hm1, nv, v), rh, nv);
+  const v2f gx = pk_fma(nu, pk1(2.0f), pk1(-1.0f)), gy = pk_fma(nv, pk1(2.0f), pk1(-1.0f));     // bbd_norm_to_grid
+  v2f ix = pk_fma(gx, pk1(0.5f), pk1(0.5f)) * wm1, iy = pk_fma(gy, pk1(0.5f), pk1(0.5f)) * hm1; // bbd_grid_to_unit
+  BbdSample* so[2] = {s0, s1};
+  const float ixs[2] = {ix.x, ix.y}, iys[2] = {iy.x, iy.y};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float fxi = ixs[c], fyi = iys[c];
+    so[c]->clipx = !(fxi > 0.0f && fxi < dm.wm1);
+    so[c]->clipy = !(fyi > 0.0f && fyi < dm.hm1);
+    fxi = fxi > 0.0f ? fxi : 0.0f;
+    fyi = fyi > 0.0f ? fyi : 0.0f;
+    so[c]->ix = fxi < dm.wm1 ? fxi : dm.wm1;
+    so[c]->iy = fyi < dm.hm1 ? fyi : dm.hm1;
+  }
+  if (GUARDED) {
+    const float qxs[2] = {qx.x, qx.y}, qys[2] = {qy.x, qy.y}, zis[2] = {zi.x, zi.y}, us[2] = {u.x, u.y}, vs[2] = {v.x, v.y};
+    const int xys[2] = {xy0, xy1};
+    const float ds_[2] = {d0, d1};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ok = bbd_exp_ok3(qxs[c], qys[c], zis[c]) & (bbd_exp_ok(us[c]) | (us[c] == 0.0f)) &
+                     (bbd_exp_ok(vs[c]) | (vs[c] == 0.0f));
+      if (!ok) bbd_project(pj, xys[c] & 0xffff, xys[c] >> 16, ds_[c], dm, so[c]);
+    }
+  }
+#else
+  bbd_project(pj, xy0 & 0xffff, xy0 >> 16, d0, dm, s0);
+  bbd_project(pj, xy1 & 0xffff, xy1 >> 16, d1, dm, s1);
+#endif
+}
+
 // COORDS: 0 = project every cell (depth d, pose row); 1 = project and also store the coordinates of owned cells to
 // `coords` (forward, when a backward will follow); 2 = take the coordinates from `pre` (backward: no projection).
 template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int COORDS = 0>
@@ -300,10 +381,29 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
   for (int k0 = 0; k0 < CellsT::N; k0 += BATCH) {
     BbdTaps t[BATCH];
     int clip[BATCH];
+    BbdSample smp[BATCH];
+    if (COORDS != 2) {
+      // two cells per packed projection, a last odd one by the scalar function.  Measured (profiles/r03/pair_project_ab.txt):
+      // pays in the backward (unguarded divisions); in the forward the per-component validity tests and the register
+      // pairs cost more than the packing saves (+9 % in the training step) - scalar there.
+      constexpr bool PAIRS = BWD ? (BBD_PAIR_PROJECT_BWD != 0) : (BBD_PAIR_PROJECT_FWD != 0);
+      constexpr int NPAIR = PAIRS ? BATCH / 2 : 0;
+#pragma unroll
+      for (int kk = 0; kk < 2 * NPAIR; kk += 2) {
+        const int ka = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1, kb = k0 + kk + 1 < CellsT::N ? k0 + kk + 1 : CellsT::N - 1;
+        project_pair<!BWD>(pj, cl.xy[ka], cl.xy[kb], d[ka], d[kb], dm, &smp[kk], &smp[kk + 1]);
+      }
+#pragma unroll
+      for (int kk = 2 * NPAIR; kk < BATCH; ++kk) {
+        const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
+        if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
+        else bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < BATCH; ++kk) {
       const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-      BbdSample sm;
+      BbdSample sm = smp[kk];
       if (COORDS == 2) {
         const unsigned bx = __float_as_uint(pre[k].x), by = __float_as_uint(pre[k].y);
         sm.ix = __uint_as_float(bx & 0x7fffffffu);
@@ -311,9 +411,6 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
         sm.clipx = (int)(bx >> 31);
         sm.clipy = (int)(by >> 31);
       } else {
-        if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
-        else
-          bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
         if (COORDS == 1 && coords != nullptr && k0 + kk < CellsT::N && cl.own(k)) coords[cl.pix(k, dm.W)] = pack_coords(sm);
       }
       bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
@@ -330,10 +427,23 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
     for (int kk = 0; kk < BATCH; ++kk) {
       if (k0 + kk >= CellsT::N) break;
       const int k = k0 + kk;
-      float val[3];
+      float val[3], dvx[3], dvy[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        val[ch] = bbd_bilerp(v[kk][ch], &t[kk]);
+        if (BWD) {
+          // the backward needs the forward's TEXELS (the coordinates above are its bits), not its blend rounding:
+          // x = top + n (bot - top) with top / bot the two horizontal lerps shares every difference with
+          // d x / d ix = d_top + n (d_bot - d_top) and d x / d iy = bot - top: 8 operations per channel instead of 20
+          const float* vv = v[kk][ch];
+          const float dt = vv[1] - vv[0], db = vv[3] - vv[2];
+          const float top = fmaf(t[kk].w, dt, vv[0]), bot = fmaf(t[kk].w, db, vv[2]);
+          const float bt = bot - top;
+          val[ch] = fmaf(t[kk].n, bt, top);
+          dvx[ch] = fmaf(t[kk].n, db - dt, dt);
+          dvy[ch] = bt;
+        } else {
+          val[ch] = bbd_bilerp(v[kk][ch], &t[kk]);
+        }
         s[ch][cl.lds[k]] = val[ch];
       }
       if (warped_out != nullptr && cl.own(k)) {
@@ -348,9 +458,14 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
         const int ci = cl.own_index(k);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float* vv = v[kk][ch];
-          dv[ch][ci] = (clip[kk] & 1) ? 0.0f : (vv[1] - vv[0]) * t[kk].s + (vv[3] - vv[2]) * t[kk].n;
-          dv[3 + ch][ci] = (clip[kk] & 2) ? 0.0f : (vv[2] - vv[0]) * t[kk].e + (vv[3] - vv[1]) * t[kk].w;
+          if (BWD) {
+            dv[ch][ci] = (clip[kk] & 1) ? 0.0f : dvx[ch];
+            dv[3 + ch][ci] = (clip[kk] & 2) ? 0.0f : dvy[ch];
+          } else {
+            const float* vv = v[kk][ch];
+            dv[ch][ci] = (clip[kk] & 1) ? 0.0f : (vv[1] - vv[0]) * t[kk].s + (vv[3] - vv[2]) * t[kk].n;
+            dv[3 + ch][ci] = (clip[kk] & 2) ? 0.0f : (vv[2] - vv[0]) * t[kk].e + (vv[3] - vv[1]) * t[kk].w;
+          }
         }
       }
     }
@@ -655,10 +770,6 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
 // rounding per component, half the instructions.  The running minimum compares ids on ties, so the order in which
 // candidates are visited does not matter (torch.min: first index wins, a NaN wins and sticks).
 // ------------------------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
-__device__ __forceinline__ v2f pk1(float a) { v2f r; r.x = a; r.y = a; return r; }
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pk_div9(v2f x) {               // bbd_div9 per component
   const v2f r = pk1(1.0f / 9.0f);
   const v2f q = x * r;
@@ -1270,7 +1381,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
 
     BBD_STAMP(9 + 8 * (c & 1));
-    // texel gradient -> sampling coordinates -> depth and P
+    // texel gradient -> sampling coordinates -> depth and P; the strip's two pixels as the two halves of packed
+    // registers (bbd_sample_smooth + bbd_project_grad, operation for operation: same arithmetic, half the instructions)
     float gP[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
@@ -1278,26 +1390,45 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       float pj[21];
 #pragma unroll
       for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
-      float dxy[6][PPT2];
+      v2f dxy[6];
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl) {
         const float2 q = *reinterpret_cast<const float2*>(&s_dv[pl][ly * TW2 + lx0]);
-        dxy[pl][0] = q.x; dxy[pl][1] = q.y;
+        dxy[pl] = pk2(q.x, q.y);
       }
+      const v2f g0 = pk2(gx[0][0], gx[0][1]), g1 = pk2(gx[1][0], gx[1][1]), g2 = pk2(gx[2][0], gx[2][1]);   // (0 beyond W)
+      const v2f gix = g0 * dxy[0] + g1 * dxy[1] + g2 * dxy[2];
+      const v2f giy = g0 * dxy[3] + g1 * dxy[4] + g2 * dxy[5];
+      const float* iK = pj + 12;
+      const v2f fx = pk2((float)qx0, (float)(qx0 + 1)), fy = pk1((float)qy), dep = pk2(qdepth[0], qdepth[1]);
+      const v2f cx = pk_fma(pk1(iK[1]), fy, pk1(iK[0]) * fx) + pk1(iK[2]);
+      const v2f cy = pk_fma(pk1(iK[4]), fy, pk1(iK[3]) * fx) + pk1(iK[5]);
+      const v2f cz = pk_fma(pk1(iK[7]), fy, pk1(iK[6]) * fx) + pk1(iK[8]);
+      const v2f X = dep * cx, Y = dep * cy, Z = dep * cz;
+      const v2f qx_ = pk_fma(pk1(pj[2]), Z, pk_fma(pk1(pj[1]), Y, pk1(pj[0]) * X)) + pk1(pj[3]);
+      const v2f qy_ = pk_fma(pk1(pj[6]), Z, pk_fma(pk1(pj[5]), Y, pk1(pj[4]) * X)) + pk1(pj[7]);
+      const v2f zi = pk_fma(pk1(pj[10]), Z, pk_fma(pk1(pj[9]), Y, pk1(pj[8]) * X)) + pk1(pj[11] + BBD_EPS);
+      v2f r0;
+      r0.x = __builtin_amdgcn_rcpf(zi.x);
+      r0.y = __builtin_amdgcn_rcpf(zi.y);
+      const v2f rz = pk_fma(pk_fma(-zi, r0, pk1(1.0f)), r0, r0);
+      const v2f u = qx_ * rz, v = qy_ * rz;
+      const v2f gq0 = gix * rz, gq1 = giy * rz;
+      const v2f gq2 = -(gix * u + giy * v) * rz;
+      const v2f gX = gq0 * pk1(pj[0]) + gq1 * pk1(pj[4]) + gq2 * pk1(pj[8]);
+      const v2f gY = gq0 * pk1(pj[1]) + gq1 * pk1(pj[5]) + gq2 * pk1(pj[9]);
+      const v2f gZ = gq0 * pk1(pj[2]) + gq1 * pk1(pj[6]) + gq2 * pk1(pj[10]);
+      const v2f gd = gX * cx + gY * cy + gZ * cz;
+      gdepth[0] += gd.x;
+      gdepth[1] += gd.y;
+      const v2f gq[3] = {gq0, gq1, gq2};
 #pragma unroll
-      for (int j = 0; j < PPT2; ++j) {
-        const int qx = qx0 + j;
-        if (qx >= W) continue;
-        if (gx[0][j] == 0.0f && gx[1][j] == 0.0f && gx[2][j] == 0.0f) continue;
-        const float gix = gx[0][j] * dxy[0][j] + gx[1][j] * dxy[1][j] + gx[2][j] * dxy[2][j];
-        const float giy = gx[0][j] * dxy[3][j] + gx[1][j] * dxy[4][j] + gx[2][j] * dxy[5][j];
-        BbdSample sm;
-        bbd_sample_smooth(pj, qx, qy, qdepth[j], &sm);
-        float gd, gp1[12];
-        bbd_project_grad(pj, &sm, gix, giy, &gd, gp1);
-        gdepth[j] += gd;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gP[k] += gp1[k];
+      for (int r = 0; r < 3; ++r) {
+        const v2f a = gq[r] * X, b2 = gq[r] * Y, c2 = gq[r] * Z;
+        gP[4 * r + 0] = a.x + a.y;
+        gP[4 * r + 1] = b2.x + b2.y;
+        gP[4 * r + 2] = c2.x + c2.y;
+        gP[4 * r + 3] = gq[r].x + gq[r].y;
       }
     }
     if (cd.kind & FLAG_NO_POSE_GRAD) {
