@@ -38,8 +38,8 @@ SIGNATURES = {
     "bbd_identity_loss_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
     "bbd_warp_ssim_min_fwd": [_p] * 12 + [_i] * 6 + [_p],
     "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],
-    "bbd_warp_ssim_min_disp_fwd": [_p, _p, _p, _p, _d, _d] + [_p] * 11 + [_i] * 6 + [_p],
-    "bbd_warp_ssim_min_disp_bwd": [_p, _p, _p, _p, _d, _d] + [_p] * 9 + [_i] * 6 + [_p],
+    "bbd_warp_ssim_min_disp_fwd": [_p, _p, _p, _p, _d, _d] + [_p] * 10 + [_i] * 6 + [_p],
+    "bbd_warp_ssim_min_disp_bwd": [_p, _p, _p, _p, _d, _d] + [_p] * 8 + [_i] * 6 + [_p],
     "bbd_disp_upsample_adjoint": [_p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_disp_to_depth_fwd": [_p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
     "bbd_disp_to_depth_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _p],

@@ -277,14 +277,7 @@ __device__ __forceinline__ void load_depth(const DepthSrc& src, int H, int W, co
   for (int k = 0; k < CellsT::N; ++k) d[k] = depth_at(src, cl.xy[k] >> 16, cl.xy[k] & 0xffff, H, W);
 }
 
-// Warp one source image into the staged region for one pose-table row.
-// Sampling coordinates handed from the forward to the backward (one float2 per pixel and warp candidate): the
-// clamped (ix, iy) of bbd_project, with the "border clamp active" flags in the sign bits (ix, iy >= 0 otherwise).
-__device__ __forceinline__ float2 pack_coords(const BbdSample& sm) {
-  return make_float2(__uint_as_float(__float_as_uint(sm.ix) | ((unsigned)sm.clipx << 31)),
-                     __uint_as_float(__float_as_uint(sm.iy) | ((unsigned)sm.clipy << 31)));
-}
-
+// Warp one source image into the staged region for one pose-table row (after the packed helpers below).
 // ---- packed fp32 (two values per lane) ------------------------------------------------------------------------
 // Plain fp32 vector instructions issue once per ~4 cycles per SIMD on gfx950 at any occupancy; v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32 carry two fp32 values per lane at the same rate (profiles/r03/valu_rate.txt).  Each
@@ -360,14 +353,12 @@ __device__ __forceinline__ void project_pair(const float* pj, int xy0, int xy1, 
 #endif
 }
 
-// COORDS: 0 = project every cell (depth d, pose row); 1 = project and also store the coordinates of owned cells to
-// `coords` (forward, when a backward will follow); 2 = take the coordinates from `pre` (backward: no projection).
-template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int COORDS = 0>
+// XS = element stride of the staged planes (2: the backward interleaves (x, y) pairs, see its kernel).
+template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int XS = 1>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
-                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
-                                              float2* __restrict__ coords = nullptr, const float2* pre = nullptr) {
+                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr) {
   // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
@@ -382,7 +373,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
     BbdTaps t[BATCH];
     int clip[BATCH];
     BbdSample smp[BATCH];
-    if (COORDS != 2) {
+    {
       // two cells per packed projection, a last odd one by the scalar function.  Measured (profiles/r03/pair_project_ab.txt):
       // pays in the backward (unguarded divisions); in the forward the per-component validity tests and the register
       // pairs cost more than the packing saves (+9 % in the training step) - scalar there.
@@ -403,16 +394,8 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
 #pragma unroll
     for (int kk = 0; kk < BATCH; ++kk) {
       const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-      BbdSample sm = smp[kk];
-      if (COORDS == 2) {
-        const unsigned bx = __float_as_uint(pre[k].x), by = __float_as_uint(pre[k].y);
-        sm.ix = __uint_as_float(bx & 0x7fffffffu);
-        sm.iy = __uint_as_float(by & 0x7fffffffu);
-        sm.clipx = (int)(bx >> 31);
-        sm.clipy = (int)(by >> 31);
-      } else {
-        if (COORDS == 1 && coords != nullptr && k0 + kk < CellsT::N && cl.own(k)) coords[cl.pix(k, dm.W)] = pack_coords(sm);
-      }
+      const BbdSample sm = smp[kk];
+      (void)k;
       bbd_taps(sm.ix, sm.iy, dm, &t[kk]);
       clip[kk] = sm.clipx | (sm.clipy << 1);
     }
@@ -444,7 +427,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
         } else {
           val[ch] = bbd_bilerp(v[kk][ch], &t[kk]);
         }
-        s[ch][cl.lds[k]] = val[ch];
+        s[ch][XS * cl.lds[k]] = val[ch];
       }
       if (warped_out != nullptr && cl.own(k)) {
         float* o = warped_out + cl.pix(k, dm.W);
@@ -627,7 +610,6 @@ struct FwdArgs {
   float* partial;
   float* warped;
   float* depth_out;     // optional [S,B,H,W]: the depth this launch used (outputs[("depth",0,s)] of the reference)
-  float2* coords;       // optional [S,NP,H,W]: clamped sampling coordinates + clamp flags, for the backward
   DispSrc ds;
   BbdDims dm;
   int S, B, NP, ntiles, no_ssim, remap, scale_loop;
@@ -701,9 +683,8 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
       float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
       BBD_STAMP(4 + 4 * (c & 3));
-      float2* cout = a.coords ? a.coords + ((size_t)s * a.NP + cd.pose) * hw : nullptr;
-      warp_into_lds<BBD_WARP_BATCH, Cells<LH, LW, LS, 1>, FPLANE, TH * TW, false, 1>(
-          src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout, nullptr, cout);
+      warp_into_lds<BBD_WARP_BATCH, Cells<LH, LW, LS, 1>, FPLANE>(
+          src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
       BBD_STAMP(5 + 4 * (c & 3));
       __syncthreads();
       BBD_STAMP(6 + 4 * (c & 3));
@@ -1080,7 +1061,6 @@ struct BwdArgs {
   const float* gscale;
   float* grad_depth;    // depth-plane mode: d loss / d depth; disparity mode: d loss / d up-sampled disparity
   float* grad_proj;
-  const float2* coords; // optional [S,NP,H,W] from the forward: the warp recompute then needs no projection
   DispSrc ds;
   BbdDims dm;
   int S, B, NP, ntiles, no_ssim, remap;
@@ -1140,18 +1120,18 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 #ifndef BBD_BWD2_WARP_BATCH
 #define BBD_BWD2_WARP_BATCH 3
 #endif
-template <bool HANDOVER>     // true: a.coords holds the forward's sampling coordinates (no projection, no halo depth)
 __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_ybuf[3 * BPLANE2 + 8];
-  __shared__ __attribute__((aligned(16))) float s_xbuf[3 * BPLANE2 + 8];
+  // warped (x) and target (y) texels of a staged cell sit side by side - planes of (x, y) pairs: every window read of
+  // the coefficient phase is one 8-byte load that lands in a register pair, and its five running sums become three
+  // packed operations per tap ((sx, sy) += (x, y); (sxx, syy) += (x, y)^2) plus the scalar sxy
+  __shared__ __attribute__((aligned(16))) float s_xybuf[3 * 2 * BPLANE2 + 16];
   __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE2];
   __shared__ uint16_t s_list[CH * CW2];
   __shared__ __attribute__((aligned(16))) float s_dv[6][TH * TW2];
   __shared__ float s_red[NT2 / 64][12];
   __shared__ unsigned s_present;
   __shared__ int s_count;
-  float (*s_y)[BPLANE2] = reinterpret_cast<float (*)[BPLANE2]>(s_ybuf);
-  float (*s_x)[BPLANE2] = reinterpret_cast<float (*)[BPLANE2]>(s_xbuf);
+  float (*s_xy)[2 * BPLANE2] = reinterpret_cast<float (*)[2 * BPLANE2]>(s_xybuf);      // [ch][2 * cell + {0: x, 1: y}]
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
   int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -1199,12 +1179,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
   float dcell[CellsB::N];
-  if (!HANDOVER) {
-    load_depth(dsrc, H, W, cl, dcell);       // depth of the halo'd cells is only needed to project them
-  } else {
-#pragma unroll
-    for (int q = 0; q < CellsB::N; ++q) dcell[q] = 1.0f;
-  }
+  load_depth(dsrc, H, W, cl, dcell);         // depth of the halo'd cells is only needed to project them
 
   BBD_STAMP(22);
   const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
@@ -1240,9 +1215,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   BBD_STAMP(26);
 #pragma unroll
   for (int k = 0; k < CellsB::N; ++k) {
-    s_y[0][cl.lds[k]] = tcell[k][0];
-    s_y[1][cl.lds[k]] = tcell[k][1];
-    s_y[2][cl.lds[k]] = tcell[k][2];
+    s_xy[0][2 * cl.lds[k] + 1] = tcell[k][0];
+    s_xy[1][2 * cl.lds[k] + 1] = tcell[k][1];
+    s_xy[2][2 * cl.lds[k] + 1] = tcell[k][2];
   }
   BBD_STAMP(1);
   __syncthreads();
@@ -1275,17 +1250,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
-    if (HANDOVER) {
-      // the forward's clamped sampling coordinates of the staged cells (coalesced 8-byte loads); no projection
-      float2 pre[CellsB::N];
-      const float2* cp = a.coords + ((size_t)s * a.NP + cd.pose) * hw;
-#pragma unroll
-      for (int q = 0; q < CellsB::N; ++q) pre[q] = cp[cl.pix(q, W)];
-      warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr,
-                                                                            s_dv, nullptr, pre);
-    } else {
-      warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, BPLANE2, TH * TW2, true>(src, dcell, pose_row, dm, hw, cl, s_x, nullptr, s_dv);
-    }
+    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_xy, nullptr,
+                                                                               s_dv);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
@@ -1298,17 +1264,21 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       for (int idx = threadIdx.x; idx < nwin; idx += NT2) {
         const int cell = s_list[idx];
         const int pr = cell / CS2, pc = cell - pr * CS2;
-        float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
+        v2f s1 = pk1(0.0f), s2 = pk1(0.0f);       // (sum x, sum y), (sum x^2, sum y^2)
+        float sxy = 0.0f;
+        const v2f* xyp = reinterpret_cast<const v2f*>(&s_xy[ch][0]);
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr)
 #pragma unroll
           for (int dc = 0; dc < 3; ++dc) {
-            const float xv = s_x[ch][(pr + dr) * BS2 + pc + dc], yv = s_y[ch][(pr + dr) * BS2 + pc + dc];
-            sx_ += xv; sxx += xv * xv; sxy += xv * yv; sy_ += yv; syy += yv * yv;
+            const v2f xy = xyp[(pr + dr) * BS2 + pc + dc];
+            s1 = s1 + xy;
+            s2 = s2 + xy * xy;
+            sxy += xy.x * xy.y;
           }
         float mu_y, sg_y, A, Bc, Cc;
-        bbd_ystats(sy_, syy, &mu_y, &sg_y);
-        bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
+        bbd_ystats(s1.y, s2.y, &mu_y, &sg_y);
+        bbd_ssim_grad(s1.x, s2.x, sxy, mu_y, sg_y, &A, &Bc, &Cc);
         s_cf[0][cell] = A * w_ssim;
         s_cf[1][cell] = Bc * w_ssim;
         s_cf[2][cell] = Cc * w_ssim;
@@ -1319,9 +1289,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       if (ch == 0 && threadIdx.x == 0) s_count = 0;
 
       // G: adjoint of reflect-pad + 3x3 mean at this thread's 2 texels
-      const float2 xq2 = *reinterpret_cast<const float2*>(&s_x[ch][(ly + 2) * BS2 + lx0 + 2]);
-      const float2 yq2 = *reinterpret_cast<const float2*>(&s_y[ch][(ly + 2) * BS2 + lx0 + 2]);
-      const float xqv[PPT2] = {xq2.x, xq2.y}, yqv[PPT2] = {yq2.x, yq2.y};
+      const float4 xy2 = *reinterpret_cast<const float4*>(&s_xy[ch][2 * ((ly + 2) * BS2 + lx0 + 2)]);   // (x0, y0, x1, y1)
+      const float xqv[PPT2] = {xy2.x, xy2.z}, yqv[PPT2] = {xy2.y, xy2.w};
       float S3[3][PPT2];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
@@ -1331,13 +1300,13 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
         if (interior) {
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
-            float cw[3][4];
-            load_window4<CS2>(s_cf[pl], ly, lx0, cw);
-            float col[PPT2 + 2];
-#pragma unroll
-            for (int i = 0; i < PPT2 + 2; ++i) col[i] = (cw[0][i] + cw[1][i]) + cw[2][i];
-#pragma unroll
-            for (int j = 0; j < PPT2; ++j) S3[pl][j] = (col[j] + col[j + 1]) + col[j + 2];
+            // the 3x4 window arrives as register pairs (two 8-byte reads per row): column sums on pairs
+            const v2f* p2 = reinterpret_cast<const v2f*>(s_cf[pl]) + (ly * (CS2 / 2) + (lx0 >> 1));
+            const v2f colA = (p2[0] + p2[CS2 / 2]) + p2[CS2];                  // columns 0, 1
+            const v2f colB = (p2[1] + p2[CS2 / 2 + 1]) + p2[CS2 + 1];          // columns 2, 3
+            const float mid = colA.y + colB.x;
+            S3[pl][0] = colA.x + mid;
+            S3[pl][1] = mid + colB.y;
           }
         } else {
           float wy[3], wx[PPT2][3];
@@ -2871,7 +2840,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
                             const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                             const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
                             float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                            float* coords, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
+                            int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!target || (!depth && !disp) || !cand || !ncand || !min_loss || !argmin || !partial) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   FwdArgs a;
@@ -2884,7 +2853,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   if (fill_disp(disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.ident = ident; a.noise = noise;
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
-  a.warped = warped; a.depth_out = depth_out; a.coords = reinterpret_cast<float2*>(coords); a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
+  a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
   a.remap = xcd_remap_enabled();
   // BBD_FWD=2: the paired-candidate / packed-SSIM form (experimental, slower so far: profiles/r03/fwdp_ab.txt)
@@ -2894,7 +2863,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   // set-up it saves was already hidden by the other resident workgroups) - off (profiles/r03/fwd_scale_loop_ab.txt)
   static const int scale_loop = [] { const char* e = getenv("BBD_FWD_SCALE_LOOP"); return e ? atoi(e) : 0; }();
   a.scale_loop = 0;
-  if (form == 2 && a.coords == nullptr) {
+  if (form == 2) {
     hipLaunchKernelGGL(warp_ssim_min_fwdp_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                        static_cast<hipStream_t>(stream), a);
   } else {
@@ -2908,10 +2877,9 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
 static int launch_fused_bwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
                             const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                             const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
-                            const float* coords, float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W,
+                            float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W,
                             int no_ssim, void* stream) {
   if (!target || (!depth && !disp) || !cand || !ncand || !argmin || !gscale || !grad_depth || !grad_proj) return BBD_E_BADARG;
-  if (coords && !depth) return BBD_E_BADARG;     // with hand-over coordinates the own-pixel depth comes from the planes
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   BwdArgs a;
 #ifdef BBD_STAMPS
@@ -2923,24 +2891,19 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   if (fill_disp(disp, disp_hw, min_depth, max_depth, S, H, W, &a.ds)) return BBD_E_BADARG;
   a.target = target; a.depth = depth; a.pose = proj; a.cand = cand; a.ncand = ncand; a.argmin = argmin;
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
-  a.coords = reinterpret_cast<const float2*>(coords);
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
   a.remap = xcd_remap_enabled();
   // BBD_BWD=3: the sparse-item form (experimental: equal on per-pixel random disparities, slower inside the training
   // step - profiles/r03/bwd3_*.txt)
   static const int form = [] { const char* e = getenv("BBD_BWD"); return e ? atoi(e) : 2; }();
-  if (!coords && form == 3) {
+  if (form == 3) {
     hipLaunchKernelGGL(warp_ssim_min_bwd3_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                        static_cast<hipStream_t>(stream), a);
     return launch_status();
   }
-  if (coords)
-    hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
-                       static_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<false>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
-                       static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                     static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 
@@ -2950,7 +2913,7 @@ int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const 
                           int H, int W, int no_ssim, void* stream) {
   if (!depth) return BBD_E_BADARG;
   return launch_fused_fwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, ident, noise, cand, ncand, min_loss,
-                          argmin, partial, warped, nullptr, nullptr, S, B, NP, H, W, no_ssim, stream);
+                          argmin, partial, warped, nullptr, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth, const float* proj,
@@ -2958,7 +2921,7 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
                           float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
                           void* stream) {
   if (!depth) return BBD_E_BADARG;
-  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, argmin, gscale, nullptr,
+  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, argmin, gscale,
                           grad_depth, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 
@@ -2966,20 +2929,20 @@ int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, c
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                                const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
                                float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                               float* coords_out, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
+                               int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
   return launch_fused_fwd(frames, target, nullptr, disp, disp_hw, min_depth, max_depth, proj, ident, noise, cand, ncand,
-                          min_loss, argmin, partial, warped, depth_out, coords_out, S, B, NP, H, W, no_ssim, stream);
+                          min_loss, argmin, partial, warped, depth_out, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* depth,
-                               const float* coords, const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
+                               const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
                                const uint8_t* argmin, const float* gscale, float* grad_up, float* grad_proj, int S, int B,
                                int NP, int H, int W, int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
   return launch_fused_bwd(frames, target, depth, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
-                          coords, grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
+                          grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B,

@@ -16,10 +16,6 @@ from ._lib import COMPOSE_STRIDE, COMPOSE_ERROR, COMPOSE_REPLACE, POSE_STRIDE, P
 from .plan import frame_slot
 
 
-# BBD_COORD_HANDOVER=1: the forward hands every warp candidate's clamped sampling coordinates to the backward
-# (8 B per pixel and candidate), whose warp recompute then skips the projection.  Measured neutral (backward -1..2 %,
-# forward +2 %: the dependent coordinate load costs what the arithmetic saved - profiles/r02/handover_ab.txt), so OFF.
-HANDOVER = os.environ.get("BBD_COORD_HANDOVER", "0") == "1"
 # BBD_FUSED_NN=0 sends the encoder / decoder glue (pad, max-pool) back to the stock ATen kernels (A/B runs)
 FUSED_NN = os.environ.get("BBD_FUSED_NN", "1") != "0"
 
@@ -428,25 +424,19 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         partial = torch.empty(S, B, ntiles, device=dev, dtype=torch.float32)
         warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
         depth = torch.empty(S, B, H, W, device=dev, dtype=torch.float32) if want_depth else None
-        # a backward will follow: let the forward hand over every candidate's sampling coordinates (8 B per pixel
-        # and warp candidate) so that the backward's warp recompute needs no projection
-        need_bwd = torch.is_grad_enabled() and (proj.requires_grad or any(d.requires_grad for d in disps))
-        coords = (torch.empty(S, plan.NP, H, W, 2, device=dev, dtype=torch.float32)
-                  if (need_bwd and depth is not None and HANDOVER) else None)
         backend._check(proj, target, ident, noise, *disps, *frame_tensors.values())
         frames = frame_pointer_array(frame_tensors)
         ptab = torch.empty(plan.NP, PROJ_STRIDE, device=dev, dtype=torch.float32)
         backend.run("bbd_pose_expand", proj, ptr(proj), ptr(ptab), plan.NP)
         backend.run("bbd_warp_ssim_min_disp_fwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps),
                     float(min_depth), float(max_depth), ptr(ptab), ptr(ident), ptr(noise), ptr(tb["cand"]),
-                    ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), ptr(coords), S, B,
+                    ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), S, B,
                     plan.NP, H, W, int(no_ssim))
         # the depth by-product is handed to the caller (outputs[("depth",0,s)], NOT differentiable: a depth-based
         # regulariser must use disp_to_depth / opt.fused_disp=False) AND read by the backward: saving it
         # through autograd makes an in-place edit by the caller an error instead of a silently corrupted gradient
         ctx.has_depth = depth is not None
         ctx.save_for_backward(proj, target, argmin, ptab, *([depth] if depth is not None else []), *disps)
-        ctx.coords = coords
         ctx.meta = (plan, frame_tensors, frames, int(no_ssim), backend, float(min_depth), float(max_depth))
         ctx.mark_non_differentiable(min_loss, argmin)
         if materialize:
@@ -470,7 +460,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         ntb = backend.num_tiles_bwd(H, W)
         gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
         backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
-                    ptr(depth), ptr(ctx.coords), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
+                    ptr(depth), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
                     S, B, plan.NP, H, W, no_ssim)
         # a scale at full resolution: grad_up IS its disparity gradient; the reduced ones share one adjoint launch
         grads, small, small_g, small_up = [None] * S, [], [], []

@@ -152,9 +152,6 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
  * {h_0,w_0,h_1,w_1,...} - and evaluate F.interpolate(bilinear, align_corners=False) + layers.disp_to_depth
  * (trainer.py:455-461, layers.py:13-22) per staged pixel, bit-identical to bbd_disp_to_depth_fwd.  No depth
  * buffer is read; depth_out (optional, [S,B,H,W]) receives outputs[("depth",0,s)] as a by-product.
- * coords_out (optional, [S,NP,H,W,2]) receives every warp candidate's clamped sampling coordinates (clamp flags in the
- * sign bits); given back to the backward as `coords` (needs `depth` too) its warp recompute skips the projection -
- * the selected texels are the forward's by construction.
  * The backward takes `depth` = the forward's depth_out (or NULL: it then re-evaluates the up-sampling per staged
  * pixel, +5 % instructions) and hands back grad_up [S,B,H,W] = d loss / d (up-sampled disparity); for a scale at full
  * resolution that IS the disparity gradient, the reduced scales go through bbd_disp_upsample_adjoint
@@ -163,10 +160,10 @@ int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, c
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                                const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
                                float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                               float* coords_out, int S, int B, int NP, int H, int W, int no_ssim, void* stream);
+                               int S, int B, int NP, int H, int W, int no_ssim, void* stream);
 int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* depth,
-                               const float* coords, const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
+                               const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
                                const uint8_t* argmin, const float* gscale, float* grad_up, float* grad_proj, int S, int B,
                                int NP, int H, int W, int no_ssim, void* stream);
 int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B,

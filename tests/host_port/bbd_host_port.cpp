@@ -258,7 +258,7 @@ int hp_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, co
                               const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                               const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                              float* /*coords_out*/, int S, int B, int NP, int H, int W, int no_ssim) {
+                              int S, int B, int NP, int H, int W, int no_ssim) {
   std::vector<float> tmp;
   float* depth = depth_out;
   if (!depth) { tmp.resize((size_t)S * B * H * W); depth = tmp.data(); }
@@ -269,7 +269,7 @@ int hp_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, co
 
 int hp_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                               const int32_t* disp_hw, double min_depth, double max_depth, const float* /*depth planes*/,
-                              const float* /*coords*/, const float* proj,
+                              const float* proj,
                               const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
                               float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim) {
   std::vector<float> depth((size_t)S * B * H * W);
