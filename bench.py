@@ -416,11 +416,15 @@ def main(argv=None):
         # HBM bytes per launch from rocprofv3 PMC passes of the same workload (committed under profiles/)
         traffic = None
         tpath = None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             cand = os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % args.config)
             if os.path.isfile(cand):
                 tpath = cand
                 break
+        isa_mix = {}
+        mix_path = os.path.join(ROOT, "profiles", "r03", "isa_mix.json")
+        if os.path.isfile(mix_path):
+            isa_mix = json.load(open(mix_path))
         if args.batch == 12 and tpath is not None:
             tj = json.load(open(tpath))
             alias = lambda k: k.replace("_disp_", "_")           # PMC files name the kernels, not the entry points
@@ -431,11 +435,14 @@ def main(argv=None):
                 if k in tj:
                     kernels[k]["pmc_traffic_MB_per_launch"] = round(tj[k]["traffic_bytes"] / 1e6, 1)
                     if "valu_wave_instructions" in tj[k]:
-                        # the kernels are VALU-bound: 1024 SIMDs, 1.25 ns per wave-instruction
-                        # per SIMD measured by tools/microbench/valu_rate.hip at >= 4 waves/SIMD
-                        floor_ms = tj[k]["valu_wave_instructions"] / 1024 * 1.25e-6
-                        kernels[k]["valu_floor_ms"] = round(floor_ms, 4)
-                        kernels[k]["frac_of_valu_floor"] = round(floor_ms / kernels[k]["mean_ms"], 3)
+                        # issue floor of the fp32 pipe: counter-measured vector instructions of the launch
+                        # (a committed PMC pass, not this run) x the kernel's static fp32-pipe share
+                        # (profiles/r03/isa_mix.json) x 4.1 cycles per wave-instruction per SIMD at 2.4 GHz
+                        # (profiles/r03/valu_rate.txt: the same at 1..8 waves per SIMD), 1024 SIMDs
+                        share = isa_mix.get(alias(k), {}).get("fp32_share", 0.75)
+                        floor_ms = tj[k]["valu_wave_instructions"] * share / 1024 * (4.1 / 2.4e9) * 1e3
+                        kernels[k]["fp32_issue_floor_ms"] = round(floor_ms, 4)
+                        kernels[k]["frac_of_issue_floor"] = round(floor_ms / kernels[k]["mean_ms"], 3)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
                     "traffic_source": os.path.relpath(tpath, ROOT) if (traffic is not None) else None}
