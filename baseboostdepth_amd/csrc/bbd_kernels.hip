@@ -580,6 +580,37 @@ __global__ __launch_bounds__(NT) void identity_loss_kernel(FramePtrs frames, con
   if (yy < H) store_strip(ident + (size_t)item * hw + yy * W + xx, xx, W, (xx + PPT <= W) && ((W & 3) == 0), loss);
 }
 
+// torch.min(dim) as an order-free update: smaller wins, on equal values the smaller id, a NaN wins over numbers and
+// among NaNs the smaller id (= "first index", "NaN wins and sticks" of the sequential form bbd_min_update)
+__device__ __forceinline__ void min_update_any_order(float cand, int id, float* best, int* arg) {
+  const bool cn = cand != cand, bn = *best != *best;
+  const bool take = (cand < *best) || ((cand == *best || (cn && bn)) && id < *arg) || (cn && !bn);
+  *best = take ? cand : *best;
+  *arg = take ? id : *arg;
+}
+
+// Visiting order of a sample's candidates: ascending id, except that a warp candidate is followed at once by its pairing
+// partner (bits 16-23 of `kind`: the error-induced warp of the same source frame).  The pair samples almost the same
+// texels, so the second candidate's gathers hit the lines the first brought in (L1 / this XCD's L2) instead of going
+// back to the fabric.  Uniform (scalar) bookkeeping; results do not depend on the order (min_update_any_order).
+struct CandOrder {
+  unsigned todo;
+  int forced;
+  __device__ __forceinline__ void init(int nc) { todo = nc >= 32 ? 0xffffffffu : ((1u << nc) - 1u); forced = -1; }
+  __device__ __forceinline__ bool more() const { return todo != 0u || forced >= 0; }
+  __device__ __forceinline__ int next(const bbd_cand_t* tab, bbd_cand_t* cd) {
+    int c;
+    if (forced >= 0) { c = forced; forced = -1; }
+    else { c = __builtin_ctz(todo); todo &= todo - 1u; }
+    *cd = load_cand(tab + c);
+    if ((cd->kind & KIND_MASK) == BBD_KIND_WARP) {
+      const int hint = ((cd->kind >> 16) & 0xff) - 1;
+      if (hint >= 0 && hint < 32 && ((todo >> hint) & 1u)) { forced = hint; todo &= ~(1u << hint); }
+    }
+    return c;
+  }
+};
+
 // ------------------------------------------------------------------------------------------
 // Fused forward: warp + SSIM/L1 + min/arg-min over the candidate list.
 // ------------------------------------------------------------------------------------------
@@ -676,20 +707,26 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
-  for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
+  CandOrder order;
+  order.init(nc);
+  int visit = 0;
+  while (order.more()) {
+    bbd_cand_t cd;
+    const int c = order.next(a.cand + b * BBD_MAX_CAND, &cd);
+    const int vs = visit++;
+    (void)vs;
     float loss[PPT];
     if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
       const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
       float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
-      BBD_STAMP(4 + 4 * (c & 3));
+      BBD_STAMP(4 + 4 * (vs & 3));
       warp_into_lds<BBD_WARP_BATCH, Cells<LH, LW, LS, 1>, FPLANE>(
           src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
-      BBD_STAMP(5 + 4 * (c & 3));
+      BBD_STAMP(5 + 4 * (vs & 3));
       __syncthreads();
-      BBD_STAMP(6 + 4 * (c & 3));
+      BBD_STAMP(6 + 4 * (vs & 3));
       strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
-      BBD_STAMP(7 + 4 * (c & 3));
+      BBD_STAMP(7 + 4 * (vs & 3));
       buf ^= 1;
     } else {
 #pragma unroll
@@ -707,7 +744,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       int aj = (int)((argw >> (8 * j)) & 0xffu);
-      bbd_min_update(loss[j], c, &best[j], &aj);
+      min_update_any_order(loss[j], c, &best[j], &aj);
       argw = (argw & ~(0xffu << (8 * j))) | ((unsigned)aj << (8 * j));
     }
   }
@@ -775,15 +812,6 @@ __device__ __forceinline__ v2f pk_div(v2f n, v2f d) {         // bbd_div per com
   if (!bbd_exp_ok3(n.y, d.y, d.y)) q.y = n.y / d.y;
 #endif
   return q;
-}
-
-// torch.min(dim) as an order-free update: smaller wins, on equal values the smaller id, a NaN wins over numbers and
-// among NaNs the smaller id (= "first index", "NaN wins and sticks" of the sequential form bbd_min_update)
-__device__ __forceinline__ void min_update_any_order(float cand, int id, float* best, int* arg) {
-  const bool cn = cand != cand, bn = *best != *best;
-  const bool take = (cand < *best) || ((cand == *best || (cn && bn)) && id < *arg) || (cn && !bn);
-  *best = take ? cand : *best;
-  *arg = take ? id : *arg;
 }
 
 // 3 rows x 8 columns (6 used) of a float2 plane starting at row r0, column c0 (c0 % 4 == 0): ds_read_b128 x 4 per row
@@ -1226,8 +1254,11 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 
   const int nc = uniform_load(a.ncand + b);
   int prev = -1;
-  for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = load_cand(a.cand + b * BBD_MAX_CAND + c);
+  CandOrder order;                       // a frame's true-pose and error-induced warps back to back (cache locality)
+  order.init(nc);
+  while (order.more()) {
+    bbd_cand_t cd;
+    const int c = order.next(a.cand + b * BBD_MAX_CAND, &cd);
     if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
     float* gp_out = a.grad_proj + (((size_t)s * a.NP + cd.pose) * a.ntiles + tc.tile) * 12;
     if (!((present >> c) & 1u)) {
@@ -2778,13 +2809,14 @@ int fill_frames(const void* const* frames, FramePtrs* out) {
   return 0;
 }
 
-// BBD_XCD_REMAP=1 turns the XCD-aware work order on.  Measured (profiles/r03/xcd_remap_ab.txt): with per-pixel random
-// disparities (scattered gathers, tools/kernel_bench.py boost7) forward -11 %, backward -3 %; inside the training step
-// (smooth network disparities: neighbouring tiles' gathers already hit L1/L2) boosted 0.2143 -> 0.2133 ms, MD2 forward
-// 0.1744 -> 0.1789 ms (the four scales of a sample no longer run side by side on all XCDs).  Off by default.
-int xcd_remap_enabled() {
-  static const int on = [] { const char* e = getenv("BBD_XCD_REMAP"); return e != nullptr && e[0] == '1'; }();
-  return on;
+// XCD-aware work order: on for single-scale launches (the boosted recipe's epoch >= 10 regime), off for the 4-scale
+// launches; BBD_XCD_REMAP=0 / 1 forces it.  Measured (profiles/r03/xcd_remap_ab.txt, traffic_boosted*.json): m = 7 with
+// per-pixel random disparities forward -11 %, backward -3 %; inside the training step the time is unchanged but the
+// fabric-side traffic drops (neighbouring tiles, and a frame's two warps, then meet in ONE XCD's L2); with four scales the
+// forward is 2.5 % slower (the scales of a sample no longer run side by side on all XCDs).
+int xcd_remap_enabled(int S) {
+  static const int forced = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr ? -1 : (e[0] == '1'); }();
+  return forced >= 0 ? forced : (S == 1);
 }
 
 int launch_status() {
@@ -2814,7 +2846,7 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   const int ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(identity_loss_kernel, dim3((unsigned)(NI * ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim,
-                     xcd_remap_enabled());
+                     xcd_remap_enabled(0));
   return launch_status();
 }
 
@@ -2855,7 +2887,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.cand = cand; a.ncand = ncand; a.min_loss = min_loss; a.argmin = argmin; a.partial = partial;
   a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
-  a.remap = xcd_remap_enabled();
+  a.remap = xcd_remap_enabled(S);
   // BBD_FWD=2: the paired-candidate / packed-SSIM form (experimental, slower so far: profiles/r03/fwdp_ab.txt)
   static const int form = [] { const char* e = getenv("BBD_FWD"); return e ? atoi(e) : 1; }();
   // BBD_FWD_SCALE_LOOP=1: one workgroup per (sample, tile) walks the scales (set-up once).  Measured neutral inside the
@@ -2893,7 +2925,7 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.gscale = gscale; a.grad_depth = grad_depth; a.grad_proj = grad_proj;
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
-  a.remap = xcd_remap_enabled();
+  a.remap = xcd_remap_enabled(S);
   // BBD_BWD=3: the sparse-item form (experimental: equal on per-pixel random disparities, slower inside the training
   // step - profiles/r03/bwd3_*.txt)
   static const int form = [] { const char* e = getenv("BBD_BWD"); return e ? atoi(e) : 2; }();
