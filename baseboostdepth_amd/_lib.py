@@ -36,6 +36,7 @@ SIGNATURES = {
     "bbd_num_tiles_bwd": [_i, _i],
     "bbd_pose_expand": [_p, _p, _i, _p],
     "bbd_identity_loss_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
+    "bbd_identity_loss_grouped_fwd": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     "bbd_warp_ssim_min_fwd": [_p] * 12 + [_i] * 6 + [_p],
     "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],
     "bbd_warp_ssim_min_disp_fwd": [_p, _p, _p, _p, _d, _d] + [_p] * 10 + [_i] * 6 + [_p],

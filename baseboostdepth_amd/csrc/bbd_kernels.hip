@@ -580,6 +580,71 @@ __global__ __launch_bounds__(NT) void identity_loss_kernel(FramePtrs frames, con
   if (yy < H) store_strip(ident + (size_t)item * hw + yy * W + xx, xx, W, (xx + PPT <= W) && ((W & 3) == 0), loss);
 }
 
+// Grouped form (the training path): one workgroup per (group, tile) walks the group's items - the identity candidates of
+// ONE target sample (2 for MD2, up to 6 for the boosted recipe).  The target tile, its cell table and its window
+// statistics are set up once per group instead of once per item, and item i + 1's source texels travel (15 coalesced
+// loads per thread, held in registers) while item i's SSIM runs; the staged source is double-buffered, one barrier per item.
+__global__ __launch_bounds__(NT) void identity_loss_grouped_kernel(FramePtrs frames, const float* __restrict__ target,
+                                                                   const int32_t* __restrict__ items,
+                                                                   const int32_t* __restrict__ group_off,
+                                                                   float* __restrict__ ident, int H, int W, int ntiles,
+                                                                   int no_ssim, int remap) {
+  __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
+  __shared__ __attribute__((aligned(16))) float s_x[2][3][FPLANE];
+  const int wid = remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int grp = wid / ntiles;
+  const TileCoord tc = decode_tile(wid - grp * ntiles, W);
+  const int i0 = uniform_load(group_off + grp), i1 = uniform_load(group_off + grp + 1);
+  if (i0 >= i1) return;
+  const int b = uniform_load(items + i0 * 4 + 0);
+  const int hw = H * W;
+  const size_t img = (size_t)3 * hw;
+  typedef Cells<LH, LW, LS, 1> CellsI;
+  CellsI cl;
+  cl.init(H, W, tc.tx0, tc.ty0);
+  float v[CellsI::N][3];
+  auto fetch = [&](int item) {
+    const int slot = uniform_load(items + item * 4 + 1), row = uniform_load(items + item * 4 + 2);
+    const float* src = frames.base[slot] + (size_t)row * img;
+#pragma unroll
+    for (int k = 0; k < CellsI::N; ++k) {
+      const int px = cl.pix(k, W);
+      v[k][0] = src[px];
+      v[k][1] = src[px + hw];
+      v[k][2] = src[px + 2 * hw];
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < CellsI::N; ++k) {
+      s_x[buf][0][cl.lds[k]] = v[k][0];
+      s_x[buf][1][cl.lds[k]] = v[k][1];
+      s_x[buf][2][cl.lds[k]] = v[k][2];
+    }
+  };
+  fetch(i0);
+  stage_image(target + (size_t)b * img, hw, W, cl, s_y);
+  stage(0);
+  __syncthreads();
+  int ly, lx0;
+  strip_of_thread(&ly, &lx0);
+  float mu_y[3][PPT], sg_y[3][PPT];
+  strip_ystats(s_y, ly, lx0, mu_y, sg_y);
+  const int yy = tc.ty0 + ly, xx = tc.tx0 + lx0;
+  const bool vec_ok = (xx + PPT <= W) && ((W & 3) == 0);
+  for (int item = i0; item < i1; ++item) {
+    const int buf = (item - i0) & 1;
+    if (item + 1 < i1) fetch(item + 1);
+    float loss[PPT];
+    strip_loss(s_x[buf], s_y, ly, lx0, mu_y, sg_y, no_ssim, loss);
+    if (yy < H) store_strip(ident + (size_t)item * hw + yy * W + xx, xx, W, vec_ok, loss);
+    if (item + 1 < i1) {
+      stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+}
+
 // torch.min(dim) as an order-free update: smaller wins, on equal values the smaller id, a NaN wins over numbers and
 // among NaNs the smaller id (= "first index", "NaN wins and sticks" of the sequential form bbd_min_update)
 __device__ __forceinline__ void min_update_any_order(float cand, int id, float* best, int* arg) {
@@ -2850,6 +2915,9 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   return launch_status();
 }
 
+int bbd_identity_loss_grouped_fwd(const void* const* frames, const float* target, const int32_t* items,
+                                  const int32_t* group_off, int G, float* ident, int H, int W, int no_ssim, void* stream);
+
 static int fill_disp(const void* const* disp, const int32_t* disp_hw, double min_depth, double max_depth, int S, int H,
                      int W, DispSrc* ds) {
   for (int i = 0; i < MAX_SCALES; ++i) { ds->disp[i] = nullptr; ds->h[i] = H; ds->w[i] = W; }
@@ -2975,6 +3043,19 @@ int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, c
   if (!disp) return BBD_E_BADARG;
   return launch_fused_bwd(frames, target, depth, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
                           grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
+}
+
+int bbd_identity_loss_grouped_fwd(const void* const* frames, const float* target, const int32_t* items,
+                                  const int32_t* group_off, int G, float* ident, int H, int W, int no_ssim, void* stream) {
+  if (!target || !items || !group_off || !ident || G < 0 || H < 3 || W < 3) return BBD_E_BADARG;
+  if (G == 0) return 0;
+  FramePtrs fp;
+  if (fill_frames(frames, &fp)) return BBD_E_BADARG;
+  const int ntiles = bbd_num_tiles(H, W);
+  hipLaunchKernelGGL(identity_loss_grouped_kernel, dim3((unsigned)(G * ntiles)), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), fp, target, items, group_off, ident, H, W, ntiles, no_ssim,
+                     xcd_remap_enabled(0));
+  return launch_status();
 }
 
 int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B,

@@ -83,6 +83,11 @@ class ReprojectionPlan:
                 self.ident_index[(b, f)] = len(self.ident_items)
                 self.ident_items.append((b, frame_slot(f), self.source_row(f, b), 0))
         self.NI = len(self.ident_items)
+        # items are sample-major: group g = the identity candidates of target sample g (bbd_identity_loss_grouped_fwd)
+        self.ident_off = [0]
+        for b in range(self.B):
+            self.ident_off.append(self.ident_off[-1] + sum(1 for it in self.ident_items if it[0] == b))
+        assert all(self.ident_items[i][0] == b for b in range(self.B) for i in range(self.ident_off[b], self.ident_off[b + 1]))
 
         cand = np.zeros((self.B, MAX_CAND, 4), dtype=np.int32)
         ncand = np.zeros(self.B, dtype=np.int32)
@@ -147,6 +152,7 @@ class ReprojectionPlan:
                 cand=torch.from_numpy(self.cand_np).to(device).contiguous(),
                 ncand=torch.from_numpy(self.ncand_np).to(device).contiguous(),
                 items=torch.tensor(self.ident_items, dtype=torch.int32).reshape(-1, 4).to(device).contiguous(),
+                ident_off=torch.tensor(self.ident_off, dtype=torch.int32).to(device).contiguous(),
                 k_rows=torch.from_numpy(self.k_rows).to(device))
         return self._dev[key]
 

@@ -113,6 +113,13 @@ int bbd_pose_expand(const float* pose, float* proj, int NP, void* stream);
 int bbd_identity_loss_fwd(const void* const* frames, const float* target,
                           const int32_t* items, int NI, float* ident,
                           int H, int W, int no_ssim, void* stream);
+/* Grouped form of the same (what the trainer calls): the items of group g are items[group_off[g] .. group_off[g+1]) and
+ * share ONE target sample (items[first].target): the target tile and its window statistics are set up once per group
+ * and tile instead of once per item, the next item's source travels while the current one's SSIM runs.
+ *   group_off  device int32 [G+1]        Same results, bit for bit. */
+int bbd_identity_loss_grouped_fwd(const void* const* frames, const float* target, const int32_t* items,
+                                  const int32_t* group_off, int G, float* ident, int H, int W, int no_ssim,
+                                  void* stream);
 
 /* Fused forward:  back-project -> project -> bilinear border sample -> SSIM+L1 ->
  * per-pixel min/arg-min over the sample's candidate list, for S scales x B samples.

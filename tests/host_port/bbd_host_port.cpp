@@ -82,6 +82,11 @@ int hp_identity_loss_fwd(const void* const* frames, const float* target, const i
   return 0;
 }
 
+int hp_identity_loss_grouped_fwd(const void* const* frames, const float* target, const int32_t* items,
+                                 const int32_t* group_off, int G, float* ident, int H, int W, int no_ssim) {
+  return hp_identity_loss_fwd(frames, target, items, group_off[G], ident, H, W, no_ssim);
+}
+
 int hp_warp_ssim_min_fwd(const void* const* frames, const float* target, const float* depth, const float* proj,
                          const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
                          float* min_loss, uint8_t* argmin, float* partial, float* warped, int S, int B, int NP,

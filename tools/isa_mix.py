@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "baseboostdepth_amd", "csrc", "bbd_kernels.hip")
 KERNELS = {"bbd_warp_ssim_min_fwd": "warp_ssim_min_fwd_kernel", "bbd_warp_ssim_min_bwd": "warp_ssim_min_bwd2_kernel",
-           "bbd_identity_loss_fwd": "identity_loss_kernel"}
+           "bbd_identity_loss_fwd": "identity_loss_grouped_kernel"}
 # vector opcodes of the fp32 pipe (measured kinds: fma / mul / add / cmp / cndmask / dpp / max / min / v_mul_lo at ~4.1
 # cycles, v_rcp 8.2; packed forms included); everything else (integer add / logic / shifts, 64-bit shift-add,
 # conversions, floor) issues at ~2.1 cycles on the second pipe
