@@ -687,8 +687,20 @@ static unsigned long long* g_stamps_host_ptr = nullptr;
   do {                                                                                       \
     if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); \
   } while (0)
+// wall-clock (100 MHz, one counter for the whole chip) forms: where a workgroup starts / ends inside the launch, and a
+// plain value (e.g. how many candidates it processed) - tools/stamps_timeline.py
+#define BBD_STAMP_RT(k)                                                                      \
+  do {                                                                                       \
+    if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define BBD_STAMP_VAL(k, v)                                                                  \
+  do {                                                                                       \
+    if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = (unsigned long long)(v); \
+  } while (0)
 #else
 #define BBD_STAMP(k) do { } while (0)
+#define BBD_STAMP_RT(k) do { } while (0)
+#define BBD_STAMP_VAL(k, v) do { } while (0)
 #endif
 
 struct FwdArgs {
@@ -735,6 +747,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   const TileCoord tc = decode_tile(bid - (a.scale_loop ? 0 : s_first * a.ntiles), W);
   const size_t img = (size_t)3 * hw;
 
+  BBD_STAMP_RT(30);
   BBD_STAMP(0);
   Cells<LH, LW, LS, 1> cl;
   cl.init(H, W, tc.tx0, tc.ty0);
@@ -837,6 +850,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
   }     // scales
   BBD_STAMP(20);
+  BBD_STAMP_RT(31);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1240,6 +1254,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
   const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
 
+  BBD_STAMP_RT(30);
   BBD_STAMP(0);
   // setup: issue every global load first, then the LDS work that does not depend on them
   constexpr int NP_CELLS = (CH * CW2 + NT2 - 1) / NT2;
@@ -1535,6 +1550,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     }
   }
   BBD_STAMP(20);
+  BBD_STAMP_RT(31);
+  BBD_STAMP_VAL(29, __builtin_popcount(present));
 #undef BBD_PARG
 }
 
