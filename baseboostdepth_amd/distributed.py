@@ -84,7 +84,7 @@ class GradientAverager:
         return "AVG" if (self.backend == "nccl" and self.use_avg) else "SUM+div"
 
     def _mark(self):
-        if self.timing and self.flat.flat.is_cuda:
+        if self.timing and self.flat.flat.is_cuda and not torch.cuda.is_current_stream_capturing():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
@@ -157,6 +157,7 @@ class OverlappedGradientAverager(GradientAverager):
             for i in idxs:
                 self.bucket_of[i] = b
         self.streams = []          # HIP streams gradients may be produced on (set by attach())
+        self.paused = False        # True during a graph capture's warm-up steps: hooks do nothing, no collective goes out
         self._reset()
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -168,6 +169,8 @@ class OverlappedGradientAverager(GradientAverager):
 
     def _make_hook(self, i):
         def hook(param):
+            if self.paused:
+                return
             b = self.bucket_of[i]
             self.pending[b] -= 1
             self._launch_ready()
@@ -196,10 +199,11 @@ class OverlappedGradientAverager(GradientAverager):
         """The trainer runs the pose network on a second HIP stream, and autograd replays every backward
         node (and fires this hook) on its forward stream: a bucket may hold gradients produced on the
         other stream, so the stream that packs and hands the bucket to RCCL first waits for both."""
-        if not self.streams:
+        streams = self.streams() if callable(self.streams) else self.streams
+        if not streams:
             return
         cur = torch.cuda.current_stream(self.flat.flat.device)
-        for st in self.streams:
+        for st in streams:
             if st != cur:
                 cur.wait_stream(st)
 
@@ -250,7 +254,8 @@ def init_from_env(backend=None):
 def attach(trainer, group=None):
     """Multi-rank runs get a flat gradient buffer + one all-reduce per step; a single rank keeps
     PyTorch's own per-parameter gradients (nothing to exchange, nothing to pack)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    forced = os.environ.get("BBD_DP_FORCE_ATTACH") == "1"     # test hook: a ONE-rank group still packs and all-reduces
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced)):
         return None
     flat = FlatGradients(getattr(trainer, "optimizer_parameters", None) or trainer.parameters_to_train)
     trainer.flat_grads = flat
@@ -264,12 +269,20 @@ def attach(trainer, group=None):
                     dist.broadcast(b.data, src=0, group=group)
         # a step replayed as hipGraphs cannot launch collectives from autograd hooks: the split-graph step packs inside
         # its forward+backward graph and exchanges the whole buffer between its two graphs
-        overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1" and not getattr(trainer, "use_graph", False)
+        # ... unless the collectives themselves are captured (`dp_capture`: RCCL only - gloo cannot be captured): then the
+        # bucketed all-reduces launched from the autograd hooks become nodes of the ONE step graph and overlap backward
+        # inside the replay
+        capture = bool(getattr(trainer, "dp_capture", False)) and dist.get_backend(group) == "nccl"
+        trainer.dp_capture = capture
+        overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1" and (capture or not getattr(trainer, "use_graph", False))
         bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
         never = trainer.gradient_free_parameters() if hasattr(trainer, "gradient_free_parameters") else ()
         trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket, never=never) if overlap
                              else GradientAverager(flat, group))
         side = trainer._pose_stream() if hasattr(trainer, "_pose_stream") else None
         if overlap and side is not None:
-            trainer.grad_sync.streams = [torch.cuda.default_stream(trainer.device), side]
+            # the stream process_batch ran on (the default stream in the eager loop, the capturing stream while a step
+            # graph is being captured - a capturing stream must not wait on a stream outside the capture) + the pose stream
+            default = torch.cuda.default_stream(trainer.device)
+            trainer.grad_sync.streams = lambda: [getattr(trainer, "_main_stream", None) or default, side]
     return flat

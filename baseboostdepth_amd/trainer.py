@@ -26,6 +26,8 @@ def _frame_sort_key(item):
 
 class Trainer:
     _local_only = False      # True only inside a graph capture's warm-up steps: gradients are not exchanged
+    dp_capture = False       # data parallel under a step graph: RCCL all-reduces captured into the graph (opt-in)
+    _main_stream = None
     max_graphs = 8
 
     def __init__(self, options, backend=None):
@@ -80,6 +82,10 @@ class Trainer:
         self.optimizer_parameters = [p for g in self.model_optimizer.param_groups for p in g["params"]]
         self._graphs = {}
         self.max_graphs = int(os.environ.get("BBD_MAX_GRAPHS", "8"))
+        # data parallel + step graph: capture the bucketed RCCL all-reduces INTO the graph (one graph per step, exchange
+        # overlapped with backward inside the replay) instead of two graphs around one exposed all-reduce.  Opt-in:
+        # multi-rank RCCL capture cannot be exercised on the one-GPU boxes this was built on
+        self.dp_capture = bool(getattr(opt, "dp_capture", False) or os.environ.get("BBD_DP_CAPTURE") == "1")
         self.model_lr_scheduler = optim.lr_scheduler.MultiStepLR(
             self.model_optimizer, milestones=[11, 13, 15, 16, 17, 18, 19], gamma=0.4)
         if getattr(opt, "load_weights_folder", "None") not in (None, "None"):
@@ -173,11 +179,15 @@ class Trainer:
                 # under --rand / the boosted recipe), so a rank that warms up must issue exactly the collectives of a
                 # rank that replays - the ONE exchange after the replay below - or the ranks' all-reduces mis-pair
                 self._local_only = True
+                if hasattr(self.grad_sync, "paused"):
+                    self.grad_sync.paused = True
                 try:
                     for _ in range(3):
                         self._eager_step(dict(static))
                 finally:
                     self._local_only = False
+                    if hasattr(self.grad_sync, "paused"):
+                        self.grad_sync.paused = False
                 with torch.no_grad():
                     for p, v in zip(params, snap_p):
                         p.copy_(v)
@@ -198,6 +208,17 @@ class Trainer:
                 with torch.cuda.graph(graph):
                     outputs, losses = self.process_batch(dict(static))
                     losses["loss"].backward()
+                    self.model_optimizer.step()
+            elif self.dp_capture:
+                # data parallel, collectives captured: ONE graph.  The post-accumulate hooks fire while backward is being
+                # captured, so every bucket's pack + RCCL all-reduce becomes a node on RCCL's stream, forked from and
+                # joined to the capturing stream by the work handles' waits - the replay overlaps the exchange with
+                # the rest of backward like the eager overlapped loop does, with no host in between
+                self.flat_grads.zero()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    outputs, losses = self.process_batch(dict(static))
+                    losses["loss"].backward()
+                    self.grad_sync()
                     self.model_optimizer.step()
             else:
                 # data parallel: the step is split in two graphs around ONE eager exchange of the flat gradient
@@ -376,7 +397,7 @@ class Trainer:
                 # the pose network and the depth network are independent until the warp: run the pose
                 # passes on a second HIP stream so their small-grid layers overlap the depth network's
                 # (autograd replays each backward node on its forward stream, so the backward overlaps too)
-                main = torch.cuda.current_stream(self.device)
+                main = self._main_stream = torch.cuda.current_stream(self.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     outputs = self.predict_poses(inputs)

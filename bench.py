@@ -259,10 +259,12 @@ def main(argv=None):
                          "the bottleneck (measured: 480 vs 575 images/s on two boxes with identical GPU time).  auto = on for "
                          "every run, falling back to the eager loop if capture fails; multi-rank runs replay two graphs "
                          "per step (forward+backward+gradient pack | eager RCCL all-reduce | optimizer)")
-    ap.add_argument("--dp-mode", default="graph", choices=["graph", "overlap"],
+    ap.add_argument("--dp-mode", default="graph", choices=["graph", "overlap", "graph-overlap"],
                     help="multi-rank loop: graph = two hipGraphs around ONE eager all-reduce of the flat gradient buffer (host "
                          "out of the loop, exchange exposed); overlap = eager loop, 32 MB buckets all-reduced from autograd "
-                         "hooks while backward still runs.  Both print `exchange_ms` (exposed wait) so one node can compare them")
+                         "hooks while backward still runs; graph-overlap = ONE hipGraph per step with the bucketed RCCL "
+                         "all-reduces captured into it (host out of the loop AND exchange overlapped; opt-in until it has run on "
+                         "a multi-GPU node).  graph / overlap print `exchange_ms` (exposed wait) so one node can compare them")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -304,6 +306,7 @@ def main(argv=None):
         opt = make_options(args.batch, local, args.config)
         opt.fused_adam = not args.no_fused_adam
         opt.step_graph = bool(step_graph)
+        opt.dp_capture = bool(step_graph) and args.dp_mode == "graph-overlap"
         run_scales = list(opt.scales)
         opt.scales = list(SCALES)      # networks + num_scales are built for 4 scales (trainer.py:44); the epoch>=10
         tr = Trainer(opt)              # curriculum then trains on scale 0 only (run_epoch, trainer.py:209-212)
@@ -454,8 +457,11 @@ def main(argv=None):
                       "training images/sec at 640x192, MonoViT",
             "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/sec",
             "n_gpus": world, "ranks": world, "collective": collective,
-            "dp_mode": ("single" if world == 1 else ("graph" if trainer.use_graph else "overlap")),
-            "exchange_ms": round(exchange_ms, 4), "reduce_op": reduce_op,
+            "dp_mode": ("single" if world == 1 else
+                        (("graph-overlap" if trainer.dp_capture else "graph") if trainer.use_graph else "overlap")),
+            # (captured collectives cannot be bracketed by events: null there)
+            "exchange_ms": None if (trainer.use_graph and trainer.dp_capture and world > 1) else round(exchange_ms, 4),
+            "reduce_op": reduce_op,
             "buckets_launched_in_backward": overlapped,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
@@ -474,7 +480,8 @@ def main(argv=None):
                                   "find": bool(torch.backends.cudnn.benchmark)}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
             "step_graph": (graph_note if graph_note is not None else
-                           ("split: forward+backward+pack graph | eager all-reduce | optimizer graph"
+                           (("one graph per step, bucketed RCCL all-reduces captured inside" if trainer.dp_capture else
+                             "split: forward+backward+pack graph | eager all-reduce | optimizer graph")
                             if (trainer.use_graph and world > 1) else bool(trainer.use_graph))),
         }
         if world == 1 and not args.no_eager_ab and args.config == "md2":

@@ -207,6 +207,21 @@ def test_two_ranks_split_graph_step_matches_eager_data_parallel():
     assert "DDP_GRAPH_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
+def test_rccl_collectives_captured_into_the_step_graph_one_rank():
+    """Data-parallel step as ONE hipGraph with the bucketed all-reduces captured inside (`Trainer.dp_capture`,
+    `bench.py --dp-mode graph-overlap`), over RCCL with the one rank a single GPU allows: the autograd hooks fire under
+    capture, the RCCL nodes replay, parameters equal the eager overlapped loop's (tools/ddp_check.py --capture)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BBD_BUCKET_BYTES="4000000", MASTER_PORT=str(29000 + os.getpid() % 300))
+    env.pop("BBD_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_check.py"), "--capture"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert "DDP_CAPTURE_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
 def test_bench_two_ranks_sharing_this_gpu_print_one_split_graph_line():
     """`python bench.py --gpus 2` end to end (self-launch, rendezvous, split-graph data-parallel loop, max over ranks, ONE
     JSON line from rank 0), with both ranks on this GPU and gloo standing in for RCCL."""
