@@ -5,8 +5,8 @@
 // translation is divided by pose_error (T_error), and - partial mode - a cat + where that swaps in the translation
 // column of a direct 0 -> f pose for some rows.  Here every composed 4x4 of the step is one row of a small integer
 // table (built once per batch signature on the host) and ONE kernel evaluates all of them from the pose network's
-// step matrices; the backward is one kernel too (a thread per step row walks the outputs that reference it, in table
-// order: deterministic, no atomics).
+// step matrices; the backward is one kernel too (a wave per step row: its lanes take the outputs that reference it, a
+// fixed butterfly sums them: deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,16 +88,18 @@ __global__ __launch_bounds__(NT) void pose_compose_fwd_kernel(const float* __res
 }
 
 // refs: for step row r the entries refs[refs_off[r] .. refs_off[r+1]) = (output row, position k in its chain; -1 = it is
-// the output's `direct` pose)
-__global__ __launch_bounds__(NT) void pose_compose_bwd_kernel(const float* __restrict__ steps, const int32_t* __restrict__ table,
-                                                              const int32_t* __restrict__ refs_off, const int32_t* __restrict__ refs,
-                                                              const float* __restrict__ gout, float* __restrict__ gsteps, int R) {
-  const int r = blockIdx.x * NT + threadIdx.x;
-  if (r >= R) return;
+// the output's `direct` pose).  One wave per step row: lane e takes the row's e-th reference (each is two chain products
+// of dependent 4x4 multiplies - latency, not arithmetic), then the 16 sums are reduced over the lanes by a fixed
+// butterfly, so the result does not depend on timing.
+__global__ __launch_bounds__(64) void pose_compose_bwd_kernel(const float* __restrict__ steps, const int32_t* __restrict__ table,
+                                                             const int32_t* __restrict__ refs_off, const int32_t* __restrict__ refs,
+                                                             const float* __restrict__ gout, float* __restrict__ gsteps, int R) {
+  const int r = blockIdx.x, lane = threadIdx.x;
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  for (int e = refs_off[r]; e < refs_off[r + 1]; ++e) {
+  const int e0 = refs_off[r], e1 = refs_off[r + 1];
+  for (int e = e0 + lane; e < e1; e += 64) {
     const int o = refs[2 * e], k = refs[2 * e + 1];
     const int32_t* row = table + (size_t)o * BBD_COMPOSE_STRIDE;
     if (row[9] & BBD_COMPOSE_ERROR) continue;              // detached clone: no gradient (trainer.py:376)
@@ -118,7 +120,18 @@ __global__ __launch_bounds__(NT) void pose_compose_bwd_kernel(const float* __res
     for (int i = 0; i < 16; ++i) acc[i] += d.m[i];
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) gsteps[(size_t)r * 16 + i] = acc[i];
+  for (int i = 0; i < 16; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[i] = v;
+  }
+  if (lane < 16) {
+    float v = acc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) v = (lane == i) ? acc[i] : v;
+    gsteps[(size_t)r * 16 + lane] = v;
+  }
 }
 
 int launch_status() {
@@ -142,7 +155,7 @@ int bbd_pose_compose_bwd(const float* steps, const int32_t* table, const int32_t
                          const float* grad_out, float* grad_steps, int R, void* stream) {
   if (!steps || !table || !refs_off || !refs || !grad_out || !grad_steps || R < 0) return BBD_E_BADARG;
   if (R == 0) return 0;
-  hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((unsigned)((R + NT - 1) / NT)), dim3(NT), 0,
+  hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((unsigned)R), dim3(64), 0,
                      static_cast<hipStream_t>(stream), steps, table, refs_off, refs, grad_out, grad_steps, R);
   return launch_status();
 }

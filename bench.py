@@ -479,6 +479,10 @@ def main(argv=None):
                                               os.environ.get("MIOPEN_USER_DB_PATH")),
                                   "find": bool(torch.backends.cudnn.benchmark)}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
+            # what in `kernels` is measured by THIS run (mean_ms, achieved_GBps, frac) and what is read from committed files
+            "kernels_constants": "pmc_traffic_MB_per_launch and the instruction count behind fp32_issue_floor_ms come from the "
+                                 "committed rocprofv3 PMC pass of this workload (roofline.traffic_source); the fp32 share from "
+                                 "profiles/r03/isa_mix.json; 4.1 cycles per wave-instruction from profiles/r03/valu_rate.txt",
             "step_graph": (graph_note if graph_note is not None else
                            (("one graph per step, bucketed RCCL all-reduces captured inside" if trainer.dp_capture else
                              "split: forward+backward+pack graph | eager all-reduce | optimizer graph")
