@@ -88,6 +88,10 @@ SIGNATURES = {
     "bbd_factor_att_scratch_floats": [_i, _i, _i, _i],
     "bbd_factor_att_fwd": [_p] * 7 + [_i, _i, _i, _i, _d, _p],
     "bbd_factor_att_bwd": [_p] * 10 + [_i, _i, _i, _i, _d, _p],
+    "bbd_token_ln_supported": [_i],
+    "bbd_token_ln_scratch_floats": [_i, _i],
+    "bbd_token_ln_fwd": [_p] * 8 + [_i, _i, _i, _d, _p],
+    "bbd_token_ln_bwd": [_p] * 11 + [_i, _i, _i, _p],
     "bbd_dwconv_tokens_wgrad_scratch_floats": [_i, _i, _i, _i, _i],
     "bbd_dwconv_tokens_wgrad": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
@@ -138,6 +142,12 @@ class HipLibrary:
 
     def dwconv_wgrad_scratch_floats(self, B, H, W, C, k):
         return self._dll.bbd_dwconv_tokens_wgrad_scratch_floats(B, H, W, C, k)
+
+    def token_ln_supported(self, C):
+        return bool(self._dll.bbd_token_ln_supported(C))
+
+    def token_ln_scratch_floats(self, rows, C):
+        return self._dll.bbd_token_ln_scratch_floats(rows, C)
 
     def factor_att_supported(self, C, Ch):
         return bool(self._dll.bbd_factor_att_supported(C, Ch))

@@ -22,7 +22,8 @@ namespace {
 constexpr int NT = 256;
 constexpr int PW = 4;     // output pixels per thread along W
 
-// y[b,h,w,c] = bias[c] + add_in * x[b,h,w,c] + sum_{i,j} wt[c,i,j] * x[b,h+i-p,w+j-p,c]      (zero padding)
+// y[b,h,w,c] = bias[c] + (add_in & 1) * x[b,h,w,c] + sum_{i,j} wt[c,i,j] * x[b,h+i-p,w+j-p,c]      (zero padding)
+// (add_in & 2: added to what y already holds - a data gradient landing in a slice that has another contribution)
 // FLIP reads the taps mirrored: the same kernel is the data gradient (x := dy, no bias).
 template <int K, bool FLIP>
 __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restrict__ x, int x_row,
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restri
     for (int q = 0; q < PW; ++q)
 #pragma unroll
       for (int j = 0; j < K; ++j) acc[q] = fmaf(wk[i * K + j], win[q + j], acc[q]);
-    if (add_in && i == P) {
+    if ((add_in & 1) && i == P) {
 #pragma unroll
       for (int q = 0; q < PW; ++q) acc[q] += win[q + P];
     }
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restri
   float* yo = y + ((long)(b * H + h) * W + w0) * y_row + c;
 #pragma unroll
   for (int q = 0; q < PW; ++q)
-    if (w0 + q < W) yo[(long)q * y_row] = acc[q];
+    if (w0 + q < W) yo[(long)q * y_row] = (add_in & 2) ? yo[(long)q * y_row] + acc[q] : acc[q];     // bit 1: accumulate into y
 }
 
 // Weight / bias gradient.  Stage 1: one thread per (run of `spt` consecutive row segments of WCH pixels, channel)

@@ -55,14 +55,20 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob, self.scale_by_keep = float(drop_prob), scale_by_keep
 
-    def forward(self, x):
+    def scale(self, x):
+        """The per-sample factor of this call ([B]: 0 or 1/keep), or None when the layer is the identity - the same
+        draw `forward` makes, for callers that fold the multiply into their own kernel."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        mask = x.new_empty((x.shape[0],)).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
-        return x * mask
+        return mask
+
+    def forward(self, x):
+        mask = self.scale(x)
+        return x if mask is None else x * mask.view((x.shape[0],) + (1,) * (x.ndim - 1))
 
 
 class Mlp(nn.Module):
@@ -227,8 +233,11 @@ class FactorAtt_ConvRelPosEnc(nn.Module):
         if _hip_tokens(qkv) and ops.factor_attention_supported(C, h):
             # two HIP ops on the packed activation: conv(v) read in place from the v third, then column
             # statistics of k + [Ch x Ch] contexts + the token-parallel output (csrc/bbd_vit.hip)
-            convv = self.crpe.conv_v(qkv[:, :, 2 * C:], size)
-            out = ops.factor_attention(qkv, convv, h, self.scale)
+            if ops.FUSED_TOKEN_GLUE:     # one autograd node: the conv's data gradient lands in gqkv's v third in place
+                out = ops.factor_attention_crpe(qkv, size, list(self.crpe.conv_list), h, self.scale)
+            else:
+                convv = self.crpe.conv_v(qkv[:, :, 2 * C:], size)
+                out = ops.factor_attention(qkv, convv, h, self.scale)
             return self.proj_drop(self.proj(out))
         qkv = qkv.view(B, N, 3, h, C // h)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]             # [B, N, h, Ch] strided views
@@ -254,9 +263,18 @@ class MHCABlock(nn.Module):
         self.norm1 = norm_layer(dim)
         self.norm2 = norm_layer(dim)
 
+    def _drop_scale(self, x):
+        return self.drop_path.scale(x) if isinstance(self.drop_path, DropPath) else None
+
     def forward(self, x, size):
         if self.cpe is not None:
             x = self.cpe(x, size)
+        if _hip_tokens(x) and ops.FUSED_TOKEN_GLUE and ops.token_glue_supported(x):
+            # residual + stochastic depth + the NEXT LayerNorm as one pass each way (csrc/bbd_tokens.hip); the two
+            # stochastic-depth draws happen in the reference's order
+            att = self.factoratt_crpe(ops.layernorm_tokens(x, self.norm1), size)
+            x, z = ops.residual_layernorm(x, att, self._drop_scale(x), self.norm2)
+            return ops.residual_add(x, self.mlp(z), self._drop_scale(x))
         x = x + self.drop_path(self.factoratt_crpe(self.norm1(x), size))
         return x + self.drop_path(self.mlp(self.norm2(x)))
 

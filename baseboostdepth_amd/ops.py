@@ -18,6 +18,7 @@ from .plan import frame_slot
 
 # BBD_FUSED_NN=0 sends the encoder / decoder glue (pad, max-pool) back to the stock ATen kernels (A/B runs)
 FUSED_NN = os.environ.get("BBD_FUSED_NN", "1") != "0"
+FUSED_TOKEN_GLUE = os.environ.get("BBD_FUSED_TOKEN_GLUE", "1") != "0"   # MonoViT: residual + DropPath + LayerNorm passes
 
 
 class KernelTimer:
@@ -707,12 +708,163 @@ class _FactorAttention(torch.autograd.Function):
         return gqkv, gconvv, None, None, None
 
 
+class _FactorAttentionCRPE(torch.autograd.Function):
+    """`_FactorAttention` with the ConvRelPosEnc convolution of v inside the node: v is read in place from the packed qkv
+    activation and - the point - its data gradient is ADDED in place to the v third of the attention's gqkv.  As two
+    nodes autograd materialises the slice's gradient (a zero fill of [B,N,3C], a strided copy) and adds the two
+    [B,N,3C] tensors: three passes over the widest activation of the block, per block."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, H, W, backend, splits, *params):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        Ch = C // heads
+        assert N == H * W and sum(splits) == C
+        qkv = qkv.contiguous()
+        backend._check(qkv, *params)
+        dev = qkv.device
+        convv = torch.empty(B, N, C, device=dev, dtype=torch.float32)
+        c0 = 0
+        for i, n in enumerate(splits):
+            w, b = params[2 * i].contiguous(), params[2 * i + 1]
+            backend.run("bbd_dwconv_tokens_fwd", qkv, _slice_ptr(qkv, 2 * C + c0), C3, ptr(w), ptr(b), _slice_ptr(convv, c0), C,
+                        B, H, W, n, w.shape[-1], 0, 0)
+            c0 += n
+        kmax = torch.empty(B, C, device=dev, dtype=torch.float32)
+        krsum = torch.empty(B, C, device=dev, dtype=torch.float32)
+        ctxs = torch.empty(B, C * Ch, device=dev, dtype=torch.float32)
+        scratch = torch.empty(backend.lib.factor_att_scratch_floats(B, N, C, Ch), device=dev, dtype=torch.float32)
+        out = torch.empty(B, N, C, device=dev, dtype=torch.float32)
+        backend.run("bbd_factor_att_fwd", qkv, ptr(qkv), ptr(convv), ptr(kmax), ptr(krsum), ptr(ctxs), ptr(scratch),
+                    ptr(out), B, N, C, Ch, float(scale))
+        ctx.save_for_backward(qkv, convv, kmax, krsum, ctxs, *params)
+        ctx.meta = (heads, float(scale), H, W, backend, tuple(splits))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, convv, kmax, krsum, ctxs = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        heads, scale, H, W, backend, splits = ctx.meta
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        Ch = C // heads
+        gout = gout.contiguous()
+        dev = qkv.device
+        dctx = torch.empty_like(ctxs)
+        scratch = torch.empty(backend.lib.factor_att_scratch_floats(B, N, C, Ch), device=dev, dtype=torch.float32)
+        gqkv = torch.empty_like(qkv)
+        gconvv = torch.empty_like(convv)
+        backend.run("bbd_factor_att_bwd", qkv, ptr(qkv), ptr(convv), ptr(kmax), ptr(krsum), ptr(ctxs), ptr(gout),
+                    ptr(dctx), ptr(scratch), ptr(gqkv), ptr(gconvv), B, N, C, Ch, scale)
+        grads, c0 = [], 0
+        for i, n in enumerate(splits):
+            w, b = params[2 * i].contiguous(), params[2 * i + 1]
+            k = w.shape[-1]
+            backend.run("bbd_dwconv_tokens_fwd", gconvv, _slice_ptr(gconvv, c0), C, ptr(w), ptr(None), _slice_ptr(gqkv, 2 * C + c0),
+                        C3, B, H, W, n, k, 2, 1)                    # accumulate into the v third
+            gw = torch.empty_like(w)
+            gb = torch.empty_like(b) if b is not None else None
+            wscratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, n, k), device=dev, dtype=torch.float32)
+            backend.run("bbd_dwconv_tokens_wgrad", qkv, _slice_ptr(qkv, 2 * C + c0), C3, _slice_ptr(gconvv, c0), C, ptr(wscratch),
+                        ptr(gw), ptr(gb), B, H, W, n, k)
+            grads += [gw, gb]
+            c0 += n
+        return (gqkv, None, None, None, None, None, None) + tuple(grads)
+
+
+def factor_attention_crpe(qkv, size, convs, heads, scale, backend=None):
+    """Factorised attention with MPViT's ConvRelPosEnc of v computed inside (`convs`: its depth-wise nn.Conv2d list)."""
+    params, splits = [], []
+    for conv in convs:
+        params += [conv.weight, conv.bias]
+        splits.append(conv.weight.shape[0])
+    return _FactorAttentionCRPE.apply(qkv, heads, scale, size[0], size[1], backend or default_backend(), tuple(splits), *params)
+
+
 def factor_attention(qkv, convv, heads, scale, backend=None):
     return _FactorAttention.apply(qkv, convv, heads, scale, backend or default_backend())
 
 
 def factor_attention_supported(C, heads, backend=None):
     return (backend or default_backend()).lib.factor_att_supported(C, C // heads)
+
+
+class _ResidualLayerNorm(torch.autograd.Function):
+    """y = x + branch * mask[b];  z = LayerNorm(y)  on [B, N, C] tokens in one pass each way (csrc/bbd_tokens.hip).
+    `branch is None`: plain LayerNorm of x (returns z only).  `mask`: [B] stochastic-depth scale (0 or 1/keep) or None."""
+
+    @staticmethod
+    def forward(ctx, x, branch, mask, weight, bias, eps, backend):
+        B, N, C = x.shape
+        x = x.contiguous()
+        backend._check(x, branch, mask, weight, bias)
+        if branch is not None:
+            branch = branch.contiguous()
+        y = torch.empty_like(x) if branch is not None else x
+        z = torch.empty_like(x)
+        stats = torch.empty(B * N, 2, device=x.device, dtype=torch.float32)
+        backend.run("bbd_token_ln_fwd", x, ptr(x), ptr(branch), ptr(mask), ptr(weight), ptr(bias),
+                    ptr(y) if branch is not None else ptr(None), ptr(z), ptr(stats), B * N, N, C, float(eps))
+        ctx.save_for_backward(y, stats, weight, mask)
+        ctx.meta = (backend, branch is not None)
+        return (y, z) if branch is not None else z
+
+    @staticmethod
+    def backward(ctx, *grads):
+        y, stats, weight, mask = ctx.saved_tensors
+        backend, has_branch = ctx.meta
+        gy, gz = (grads if has_branch else (None, grads[0]))
+        B, N, C = y.shape
+        if gz is None:                     # z unused downstream: only the residual carries gradient
+            gz = torch.zeros_like(y)
+        gz = gz.contiguous()
+        gy = gy.contiguous() if gy is not None else None
+        gx = torch.empty_like(y)
+        gbranch = torch.empty_like(y) if has_branch else None
+        gw, gb = torch.empty_like(weight), torch.empty_like(weight)
+        scratch = torch.empty(backend.lib.token_ln_scratch_floats(B * N, C), device=y.device, dtype=torch.float32)
+        backend.run("bbd_token_ln_bwd", gz, ptr(gz), ptr(gy), ptr(y), ptr(stats), ptr(weight), ptr(mask), ptr(gx), ptr(gbranch),
+                    ptr(scratch), ptr(gw), ptr(gb), B * N, N, C)
+        return gx, gbranch, None, gw, gb, None, None
+
+
+class _ResidualAdd(torch.autograd.Function):
+    """y = x + branch * mask[b] (one launch instead of a broadcast multiply and an add)."""
+
+    @staticmethod
+    def forward(ctx, x, branch, mask, backend):
+        B, N, C = x.shape
+        x, branch = x.contiguous(), branch.contiguous()
+        backend._check(x, branch, mask)
+        y = torch.empty_like(x)
+        backend.run("bbd_token_ln_fwd", x, ptr(x), ptr(branch), ptr(mask), ptr(None), ptr(None), ptr(y), ptr(None), ptr(None),
+                    B * N, N, C, 0.0)
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (mask,) = ctx.saved_tensors
+        return gy, (gy if mask is None else gy * mask.view(-1, 1, 1)), None, None
+
+
+def token_glue_supported(x, backend=None):
+    return x.dim() == 3 and (backend or default_backend()).lib.token_ln_supported(x.shape[-1])
+
+
+def layernorm_tokens(x, norm, backend=None):
+    """nn.LayerNorm `norm` over the channel axis of [B, N, C] tokens."""
+    return _ResidualLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, backend or default_backend())
+
+
+def residual_layernorm(x, branch, mask, norm, backend=None):
+    """(x + branch * mask[b], norm(of that)) - `mask` [B] or None."""
+    return _ResidualLayerNorm.apply(x, branch, mask, norm.weight, norm.bias, norm.eps, backend or default_backend())
+
+
+def residual_add(x, branch, mask, backend=None):
+    return _ResidualAdd.apply(x, branch, mask, backend or default_backend())
 
 
 # ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)

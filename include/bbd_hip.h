@@ -383,8 +383,9 @@ int bbd_bias_elu_bwd(const float* y, const float* grad_y, float* grad_x, float* 
  * rows: `*_row` is the number of floats between consecutive tokens and the pointer addresses the slice's
  * first channel, C is the number of channels of the slice.  weight [C,k,k] (nn.Conv2d's [C,1,k,k]), bias [C]
  * or NULL.
- *   fwd   : y = bias + conv(x) (+ x when add_input).  flip = 1 mirrors the taps: with x := grad_y, bias NULL
- *           this is the data gradient (add_input carries the residual's gradient).
+ *   fwd   : y = bias + conv(x) (+ x when add_input & 1; added to y's previous contents when add_input & 2).
+ *           flip = 1 mirrors the taps: with x := grad_y, bias NULL this is the data gradient (bit 0 carries the
+ *           residual's gradient, bit 1 lets it land in a slice that already holds another contribution).
  *   wgrad : grad_weight [C,k,k], grad_bias [C] (or NULL); partial = scratch of
  *           bbd_dwconv_tokens_wgrad_scratch_floats(B,H,W,C,k) floats.  Deterministic (per-segment partial
  *           sums, two fixed-order column-sum passes, the last in fp64).                                  */
@@ -393,6 +394,23 @@ int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const 
                           int B, int H, int W, int C, int k, int add_input, int flip, void* stream);
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
                             float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, void* stream);
+
+/* Residual + stochastic depth + LayerNorm on token-layout activations [rows = B*N, C] (csrc/bbd_tokens.hip), the glue of
+ * the reference's MHCABlock (networksvit/mpvit.py:397-440: x = x + drop_path(branch); z = norm(x)) as one pass each way.
+ *   fwd: y = x + branch * mask[row / N];  z = LayerNorm(y) * weight + bias;  stats[row] = (mean, rstd).
+ *        branch == NULL: plain LayerNorm of x (y is not written);  mask == NULL: no stochastic depth;
+ *        weight == NULL: residual only (z, stats, bias unused).
+ *   bwd: g = grad_y + dLayerNorm(grad_z);  grad_x = g;  grad_branch = g * mask[row / N] (NULL: not wanted);
+ *        grad_weight / grad_bias through `partial` (bbd_token_ln_scratch_floats(rows, C) floats): one partial row per
+ *        workgroup, summed in a fixed order by a second launch (deterministic).  grad_y may be NULL.
+ *   C % 4 == 0 and C <= 1024 (bbd_token_ln_supported).                                                             */
+int bbd_token_ln_supported(int C);
+long bbd_token_ln_scratch_floats(int rows, int C);
+int bbd_token_ln_fwd(const float* x, const float* branch, const float* mask, const float* weight, const float* bias,
+                     float* y, float* z, float* stats, int rows, int N, int C, double eps, void* stream);
+int bbd_token_ln_bwd(const float* grad_z, const float* grad_y, const float* y, const float* stats, const float* weight,
+                     const float* mask, float* grad_x, float* grad_branch, float* partial, float* grad_weight,
+                     float* grad_bias, int rows, int N, int C, void* stream);
 
 /* Factorised attention of MPViT (networksvit/mpvit.py:333-394) on the packed qkv activation.
  *   qkv [B, N, 3, h, Ch] = the qkv Linear's output (C = h*Ch); convv [B,N,C] = ConvRelPosEnc's conv(v)

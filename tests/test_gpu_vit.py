@@ -148,3 +148,86 @@ def test_factorised_attention_matches_torch(B, H, W, C, heads):
         a, b = got[1][:, :, t * C:(t + 1) * C], want[1][:, :, t * C:(t + 1) * C]
         err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
         assert err < 1e-4, (name, err)
+
+
+@pytest.mark.parametrize("B,N,C,branch,drop", [(3, 37, 64, True, True), (2, 130, 128, True, False), (2, 61, 216, True, True),
+                                               (5, 9, 288, True, True), (1, 7, 512, True, False), (3, 50, 64, False, False),
+                                               (2, 33, 216, False, False)])
+def test_residual_droppath_layernorm_matches_torch(B, N, C, branch, drop):
+    """csrc/bbd_tokens.hip against the eager formulation of reference networksvit/mpvit.py:397-440
+    (x + drop_path(branch), LayerNorm): both outputs and all five gradients, 2e-5 of each tensor's maximum."""
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N + C)
+    dev = "cuda:0"
+    x = (torch.randn(B, N, C, generator=g) * 2 + 0.3).to(dev).requires_grad_(True)
+    br = torch.randn(B, N, C, generator=g).to(dev).requires_grad_(True) if branch else None
+    mask = None
+    if drop:
+        mask = (torch.rand(B, generator=g) < 0.6).float().div(0.6).to(dev)
+        mask[0] = 0.0
+    norm = torch.nn.LayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    wy, wz = torch.randn(B, N, C, generator=g).to(dev), torch.randn(B, N, C, generator=g).to(dev)
+
+    def reference():
+        y = x if br is None else x + br * (mask.view(B, 1, 1) if mask is not None else 1.0)
+        z = norm(y)
+        return y, z
+
+    def fused():
+        if br is None:
+            return x, ops.layernorm_tokens(x, norm)
+        return ops.residual_layernorm(x, br, mask, norm)
+
+    results = []
+    for fn in (reference, fused):
+        for t in (x, br, norm.weight, norm.bias):
+            if t is not None:
+                t.grad = None
+        y, z = fn()
+        ((y * wy).sum() + (z * wz).sum()).backward()
+        results.append([y.detach().clone(), z.detach().clone(), x.grad.clone(), br.grad.clone() if br is not None else None,
+                        norm.weight.grad.clone(), norm.bias.grad.clone()])
+    names = ["y", "z", "grad x", "grad branch", "grad weight", "grad bias"]
+    for name, want, got in zip(names, *results):
+        if want is None:
+            continue
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * float(want.abs().max()) + 1e-7, (name, err, float(want.abs().max()))
+    if br is not None:          # residual only (the MLP branch's add): y and its two gradients
+        x.grad = br.grad = None
+        y = ops.residual_add(x, br, mask)
+        (y * wy).sum().backward()
+        want = x.detach() + br.detach() * (mask.view(B, 1, 1) if mask is not None else 1.0)
+        assert float((y - want).abs().max()) <= 1e-6 * float(want.abs().max())
+        assert torch.equal(x.grad, wy)
+        assert torch.allclose(br.grad, wy * (mask.view(B, 1, 1) if mask is not None else 1.0), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,windows", [(2, 6, 10, 64, 8, {3: 2, 5: 3, 7: 3}), (1, 5, 7, 216, 8, {3: 2, 5: 3, 7: 3}),
+                                                  (2, 4, 9, 128, 8, {3: 8})])
+def test_attention_with_position_encoding_inside_equals_the_two_node_form(B, H, W, C, heads, windows):
+    """`factor_attention_crpe` (ConvRelPosEnc of v inside the attention's autograd node, its data gradient added in place to
+    gqkv's v third) against conv_v + factor_attention as two nodes: same output, same gqkv, same conv gradients."""
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.networksvit.mpvit import ConvRelPosEnc
+    N, Ch = H * W, C // heads
+    g = torch.Generator().manual_seed(C + N)
+    crpe = ConvRelPosEnc(Ch, heads, windows).to(DEV)
+    qkv = (1.5 * torch.randn(B, N, 3 * C, generator=g)).to(DEV).requires_grad_(True)
+    w = torch.randn(B, N, C, generator=g).to(DEV)
+    res = []
+    for fused in (False, True):
+        qkv.grad = None
+        for p in crpe.parameters():
+            p.grad = None
+        if fused:
+            out = ops.factor_attention_crpe(qkv, (H, W), list(crpe.conv_list), heads, Ch ** -0.5)
+        else:
+            out = ops.factor_attention(qkv, crpe.conv_v(qkv[:, :, 2 * C:], (H, W)), heads, Ch ** -0.5)
+        (out * w).sum().backward()
+        res.append([out.detach().clone(), qkv.grad.clone()] + [p.grad.clone() for p in crpe.parameters()])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, i

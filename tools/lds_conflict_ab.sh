@@ -41,7 +41,7 @@ for d in /tmp/bbdvar/src_*; do
   name=${d##*/src_}
   lib=/tmp/bbdvar/libbbd_lds_$name.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -std=c++17 -fPIC -shared -I $PWD/include -I $PWD/$CS -o $lib \
-      $d/bbd_kernels.hip $CS/bbd_eval.hip $CS/bbd_image.hip $CS/bbd_nn.hip $CS/bbd_vit.hip $CS/bbd_pose.hip 2>&1 | grep -E "error"
+      $d/bbd_kernels.hip $CS/bbd_eval.hip $CS/bbd_image.hip $CS/bbd_nn.hip $CS/bbd_vit.hip $CS/bbd_pose.hip $CS/bbd_tokens.hip 2>&1 | grep -E "error"
   [ -f $lib ] || { echo "build of $name failed"; continue; }
   BBD_HIP_LIB=$lib rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES \
       --kernel-trace --output-format csv -d "$OUT" -o $name -- python3 tools/kernel_bench.py --iters 3 --warmup 1 > "$OUT/$name.log" 2>&1

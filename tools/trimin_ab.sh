@@ -1,5 +1,5 @@
 set -u
-SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hip baseboostdepth_amd/csrc/bbd_image.hip baseboostdepth_amd/csrc/bbd_nn.hip baseboostdepth_amd/csrc/bbd_vit.hip baseboostdepth_amd/csrc/bbd_pose.hip"
+SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hip baseboostdepth_amd/csrc/bbd_image.hip baseboostdepth_amd/csrc/bbd_nn.hip baseboostdepth_amd/csrc/bbd_vit.hip baseboostdepth_amd/csrc/bbd_pose.hip baseboostdepth_amd/csrc/bbd_tokens.hip"
 mkdir -p /tmp/bbdvar
 for spec in "default:" "w3:-DBBD_BWD2_WGS=3" "guarded:-DBBD_BWD_GUARDED" "w3guarded:-DBBD_BWD2_WGS=3 -DBBD_BWD_GUARDED"; do
   name="${spec%%:*}"; flags="${spec#*:}"

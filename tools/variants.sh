@@ -3,7 +3,7 @@
 # time each with tools/kernel_bench.py.   usage: tools/variants.sh "name:-DFLAG ..." ...
 set -u
 cd "$(dirname "$0")/.."
-SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hip baseboostdepth_amd/csrc/bbd_image.hip baseboostdepth_amd/csrc/bbd_nn.hip baseboostdepth_amd/csrc/bbd_vit.hip baseboostdepth_amd/csrc/bbd_pose.hip"
+SRC="baseboostdepth_amd/csrc/bbd_kernels.hip baseboostdepth_amd/csrc/bbd_eval.hip baseboostdepth_amd/csrc/bbd_image.hip baseboostdepth_amd/csrc/bbd_nn.hip baseboostdepth_amd/csrc/bbd_vit.hip baseboostdepth_amd/csrc/bbd_pose.hip baseboostdepth_amd/csrc/bbd_tokens.hip"
 mkdir -p /tmp/bbdvar
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
