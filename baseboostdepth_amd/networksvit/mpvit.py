@@ -47,6 +47,45 @@ def _he_fan_out(conv, per_group=False):
         conv.bias.data.zero_()
 
 
+class _DropPathBank:
+    """All stochastic-depth draws of one encoder forward from ONE uniform draw (GPU training only).  The encoder makes 76
+    draws of [B] per forward (two per block); as separate `bernoulli_` + `div_` calls that is ~150 tiny launches.  The
+    first GPU forward records the sequence of rates while drawing per call; later forwards draw a [draws, B] matrix up
+    front and hand out its rows in call order.  Same distribution per draw; CPU runs keep the per-call draws (whose
+    order on the CPU generator is what the reference fixtures pin)."""
+
+    def __init__(self):
+        self.rates, self.keep, self.masks, self.at, self.recording = None, None, None, 0, None
+
+    def begin(self, x):
+        self.masks, self.at, self.recording = None, 0, None
+        if not (x.is_cuda and ops.FUSED_TOKEN_GLUE):
+            return
+        if self.rates is None:
+            self.recording = []
+            return
+        if self.keep is None or self.keep.device != x.device:
+            self.keep = torch.tensor([1.0 - r for r in self.rates], device=x.device).view(-1, 1)
+        u = torch.rand(len(self.rates), x.shape[0], device=x.device)
+        self.masks = (u < self.keep).float() / self.keep
+
+    def end(self):
+        if self.recording is not None:
+            self.rates, self.recording = list(self.recording), None
+        self.masks = None
+
+    def draw(self, rate, batch):
+        """Row of the pre-drawn matrix for this call, or None (caller draws itself)."""
+        if self.recording is not None:
+            self.recording.append(rate)
+            return None
+        if self.masks is None or self.at >= len(self.rates) or self.rates[self.at] != rate or self.masks.shape[1] != batch:
+            self.masks = None          # call pattern changed (a sub-module run on its own): per-call draws from here on
+            return None
+        self.at += 1
+        return self.masks[self.at - 1]
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm 0.6.12 `DropPath`): a Bernoulli(keep) mask over the batch
     dimension, divided by keep; identity in eval mode."""
@@ -54,6 +93,7 @@ class DropPath(nn.Module):
     def __init__(self, drop_prob=0.0, scale_by_keep=True):
         super().__init__()
         self.drop_prob, self.scale_by_keep = float(drop_prob), scale_by_keep
+        self.bank = None           # set by MPViT: pre-drawn masks on the GPU
 
     def scale(self, x):
         """The per-sample factor of this call ([B]: 0 or 1/keep), or None when the layer is the identity - the same
@@ -61,6 +101,10 @@ class DropPath(nn.Module):
         if self.drop_prob == 0.0 or not self.training:
             return None
         keep = 1.0 - self.drop_prob
+        if self.bank is not None and keep > 0.0 and self.scale_by_keep:
+            mask = self.bank.draw(self.drop_prob, x.shape[0])
+            if mask is not None:
+                return mask
         mask = x.new_empty((x.shape[0],)).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
@@ -272,7 +316,8 @@ class MHCABlock(nn.Module):
         if _hip_tokens(x) and ops.FUSED_TOKEN_GLUE and ops.token_glue_supported(x):
             # residual + stochastic depth + the NEXT LayerNorm as one pass each way (csrc/bbd_tokens.hip); the two
             # stochastic-depth draws happen in the reference's order
-            att = self.factoratt_crpe(ops.layernorm_tokens(x, self.norm1), size)
+            x, z = ops.layernorm_tokens(x, self.norm1, passthrough=True)     # x comes back as an output of the node: the
+            att = self.factoratt_crpe(z, size)                                # residual's gradient meets LayerNorm's inside
             x, z = ops.residual_layernorm(x, att, self._drop_scale(x), self.norm2)
             return ops.residual_add(x, self.mlp(z), self._drop_scale(x))
         x = x + self.drop_path(self.factoratt_crpe(self.norm1(x), size))
@@ -371,6 +416,10 @@ class MPViT(nn.Module):
                        num_heads[i], mlp_ratios[i], num_path[i], norm_cfg=norm_cfg, drop_path_list=dpr[i])
             for i in range(num_stages)])
         self.num_ch_enc = [embed_dims[0]] + [embed_dims[min(i + 1, num_stages - 1)] for i in range(num_stages)]
+        self._drop_bank = _DropPathBank()
+        for m in self.modules():
+            if isinstance(m, DropPath):
+                m.bank = self._drop_bank
         if pretrained is not None:
             self.init_weights(pretrained)
 
@@ -391,11 +440,15 @@ class MPViT(nn.Module):
             raise TypeError("pretrained must be a str or None")
 
     def forward_features(self, x):
+        if self.training:
+            self._drop_bank.begin(x)
         x = self.stem(x)
         outs = [x]
         for embed, stage in zip(self.patch_embed_stages, self.mhca_stages):
             x, _ = stage(embed(x))
             outs.append(x)
+        if self.training:
+            self._drop_bank.end()
         return outs
 
     def forward(self, x):

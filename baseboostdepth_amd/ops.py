@@ -795,7 +795,7 @@ class _ResidualLayerNorm(torch.autograd.Function):
     `branch is None`: plain LayerNorm of x (returns z only).  `mask`: [B] stochastic-depth scale (0 or 1/keep) or None."""
 
     @staticmethod
-    def forward(ctx, x, branch, mask, weight, bias, eps, backend):
+    def forward(ctx, x, branch, mask, weight, bias, eps, backend, passthrough=False):
         B, N, C = x.shape
         x = x.contiguous()
         backend._check(x, branch, mask, weight, bias)
@@ -807,14 +807,18 @@ class _ResidualLayerNorm(torch.autograd.Function):
         backend.run("bbd_token_ln_fwd", x, ptr(x), ptr(branch), ptr(mask), ptr(weight), ptr(bias),
                     ptr(y) if branch is not None else ptr(None), ptr(z), ptr(stats), B * N, N, C, float(eps))
         ctx.save_for_backward(y, stats, weight, mask)
-        ctx.meta = (backend, branch is not None)
-        return (y, z) if branch is not None else z
+        ctx.meta = (backend, branch is not None, bool(passthrough))
+        if branch is not None:
+            return y, z
+        # `passthrough`: x is handed back as an OUTPUT of this node (a view), so a caller that goes on using it (the
+        # residual) sends that gradient here and the kernel adds it to LayerNorm's - no separate add
+        return (x.view_as(x), z) if passthrough else z
 
     @staticmethod
     def backward(ctx, *grads):
         y, stats, weight, mask = ctx.saved_tensors
-        backend, has_branch = ctx.meta
-        gy, gz = (grads if has_branch else (None, grads[0]))
+        backend, has_branch, passthrough = ctx.meta
+        gy, gz = (grads if (has_branch or passthrough) else (None, grads[0]))
         B, N, C = y.shape
         if gz is None:                     # z unused downstream: only the residual carries gradient
             gz = torch.zeros_like(y)
@@ -826,7 +830,7 @@ class _ResidualLayerNorm(torch.autograd.Function):
         scratch = torch.empty(backend.lib.token_ln_scratch_floats(B * N, C), device=y.device, dtype=torch.float32)
         backend.run("bbd_token_ln_bwd", gz, ptr(gz), ptr(gy), ptr(y), ptr(stats), ptr(weight), ptr(mask), ptr(gx), ptr(gbranch),
                     ptr(scratch), ptr(gw), ptr(gb), B * N, N, C)
-        return gx, gbranch, None, gw, gb, None, None
+        return gx, gbranch, None, gw, gb, None, None, None
 
 
 class _ResidualAdd(torch.autograd.Function):
@@ -853,9 +857,10 @@ def token_glue_supported(x, backend=None):
     return x.dim() == 3 and (backend or default_backend()).lib.token_ln_supported(x.shape[-1])
 
 
-def layernorm_tokens(x, norm, backend=None):
-    """nn.LayerNorm `norm` over the channel axis of [B, N, C] tokens."""
-    return _ResidualLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, backend or default_backend())
+def layernorm_tokens(x, norm, backend=None, passthrough=False):
+    """nn.LayerNorm `norm` over the channel axis of [B, N, C] tokens; `passthrough`: returns (x, norm(x)) with x routed
+    through the node (see _ResidualLayerNorm.forward)."""
+    return _ResidualLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, backend or default_backend(), passthrough)
 
 
 def residual_layernorm(x, branch, mask, norm, backend=None):

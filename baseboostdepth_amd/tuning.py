@@ -66,3 +66,43 @@ def use_shipped_db():
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(db, "cache"))
     return db
+
+
+# ------------------------------------------------------------------------------------------------ GEMM solutions
+GEMM_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_db", "tunableop_gfx950.csv")
+
+
+def use_shipped_gemm_db():
+    """Point PyTorch's TunableOp at the in-tree table of measured-fastest hipBLASLt / rocBLAS solutions for the token
+    GEMMs of MonoViT (BASELINE configs[4]: qkv / proj / MLP Linear layers forward, data and weight gradients; recorded
+    on an MI355X by `tools/gemm_tune.sh`).  hipBLASLt's own heuristic picks poorly for these tall-skinny fp32 shapes
+    ([92 160 x 64] x [64 x 256] ...): the MonoViT step runs 161.8 -> 180.2 images/s with the table
+    (profiles/r03/bench_vit_gemm_db_ab.txt).  Tuning stays OFF at run time: a known shape takes its recorded solution, an
+    unknown one the library default - nothing is measured or written during training, so the step graph capture is
+    unaffected.  The table is validated by TunableOp against the PyTorch / HIP / hipBLASLt / rocBLAS versions and the GPU
+    architecture in its header and ignored if they differ.  Explicit call (Trainer.__init__, bench.py), a private copy
+    like the MIOpen database; BBD_GEMM_DB=0 or a caller's own PYTORCH_TUNABLEOP_ENABLED wins.  Returns the file in use."""
+    if os.environ.get("BBD_GEMM_DB", "1") == "0" or not os.path.isfile(GEMM_DB):
+        return None
+    if "PYTORCH_TUNABLEOP_ENABLED" in os.environ:
+        return os.environ.get("PYTORCH_TUNABLEOP_FILENAME")
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    import torch.cuda.tunable as tunable
+    st = os.stat(GEMM_DB)
+    tag = hashlib.sha256(("%d:%d" % (st.st_size, int(st.st_mtime))).encode()).hexdigest()[:12]
+    dst = os.path.join(_cache_root(), "gemm_db_%s.csv" % tag)
+    if not os.path.isfile(dst):
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        fd, tmp = tempfile.mkstemp(prefix="gemm_db_", dir=os.path.dirname(dst))
+        os.close(fd)
+        shutil.copyfile(GEMM_DB, tmp)
+        try:
+            os.rename(tmp, dst)
+        except OSError:
+            os.unlink(tmp)
+    tunable.set_filename(dst, insert_device_ordinal=False)
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    return dst

@@ -298,6 +298,7 @@ def main(argv=None):
     from baseboostdepth_amd.synthetic import synthetic_batch
 
     tuning.use_shipped_db()            # explicit (the Trainer would do it too): before the first convolution
+    gemm_db = tuning.use_shipped_gemm_db()
     torch.manual_seed(42)
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
@@ -477,7 +478,11 @@ def main(argv=None):
                        "miopen": {"user_db": ("shipped (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh)"
                                               if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "")).startswith("miopen_db") else
                                               os.environ.get("MIOPEN_USER_DB_PATH")),
-                                  "find": bool(torch.backends.cudnn.benchmark)}},
+                                  "find": bool(torch.backends.cudnn.benchmark)},
+                       "gemm": {"tunableop_table": ("shipped (baseboostdepth_amd/gemm_db, tools/gemm_tune.sh)"
+                                                    if (gemm_db and "gemm_db_" in os.path.basename(gemm_db)) else gemm_db),
+                                "tuning_at_run_time": bool(torch.cuda.tunable.tuning_is_enabled()
+                                                           and torch.cuda.tunable.is_enabled())}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
             # what in `kernels` is measured by THIS run (mean_ms, achieved_GBps, frac) and what is read from committed files
             "kernels_constants": "pmc_traffic_MB_per_launch and the instruction count behind fp32_issue_floor_ms come from the "

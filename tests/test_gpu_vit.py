@@ -177,8 +177,8 @@ def test_residual_droppath_layernorm_matches_torch(B, N, C, branch, drop):
         return y, z
 
     def fused():
-        if br is None:
-            return x, ops.layernorm_tokens(x, norm)
+        if br is None:           # C == 216: x routed through the node, so both of its gradients meet inside the kernel
+            return ops.layernorm_tokens(x, norm, passthrough=True) if C == 216 else (x, ops.layernorm_tokens(x, norm))
         return ops.residual_layernorm(x, br, mask, norm)
 
     results = []
@@ -231,3 +231,21 @@ def test_attention_with_position_encoding_inside_equals_the_two_node_form(B, H, 
         res.append([out.detach().clone(), qkv.grad.clone()] + [p.grad.clone() for p in crpe.parameters()])
     for i, (a, b) in enumerate(zip(*res)):
         assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, i
+
+
+def test_shipped_gemm_table_drives_tunableop_without_tuning():
+    """`tuning.use_shipped_gemm_db()`: TunableOp on, tuning off, the in-tree table loaded (private copy); a recorded
+    shape (stage-4 qkv Linear of mpvit_small at batch 12) computes the same Linear as the library default."""
+    import torch.cuda.tunable as tunable
+    from baseboostdepth_amd import tuning
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1440, 288, generator=g).to(DEV)
+    lin = torch.nn.Linear(288, 864).to(DEV)
+    tunable.enable(False)
+    want = lin(x)
+    path = tuning.use_shipped_gemm_db()
+    assert path and "gemm_db_" in path and tunable.is_enabled() and not tunable.tuning_is_enabled()
+    got = lin(x)
+    torch.cuda.synchronize()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert tunable.get_filename() == path

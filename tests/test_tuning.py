@@ -43,3 +43,23 @@ def test_database_holds_forward_backward_and_weight_gradient_records_for_md2_sha
     for direction in ("F", "B", "W"):
         assert "64-48-160-3x3-64-48-160-12-1x1-1x1-1x1-0-NCHW-FP32-%s=" % direction in text, direction
     assert "-7x7-64-96-320-12-3x3-2x2-1x1-0-NCHW-FP32-F=" in text
+
+
+def test_gemm_table_is_shipped_and_wired_only_on_explicit_call():
+    """The TunableOp table of the MonoViT token GEMMs: committed text with its validator header; importing the package
+    leaves TunableOp alone, and on a machine without a GPU the explicit call is a no-op."""
+    import os
+    import subprocess
+    import sys
+    from baseboostdepth_amd import tuning
+    assert os.path.isfile(tuning.GEMM_DB)
+    lines = open(tuning.GEMM_DB).read().splitlines()
+    assert any(l.startswith("Validator,GCN_ARCH_NAME,gfx950") for l in lines)
+    assert sum(l.startswith("Gemm") for l in lines) >= 60
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTORCH_TUNABLEOP")}
+    out = subprocess.run([sys.executable, "-c",
+                          "import os, torch, baseboostdepth_amd; print(int(any(k.startswith('PYTORCH_TUNABLEOP') for k in os.environ))); "
+                          "from baseboostdepth_amd import tuning; print(tuning.use_shipped_gemm_db() if not torch.cuda.is_available() else 'gpu')"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split()[:2] in (["0", "None"], ["0", "gpu"]), (out.stdout, out.stderr[-800:])
