@@ -75,28 +75,31 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restri
     if (w0 + q < W) yo[(long)q * y_row] = (add_in & 2) ? yo[(long)q * y_row] + acc[q] : acc[q];     // bit 1: accumulate into y
 }
 
-// Weight / bias gradient.  Stage 1: one thread per (run of `spt` consecutive row segments of WCH pixels, channel)
-// accumulates its k*k + 1 partial sums, sliding the k-wide window of x through registers (spt = 1..8 by problem size:
-// the partial matrix is what this pipeline moves through HBM, 147 MB for MPViT-small's 7x7 layer at spt = 1); stage
-// 2 / 3: column sums of the partial matrix [segment runs, C*(k*k+1)] in two fixed-order passes (fp64 in the last,
-// four row lanes per column) - deterministic.
+// Weight / bias gradient.  A workgroup = 64 channels x 4 segment lanes: a thread walks row segments of WCH pixels
+// (seg = blockIdx.y * 4 + lane, stride 4 * gridDim.y), sliding the k-wide window of x through registers, and keeps its
+// k*k + 1 sums in registers over ALL its segments; the four segment lanes combine through LDS in a fixed order and the
+// workgroup writes ONE partial row - the partial matrix is [gridDim.y <= 256, C*(k*k+1)] instead of one row per
+// segment run (round 2: 147 MB for MPViT-small's 7x7 layer, plus a column-sum stage to shrink it).  Second launch: the
+// column sums of those rows in fp64, 16 row lanes per column, fixed order - deterministic.
 constexpr int WCH = 8;
+constexpr int WG_SEG_LANES = NT / 64;
+constexpr int WGRAD_MAX_ROWS = 256;
 template <int K>
 __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __restrict__ x, int x_row,
                                                                  const float* __restrict__ dy, int dy_row,
-                                                                 float* __restrict__ partial, int B, int H, int W, int C,
-                                                                 int spt) {
+                                                                 float* __restrict__ partial, int B, int H, int W, int C) {
   constexpr int P = K / 2;
+  __shared__ float sh[WG_SEG_LANES - 1][K * K + 1][64];
   const int wseg = (W + WCH - 1) / WCH;
-  const long segs = (long)B * H * wseg, runs = (segs + spt - 1) / spt;
-  const long id = (long)blockIdx.x * NT + threadIdx.x;
-  if (id >= runs * C) return;
-  const int c = (int)(id % C);
-  const long run = id / C;
+  const long segs = (long)B * H * wseg;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool live = c < C;
   float acc[K * K + 1];
 #pragma unroll
   for (int i = 0; i <= K * K; ++i) acc[i] = 0.0f;
-  for (long seg = run * spt; seg < min(segs, (run + 1) * spt); ++seg) {
+  if (live)
+  for (long seg = (long)blockIdx.y * WG_SEG_LANES + rl; seg < segs; seg += (long)gridDim.y * WG_SEG_LANES) {
   const int w0 = (int)(seg % wseg) * WCH;
   const int bh = (int)(seg / wseg);
   const int h = bh % H, b = bh / H;
@@ -125,45 +128,56 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __
       for (int q = 0; q < WCH; ++q) acc[i * K + j] = fmaf(g[q], win[q + j], acc[i * K + j]);
   }
   }
-  float* po = partial + (run * C + c) * (K * K + 1);
+  if (rl > 0) {
 #pragma unroll
-  for (int i = 0; i <= K * K; ++i) po[i] = acc[i];
+    for (int i = 0; i <= K * K; ++i) sh[rl - 1][i][cl] = acc[i];
+  }
+  __syncthreads();
+  if (rl != 0 || !live) return;
+  float* po = partial + ((long)blockIdx.y * C + c) * (K * K + 1);
+#pragma unroll
+  for (int i = 0; i <= K * K; ++i) {
+    float t = acc[i];
+#pragma unroll
+    for (int q = 0; q < WG_SEG_LANES - 1; ++q) t += sh[q][i][cl];
+    po[i] = t;
+  }
 }
 
-// out[r, col] = sum over rows r, r + R, r + 2R ... of in[row, col]   (R = gridDim.y; coalesced along col)
-__global__ __launch_bounds__(NT) void colsum_stage_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                          long rows, int cols) {
-  const int col = blockIdx.x * NT + threadIdx.x;
-  if (col >= cols) return;
-  float s = 0.0f;
-  for (long r = blockIdx.y; r < rows; r += gridDim.y) s += in[r * cols + col];
-  out[(long)blockIdx.y * cols + col] = s;
-}
-
-// column sums with RL row lanes per column: block = 64 columns x RL rows, fixed-order combine through LDS
-constexpr int RL = NT / 64;
-__global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
-                                                                       float* __restrict__ dw, float* __restrict__ dbias,
-                                                                       int rows, int C, int kk) {
-  __shared__ double sh[RL][64];
+// column sums with WRL row lanes per column: block = 64 columns x WRL rows, fixed-order combine through LDS
+constexpr int RL = NT / 64;        // row lanes of the 256-thread combine kernels below
+constexpr int WRL = 16;            // row lanes of the weight-gradient column sum (1 024-thread blocks)
+__global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
+                                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                                           int rows, int C, int kk) {
+  __shared__ double sh[WRL][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int id = blockIdx.x * 64 + cl;
   const bool live = id < C * (kk + 1);
   double s = 0.0;
   if (live)
-    for (int r = rl; r < rows; r += RL) s += (double)partial[(long)r * C * (kk + 1) + id];
+    for (int r = rl; r < rows; r += WRL) s += (double)partial[(long)r * C * (kk + 1) + id];
   sh[rl][cl] = s;
   __syncthreads();
   if (!live || rl != 0) return;
   double t = sh[0][cl];
 #pragma unroll
-  for (int q = 1; q < RL; ++q) t += sh[q][cl];
+  for (int q = 1; q < WRL; ++q) t += sh[q][cl];
   const int c = id / (kk + 1), tap = id - c * (kk + 1);
   if (tap < kk) dw[c * kk + tap] = (float)t;
   else if (dbias) dbias[c] = (float)t;
 }
 
-constexpr int WGRAD_STAGE_ROWS = 64;
+// partial rows of the weight-gradient launch: enough workgroups to fill the chip (~768 with the channel tiles), at most
+// WGRAD_MAX_ROWS, never more than there are segment quads
+static int wgrad_rows(long segs, int C) {
+  const int tiles = (C + 63) / 64;
+  long want = (768 + tiles - 1) / tiles;
+  const long quads = (segs + WG_SEG_LANES - 1) / WG_SEG_LANES;
+  if (want > quads) want = quads;
+  if (want > WGRAD_MAX_ROWS) want = WGRAD_MAX_ROWS;
+  return (int)(want < 1 ? 1 : want);
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Factorised attention of MPViT (reference networksvit/mpvit.py:333-394), token layout.
@@ -438,7 +452,7 @@ int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const 
 
 long bbd_dwconv_tokens_wgrad_scratch_floats(int B, int H, int W, int C, int k) {
   const long segs = (long)B * H * ((W + WCH - 1) / WCH);
-  return (segs + WGRAD_STAGE_ROWS) * C * (k * k + 1);
+  return (long)wgrad_rows(segs, C) * C * (k * k + 1);
 }
 
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
@@ -446,23 +460,15 @@ int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int 
   if (!x || !grad_y || !partial || !grad_weight || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BBD_E_BADARG;
   if (k != 3 && k != 5 && k != 7) return BBD_E_BADARG;
   const long segs = (long)B * H * ((W + WCH - 1) / WCH);
-  // consecutive segments per thread: as many as keep >= 512 workgroups in flight, at most 8
-  long spt_l = segs * C / ((long)NT * 512);
-  const int spt = (int)(spt_l < 1 ? 1 : (spt_l > 8 ? 8 : spt_l));
-  const long runs = (segs + spt - 1) / spt;
-  const long total = runs * C;
-  const dim3 grid((unsigned)((total + NT - 1) / NT));
+  const int rows = wgrad_rows(segs, C);
+  const dim3 grid((unsigned)((C + 63) / 64), (unsigned)rows);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<3>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C, spt);
-  else if (k == 5) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<5>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C, spt);
-  else hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<7>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C, spt);
+  if (k == 3) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<3>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
+  else if (k == 5) hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<5>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
+  else hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<7>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
   const int cols = C * (k * k + 1);
-  float* stage = partial + runs * cols;
-  const int srows = runs < WGRAD_STAGE_ROWS ? (int)runs : WGRAD_STAGE_ROWS;
-  hipLaunchKernelGGL(colsum_stage_kernel, dim3((unsigned)((cols + NT - 1) / NT), (unsigned)srows), dim3(NT), 0, st, partial,
-                     stage, runs, cols);
-  hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(NT), 0, st, stage,
-                     grad_weight, grad_bias, srows, C, k * k);
+  hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64 * WRL), 0, st, partial,
+                     grad_weight, grad_bias, rows, C, k * k);
   return launch_status();
 }
 

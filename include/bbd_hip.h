@@ -387,8 +387,8 @@ int bbd_bias_elu_bwd(const float* y, const float* grad_y, float* grad_x, float* 
  *           flip = 1 mirrors the taps: with x := grad_y, bias NULL this is the data gradient (bit 0 carries the
  *           residual's gradient, bit 1 lets it land in a slice that already holds another contribution).
  *   wgrad : grad_weight [C,k,k], grad_bias [C] (or NULL); partial = scratch of
- *           bbd_dwconv_tokens_wgrad_scratch_floats(B,H,W,C,k) floats.  Deterministic (per-segment partial
- *           sums, two fixed-order column-sum passes, the last in fp64).                                  */
+ *           bbd_dwconv_tokens_wgrad_scratch_floats(B,H,W,C,k) floats.  Deterministic (one partial row per
+ *           workgroup, a fixed-order column sum in fp64).                                                */
 long bbd_dwconv_tokens_wgrad_scratch_floats(int B, int H, int W, int C, int k);
 int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const float* bias, float* y, int y_row,
                           int B, int H, int W, int C, int k, int add_input, int flip, void* stream);
