@@ -88,6 +88,8 @@ SIGNATURES = {
     "bbd_factor_att_scratch_floats": [_i, _i, _i, _i],
     "bbd_factor_att_fwd": [_p] * 7 + [_i, _i, _i, _i, _d, _p],
     "bbd_factor_att_bwd": [_p] * 10 + [_i, _i, _i, _i, _d, _p],
+    "bbd_colsum_scratch_floats": [ctypes.c_long, _i],
+    "bbd_colsum": [_p, _p, _p, ctypes.c_long, _i, _p],
     "bbd_token_ln_supported": [_i],
     "bbd_token_ln_scratch_floats": [_i, _i],
     "bbd_token_ln_fwd": [_p] * 8 + [_i, _i, _i, _d, _p],
@@ -142,6 +144,9 @@ class HipLibrary:
 
     def dwconv_wgrad_scratch_floats(self, B, H, W, C, k):
         return self._dll.bbd_dwconv_tokens_wgrad_scratch_floats(B, H, W, C, k)
+
+    def colsum_scratch_floats(self, rows, C):
+        return self._dll.bbd_colsum_scratch_floats(rows, C)
 
     def token_ln_supported(self, C):
         return bool(self._dll.bbd_token_ln_supported(C))

@@ -235,6 +235,80 @@ __global__ __launch_bounds__(64 * PG_ROWS) void token_ln_param_grad_kernel(const
   }
 }
 
+// Column sums of a [rows, C] matrix (the bias gradient of a token-parallel Linear layer): a thread owns one float4 column,
+// CL column lanes x 256/CL row lanes per workgroup, four independent rows in flight per thread; the row lanes combine
+// through LDS in a fixed order and the workgroup leaves one partial row; colsum_final adds the partial rows.
+template <int CL>
+__global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, long rows,
+                                                            int C) {
+  constexpr int RLN = NT / CL;
+  __shared__ float4 sh[RLN][CL];
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int c4 = blockIdx.x * CL + cl, C4 = C >> 2;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  if (c4 < C4) {
+    const long stride = (long)gridDim.y * RLN;
+    long r = (long)blockIdx.y * RLN + rl;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+      const float4 v0 = ld4(x + r * C + 4 * c4), v1 = ld4(x + (r + stride) * C + 4 * c4);
+      const float4 v2 = ld4(x + (r + 2 * stride) * C + 4 * c4), v3 = ld4(x + (r + 3 * stride) * C + 4 * c4);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; r < rows; r += stride) {
+      const float4 v0 = ld4(x + r * C + 4 * c4);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+  }
+  sh[rl][cl] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                           (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (rl != 0 || c4 >= C4) return;
+  float4 t = sh[0][cl];
+#pragma unroll
+  for (int q = 1; q < RLN; ++q) {
+    const float4 u = sh[q][cl];
+    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  st4(partial + (size_t)blockIdx.y * C + 4 * c4, t);
+}
+
+__global__ __launch_bounds__(64 * PG_ROWS) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                   int prow, int C) {
+  __shared__ float sh[PG_ROWS][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (j < C) {
+    int p = rl;
+    for (; p + PG_ROWS < prow; p += 2 * PG_ROWS) {
+      s0 += partial[(size_t)p * C + j];
+      s1 += partial[(size_t)(p + PG_ROWS) * C + j];
+    }
+    if (p < prow) s0 += partial[(size_t)p * C + j];
+  }
+  sh[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && j < C) {
+    float s = sh[0][cl];
+#pragma unroll
+    for (int k = 1; k < PG_ROWS; ++k) s += sh[k][cl];
+    out[j] = s;
+  }
+}
+
+int colsum_rows(long rows, int C) {
+  const int C4 = C >> 2, cl = C4 <= 16 ? 16 : (C4 <= 32 ? 32 : 64);
+  const int tiles = (C4 + cl - 1) / cl, rln = NT / cl;
+  long want = (1024 + tiles - 1) / tiles;                  // ~1 024 workgroups in all
+  const long most = (rows + 4L * rln - 1) / (4L * rln);    // at least four rows per thread
+  if (want > most) want = most;
+  if (want > 256) want = 256;
+  return (int)(want < 1 ? 1 : want);
+}
+
 int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -261,6 +335,19 @@ extern "C" {
 int bbd_token_ln_supported(int C) { return C > 0 && (C % 4) == 0 && C <= 1024; }
 
 long bbd_token_ln_scratch_floats(int rows, int C) { return (long)bwd_grid(rows, C) * 2 * C; }
+
+long bbd_colsum_scratch_floats(long rows, int C) { return (long)colsum_rows(rows, C) * C; }
+
+int bbd_colsum(const float* x, float* partial, float* out, long rows, int C, void* stream) {
+  if (!x || !partial || !out || rows < 0 || C <= 0 || (C % 4) != 0) return BBD_E_BADARG;
+  const hipStream_t st = static_cast<hipStream_t>(stream);
+  const int C4 = C >> 2, prow = colsum_rows(rows, C);
+  if (C4 <= 16) hipLaunchKernelGGL(colsum_partial_kernel<16>, dim3((unsigned)((C4 + 15) / 16), (unsigned)prow), dim3(NT), 0, st, x, partial, rows, C);
+  else if (C4 <= 32) hipLaunchKernelGGL(colsum_partial_kernel<32>, dim3((unsigned)((C4 + 31) / 32), (unsigned)prow), dim3(NT), 0, st, x, partial, rows, C);
+  else hipLaunchKernelGGL(colsum_partial_kernel<64>, dim3((unsigned)((C4 + 63) / 64), (unsigned)prow), dim3(NT), 0, st, x, partial, rows, C);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64 * PG_ROWS), 0, st, partial, out, prow, C);
+  return launch_status();
+}
 
 #define BBD_TOKEN_DISPATCH(KERNEL, GRID, ...)                                                                         \
   do {                                                                                                                \

@@ -124,6 +124,8 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if _hip_tokens(x):          # bias gradients by the column-sum kernel (csrc/bbd_tokens.hip)
+            return self.drop(ops.linear_tokens(self.drop(self.act(ops.linear_tokens(x, self.fc1))), self.fc2))
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -273,7 +275,8 @@ class FactorAtt_ConvRelPosEnc(nn.Module):
     def forward(self, x, size):
         B, N, C = x.shape
         h = self.num_heads
-        qkv = self.qkv(x)                                              # [B, N, 3C] = q | k | v, head-major channels
+        hip = _hip_tokens(x)
+        qkv = ops.linear_tokens(x, self.qkv) if hip else self.qkv(x)   # [B, N, 3C] = q | k | v, head-major channels
         if _hip_tokens(qkv) and ops.factor_attention_supported(C, h):
             # two HIP ops on the packed activation: conv(v) read in place from the v third, then column
             # statistics of k + [Ch x Ch] contexts + the token-parallel output (csrc/bbd_vit.hip)
@@ -282,7 +285,7 @@ class FactorAtt_ConvRelPosEnc(nn.Module):
             else:
                 convv = self.crpe.conv_v(qkv[:, :, 2 * C:], size)
                 out = ops.factor_attention(qkv, convv, h, self.scale)
-            return self.proj_drop(self.proj(out))
+            return self.proj_drop(ops.linear_tokens(out, self.proj))
         qkv = qkv.view(B, N, 3, h, C // h)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]             # [B, N, h, Ch] strided views
         # softmax over the N tokens, then the [Ch, Ch] context of every head: (k^T v) is tiny, so the

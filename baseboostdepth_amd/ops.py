@@ -853,6 +853,41 @@ class _ResidualAdd(torch.autograd.Function):
         return gy, (gy if mask is None else gy * mask.view(-1, 1, 1)), None, None
 
 
+class _LinearTokens(torch.autograd.Function):
+    """nn.Linear on [..., C_in] tokens with the bias gradient from `bbd_colsum` (two short launches) instead of ATen's
+    generic reduction of the tall-skinny [tokens, C_out] gradient; the three GEMMs stay with hipBLASLt / rocBLAS."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, backend):
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (backend, bias is not None)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        backend, has_bias = ctx.meta
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gx = g2.mm(weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = g2.t().mm(x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        gb = None
+        if has_bias and ctx.needs_input_grad[2]:
+            rows, C = g2.shape
+            gb = torch.empty(C, device=g2.device, dtype=torch.float32)
+            scratch = torch.empty(backend.lib.colsum_scratch_floats(rows, C), device=g2.device, dtype=torch.float32)
+            backend.run("bbd_colsum", g2, ptr(g2), ptr(scratch), ptr(gb), rows, C)
+        return gx, gw, gb, None
+
+
+def linear_tokens(x, linear, backend=None):
+    """`linear(x)` for an nn.Linear on GPU fp32 tokens whose output width is a multiple of 4 (else the module itself)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and FUSED_TOKEN_GLUE and linear.out_features % 4 == 0):
+        return linear(x)
+    return _LinearTokens.apply(x, linear.weight, linear.bias, backend or default_backend())
+
+
 def token_glue_supported(x, backend=None):
     return x.dim() == 3 and (backend or default_backend()).lib.token_ln_supported(x.shape[-1])
 

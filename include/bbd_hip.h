@@ -412,6 +412,13 @@ int bbd_token_ln_bwd(const float* grad_z, const float* grad_y, const float* y, c
                      const float* mask, float* grad_x, float* grad_branch, float* partial, float* grad_weight,
                      float* grad_bias, int rows, int N, int C, void* stream);
 
+/* out[c] = sum over rows of x[row, c] for a [rows, C] matrix, C % 4 == 0: the bias gradient of the token-parallel
+ * nn.Linear layers (qkv, proj, fc1, fc2 of networksvit/mpvit.py:51-78, 333-394) on [B*N, C] token activations, in two
+ * launches (one partial row per workgroup, fixed-order sum of the partial rows: deterministic).
+ * partial: bbd_colsum_scratch_floats(rows, C) floats.                                                                */
+long bbd_colsum_scratch_floats(long rows, int C);
+int bbd_colsum(const float* x, float* partial, float* out, long rows, int C, void* stream);
+
 /* Factorised attention of MPViT (networksvit/mpvit.py:333-394) on the packed qkv activation.
  *   qkv [B, N, 3, h, Ch] = the qkv Linear's output (C = h*Ch); convv [B,N,C] = ConvRelPosEnc's conv(v)
  *   fwd : out[b,n,h,vc] = sum_kc q[b,n,h,kc] ctxs[b,h,kc,vc] + q[b,n,h,vc] convv[b,n,h,vc],

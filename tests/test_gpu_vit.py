@@ -249,3 +249,22 @@ def test_shipped_gemm_table_drives_tunableop_without_tuning():
     torch.cuda.synchronize()
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert tunable.get_filename() == path
+
+
+@pytest.mark.parametrize("B,N,cin,cout", [(3, 37, 64, 192), (2, 129, 216, 648), (1, 3, 288, 1152), (12, 480, 216, 216), (2, 50, 64, 62)])
+def test_linear_on_tokens_with_column_sum_bias_gradient(B, N, cin, cout):
+    """ops.linear_tokens (bias gradient by bbd_colsum) against nn.Linear's own autograd; an output width that is not a
+    multiple of 4 takes the module itself."""
+    from baseboostdepth_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + N)
+    lin = torch.nn.Linear(cin, cout).to(DEV)
+    x = torch.randn(B, N, cin, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(B, N, cout, generator=g).to(DEV)
+    res = []
+    for fn in (lambda: lin(x), lambda: ops.linear_tokens(x, lin)):
+        x.grad = lin.weight.grad = lin.bias.grad = None
+        y = fn()
+        (y * w).sum().backward()
+        res.append([y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()])
+    for name, a, b in zip(("y", "grad x", "grad weight", "grad bias"), *res):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6, name
