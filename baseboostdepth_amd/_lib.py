@@ -20,7 +20,7 @@ PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
 COMPOSE_STRIDE, COMPOSE_ERROR, COMPOSE_REPLACE = 12, 1, 2
 PAIR_SHIFT = 16        # bits 16-23 of bbd_cand_t.kind: 1 + index of the pass partner (hint), 0 = none
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

@@ -28,8 +28,10 @@ extern "C" {
 /* Bumped on EVERY incompatible change of a prototype or of a scratch-size contract; the Python binding refuses a
  * library whose number differs (a stale build selected through BBD_HIP_LIB, or a C caller compiled against an older
  * header, would otherwise mis-marshal pointers into a kernel).  1 = round 1; 2 = bbd_bn_act_bwd gained `beta`, BN
- * scratch sizing changed (round 2, was not bumped then); 3 = round 3 (backward tiling / scratch contract). */
-#define BBD_ABI_VERSION 3
+ * scratch sizing changed (round 2, was not bumped then); 3 = round 3 (backward tiling / scratch contract); 4 = the
+ * depth-wise token weight gradient's scratch contract (one partial row per workgroup) and `add_input` of
+ * bbd_dwconv_tokens_fwd became a bit field (round 3, with the bbd_token_ln_* / bbd_colsum additions). */
+#define BBD_ABI_VERSION 4
 
 /* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
  * trainer.py:428).  A "slot" indexes a host array of their base pointers. */
