@@ -279,6 +279,13 @@ def attach(trainer, group=None):
         never = trainer.gradient_free_parameters() if hasattr(trainer, "gradient_free_parameters") else ()
         trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket, never=never) if overlap
                              else GradientAverager(flat, group))
+        if capture and overlap:
+            # RCCL sets its channels / connections up lazily, per message size, by talking to its peers: let that happen
+            # here, where every rank is, not inside one rank's graph capture (a cache miss is a per-rank event)
+            for sl in trainer.grad_sync.slices:
+                trainer.grad_sync._reduce(sl)
+            torch.cuda.synchronize()
+            flat.flat.zero_()
         side = trainer._pose_stream() if hasattr(trainer, "_pose_stream") else None
         if overlap and side is not None:
             # the stream process_batch ran on (the default stream in the eager loop, the capturing stream while a step
