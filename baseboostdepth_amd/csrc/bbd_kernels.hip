@@ -854,306 +854,6 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused forward, paired-candidate form (round 3; experimental, BBD_FWD=2 - NOT the default).
-//
-// Plain fp32 vector instructions issue once per 4 cycles per SIMD on gfx950 whatever the occupancy, and the packed forms
-// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 values per lane) issue at the same rate
-// (profiles/r03/valu_rate.txt) - the kernel's floor is its fp32 instruction count, and packing halves it where the two
-// halves of a register pair want the SAME operation.  The SSIM + L1 arithmetic of two candidates at one pixel is that
-// case: same target window, same statistics, same operation sequence.  So the warp candidates are taken two at a time
-// (the table's pairing hint: the true-pose and the error-induced warp of one source frame; otherwise the next one in id
-// order), both warped images are staged as ONE set of float2 planes (.x = first, .y = second candidate), every window
-// read delivers register pairs, and the whole photometric chain of strip_loss runs on pairs: same operations, same
-// rounding per component, half the instructions.  The running minimum compares ids on ties, so the order in which
-// candidates are visited does not matter (torch.min: first index wins, a NaN wins and sticks).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ v2f pk_div9(v2f x) {               // bbd_div9 per component
-  const v2f r = pk1(1.0f / 9.0f);
-  const v2f q = x * r;
-  return pk_fma(pk_fma(pk1(-9.0f), q, x), r, q);
-}
-__device__ __forceinline__ v2f pk_div3(v2f x) {
-  const v2f r = pk1(1.0f / 3.0f);
-  const v2f q = x * r;
-  return pk_fma(pk_fma(pk1(-3.0f), q, x), r, q);
-}
-__device__ __forceinline__ v2f pk_div(v2f n, v2f d) {         // bbd_div per component (IEEE-correct quotient)
-  v2f r0;
-  r0.x = __builtin_amdgcn_rcpf(d.x);
-  r0.y = __builtin_amdgcn_rcpf(d.y);
-  const v2f one = pk1(1.0f);
-  const v2f r = pk_fma(pk_fma(-d, r0, one), r0, r0);
-  v2f q = n * r;
-  q = pk_fma(pk_fma(-d, q, n), r, q);
-  q = pk_fma(pk_fma(-d, q, n), r, q);
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (!bbd_exp_ok3(n.x, d.x, d.x)) q.x = n.x / d.x;
-  if (!bbd_exp_ok3(n.y, d.y, d.y)) q.y = n.y / d.y;
-#endif
-  return q;
-}
-
-// 3 rows x 8 columns (6 used) of a float2 plane starting at row r0, column c0 (c0 % 4 == 0): ds_read_b128 x 4 per row
-__device__ __forceinline__ void load_window_pair(const v2f* plane, int r0, int c0, v2f win[3][6]) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const v4f* p4 = reinterpret_cast<const v4f*>(plane + r0 * LS + c0);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const v4f q0 = p4[r * (LS / 2)], q1 = p4[r * (LS / 2) + 1], q2 = p4[r * (LS / 2) + 2];
-    win[r][0] = pk2(q0.x, q0.y); win[r][1] = pk2(q0.z, q0.w);
-    win[r][2] = pk2(q1.x, q1.y); win[r][3] = pk2(q1.z, q1.w);
-    win[r][4] = pk2(q2.x, q2.y); win[r][5] = pk2(q2.z, q2.w);
-  }
-}
-
-// strip_loss for two candidates at once: sx holds (.x, .y) = the two warped images.  Component for component the
-// operations (and roundings) of strip_loss / bbd_ssim_nd / bbd_ssim_from_ratio / bbd_combine.
-__device__ __forceinline__ void strip_loss_pair(const v2f (*sx)[FPLANE], const float (*sy)[FPLANE], int ly, int lx0,
-                                                const float mu_y[3][PPT], const float sg_y[3][PPT], int no_ssim,
-                                                v2f out[PPT]) {
-  v2f ssum[PPT], lsum[PPT];
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    // (one channel's windows live at a time: without the fence hipcc hoists all three channels' 54 window registers
-    // above the arithmetic and spills a hundred registers)
-    __builtin_amdgcn_sched_barrier(0);
-    v2f x[3][6];
-    float y[3][8];
-    load_window_pair(sx[ch], ly, lx0, x);
-    load_window<LS>(sy[ch], ly, lx0, y);
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      v2f s = pk1(0.0f), ss = pk1(0.0f), sxy = pk1(0.0f);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const v2f v = x[r][j + c];
-          s = s + v;
-          ss = ss + v * v;
-          sxy = sxy + v * pk1(y[r][j + c]);
-        }
-      v2f ssim = pk1(0.0f);
-      if (!no_ssim) {
-        // (opaque copies: hipcc otherwise hoists the splatted statistics and muy * muy of all 12 pixel-channels out
-        // of the candidate loop - 72 registers that it then spills)
-        float my1 = mu_y[ch][j], sg1 = sg_y[ch][j];
-        asm volatile("" : "+v"(my1), "+v"(sg1));
-        const v2f muy = pk1(my1), sgy = pk1(sg1);
-        const v2f mu_x = pk_div9(s);
-        const v2f mxx = mu_x * mu_x, mxy = mu_x * muy;
-        const v2f sig_x = pk_div9(ss) - mxx;
-        const v2f sig_xy = pk_div9(sxy) - mxy;
-        const v2f n = pk_fma(mxy, pk1(2.0f), pk1(BBD_C1)) * pk_fma(sig_xy, pk1(2.0f), pk1(BBD_C2));
-        const v2f d = (mxx + muy * muy + pk1(BBD_C1)) * (sig_x + sgy + pk1(BBD_C2));
-        const v2f q = pk_div(n, d);
-        const v2f v = (pk1(1.0f) - q) * pk1(0.5f);
-        ssim.x = v.x < 0.0f ? 0.0f : (v.x > 1.0f ? 1.0f : v.x);
-        ssim.y = v.y < 0.0f ? 0.0f : (v.y > 1.0f ? 1.0f : v.y);
-      }
-      const v2f df = pk1(y[1][j + 1]) - x[1][j + 1];
-      const v2f l1 = pk2(fabsf(df.x), fabsf(df.y));
-      ssum[j] = ch == 0 ? ssim : ssum[j] + ssim;
-      lsum[j] = ch == 0 ? l1 : lsum[j] + l1;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    const v2f l1m = pk_div3(lsum[j]);
-    out[j] = no_ssim ? l1m : pk1(0.85f) * pk_div3(ssum[j]) + pk1(0.15f) * l1m;
-  }
-}
-
-// Warp the staged cells for TWO pose rows (member .x from srcA / rowA, member .y from srcB / rowB; `both` false = only
-// the first) into one set of float2 planes.  Per cell the two projections share the camera point depth * inv_K (x, y, 1)
-// when the rows carry the same inv_K (always, for one target sample); both candidates' gathers are in flight together.
-template <int BATCH, typename CellsT>
-__device__ __forceinline__ void warp_pair_into_lds(const float* __restrict__ srcA, const float* __restrict__ srcB, bool both,
-                                                   const float (&d)[CellsT::N], const float* __restrict__ rowA,
-                                                   const float* __restrict__ rowB, const BbdDims dm, int hw,
-                                                   const CellsT& cl, v2f (*s)[FPLANE], float* __restrict__ woutA,
-                                                   float* __restrict__ woutB) {
-  float pa[21], pb[21];
-#pragma unroll
-  for (int i = 0; i < 21; ++i) { pa[i] = uniform_load(rowA + i); pb[i] = uniform_load(rowB + i); }
-#pragma unroll
-  for (int k0 = 0; k0 < CellsT::N; k0 += BATCH) {
-    BbdTaps ta[BATCH], tb[BATCH];
-#pragma unroll
-    for (int kk = 0; kk < BATCH; ++kk) {
-      const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-      BbdSample sm;
-      bbd_project(pa, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
-      bbd_taps(sm.ix, sm.iy, dm, &ta[kk]);
-      bbd_project(pb, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &sm);
-      bbd_taps(sm.ix, sm.iy, dm, &tb[kk]);
-    }
-    float va[BATCH][3][4], vb[BATCH][3][4];
-#pragma unroll
-    for (int kk = 0; kk < BATCH; ++kk)
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        bbd_fetch4(srcA + ch * hw, &ta[kk], va[kk][ch]);
-        bbd_fetch4(srcB + ch * hw, &tb[kk], vb[kk][ch]);
-      }
-#pragma unroll
-    for (int kk = 0; kk < BATCH; ++kk) {
-      if (k0 + kk >= CellsT::N) break;
-      const int k = k0 + kk;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float xa = bbd_bilerp(va[kk][ch], &ta[kk]), xb = bbd_bilerp(vb[kk][ch], &tb[kk]);
-        s[ch][cl.lds[k]] = pk2(xa, xb);
-        if (cl.own(k)) {
-          if (woutA != nullptr) woutA[cl.pix(k, dm.W) + ch * hw] = xa;
-          if (both && woutB != nullptr) woutB[cl.pix(k, dm.W) + ch * hw] = xb;
-        }
-      }
-    }
-  }
-}
-
-#ifndef BBD_FWDP_WAVES
-#define BBD_FWDP_WAVES 3
-#endif
-#ifndef BBD_FWDP_BATCH
-#define BBD_FWDP_BATCH 2
-#endif
-__global__ __launch_bounds__(NT, BBD_FWDP_WAVES) void warp_ssim_min_fwdp_kernel(FwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
-  __shared__ __attribute__((aligned(16))) v2f s_xp[3][FPLANE];
-  __shared__ float s_red[4];
-  const BbdDims dm = a.dm;
-  const int H = dm.H, W = dm.W, hw = H * W;
-  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
-  const size_t img = (size_t)3 * hw;
-  const size_t sb = (size_t)s * a.B + b;
-
-  BBD_STAMP(0);
-  typedef Cells<LH, LW, LS, 1> CellsF;
-  CellsF cl;
-  cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
-  float dcell[CellsF::N];
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  load_depth(dsrc, H, W, cl, dcell);
-  if (a.depth_out != nullptr) {
-#pragma unroll
-    for (int k = 0; k < CellsF::N; ++k)
-      if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
-  }
-  BBD_STAMP(1);
-  __syncthreads();
-  BBD_STAMP(2);
-  int ly, lx0;
-  strip_of_thread(&ly, &lx0);
-  const int yy = tc.ty0 + ly, xx = tc.tx0 + lx0;
-  const bool row_ok = yy < H;
-  const bool vec_ok = (xx + PPT <= W) && ((W & 3) == 0);
-  const int pix = yy * W + xx;
-
-  float mu_y[3][PPT], sg_y[3][PPT];
-  strip_ystats(s_y, ly, lx0, mu_y, sg_y);
-  float best[PPT];
-  int arg[PPT];
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) { best[j] = INFINITY; arg[j] = 0; }
-
-  const int nc = uniform_load(a.ncand + b);
-  const bbd_cand_t* ctab = a.cand + b * BBD_MAX_CAND;
-  unsigned todo = 0u;
-  for (int c = 0; c < nc; ++c) {
-    const bbd_cand_t cd = load_cand(ctab + c);
-    if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
-      todo |= 1u << c;
-    } else {
-      // identity candidate (+ noise): a stored map
-      float loss[PPT];
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) loss[j] = 0.0f;
-      if (row_ok) {
-        load_strip(a.ident + (size_t)cd.row * hw + pix, xx, W, vec_ok, loss);
-        if (a.noise != nullptr) {
-          float nz[PPT];
-          load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
-#pragma unroll
-          for (int j = 0; j < PPT; ++j) loss[j] += nz[j];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) min_update_any_order(loss[j], c, &best[j], &arg[j]);
-    }
-  }
-  BBD_STAMP(3);
-  // warp candidates, two per step
-  bool first = true;
-  int pno = 0;
-  while (todo != 0u) {
-    const int ia = __builtin_ctz(todo);
-    todo &= todo - 1u;
-    const bbd_cand_t ca = load_cand(ctab + ia);
-    const int hint = ((ca.kind >> 16) & 0xff) - 1;
-    int ib = -1;
-    if (hint >= 0 && hint < 32 && ((todo >> hint) & 1u)) ib = hint;
-    else if (todo != 0u) ib = __builtin_ctz(todo);
-    bbd_cand_t cb = ca;
-    if (ib >= 0) {
-      todo &= ~(1u << ib);
-      cb = load_cand(ctab + ib);
-    }
-    const bool both = ib >= 0;
-    const float* srcA = a.frames.base[ca.slot] + (size_t)ca.row * img;
-    const float* srcB = a.frames.base[cb.slot] + (size_t)cb.row * img;
-    float* woutA = a.warped ? a.warped + ((size_t)s * a.NP + ca.pose) * img : nullptr;
-    float* woutB = a.warped ? a.warped + ((size_t)s * a.NP + cb.pose) * img : nullptr;
-    if (!first) __syncthreads();          // every wave has read the previous pair's planes
-    first = false;
-    const int sp = 4 + 4 * (pno & 3);
-    ++pno;
-    BBD_STAMP(sp);
-    warp_pair_into_lds<BBD_FWDP_BATCH, CellsF>(srcA, srcB, both, dcell, a.pose + (size_t)ca.pose * BBD_PROJ_STRIDE,
-                                               a.pose + (size_t)cb.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xp, woutA, woutB);
-    BBD_STAMP(sp + 1);
-    __syncthreads();
-    BBD_STAMP(sp + 2);
-    v2f loss[PPT];
-    strip_loss_pair(s_xp, s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
-    BBD_STAMP(sp + 3);
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      min_update_any_order(loss[j].x, ia, &best[j], &arg[j]);
-      if (both) min_update_any_order(loss[j].y, ib, &best[j], &arg[j]);
-    }
-  }
-
-  float tsum = 0.0f;
-  if (row_ok) {
-    store_strip(a.min_loss + sb * hw + pix, xx, W, vec_ok, best);
-    uint8_t* ao = a.argmin + sb * hw + pix;
-    if (vec_ok) {
-      *reinterpret_cast<uint32_t*>(ao) = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
-      tsum = ((best[0] + best[1]) + best[2]) + best[3];
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPT; ++j)
-        if (xx + j < W) {
-          ao[j] = (uint8_t)arg[j];
-          tsum += best[j];
-        }
-    }
-  }
-  const float wsum = wave_sum63(tsum);
-  if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
-  __syncthreads();
-  if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-  BBD_STAMP(20);
-}
-
-// ------------------------------------------------------------------------------------------
 // Fused backward.
 // ------------------------------------------------------------------------------------------
 struct BwdArgs {
@@ -1553,562 +1253,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   BBD_STAMP_RT(31);
   BBD_STAMP_VAL(29, __builtin_popcount(present));
 #undef BBD_PARG
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused backward, sparse-item form (round 3; experimental, BBD_BWD=3 - NOT the default, see the end of this comment).
-//
-// The round-2 form above runs its whole pipeline once per candidate that won ANY pixel around the tile: with the
-// boosted recipe's 12 warp candidates that is 12 x (warp the 36x20 halo'd region, 9 barriers), although every pixel
-// has exactly ONE winner.  This form does only the work the arg-min map asks for:
-//   * an ITEM is a (staged cell, candidate) pair whose warped value some winner's 3x3 SSIM window needs, i.e. the
-//     candidate won at least one of the cell's 9 neighbouring loss pixels.  With 18 random winners that is 4.8 of 12
-//     warps per cell, with a coherent arg-min map ~1 - instead of "every present candidate everywhere";
-//   * candidates are taken two per PASS (the (T, T_error) pair of one source frame when the caller's table pairs them:
-//     same image, gathers side by side): both item lists are compacted - ballot + popcount, every list padded to whole
-//     64-lane chunks so that a chunk's pose row stays in SGPRs - and the chunks are dealt round-robin to the four waves;
-//   * W: a lane warps its item (projection with the forward's arithmetic, 6 x 8-byte gathers, blend) into that member's
-//     x planes and keeps d warped / d (ix, iy) and the depth in registers;
-//   * C: every wave owns a band of loss-pixel rows; its winners of the two members (wave-private compaction) read their
-//     3x3 x / y windows, form the SSIM partials (A, B, C per channel) and SCATTER (A + B x + C y) / 9 onto the window's
-//     texels - reflection at the image border folds in by scattering to the reflected texel - into accumulation planes
-//     PRIVATE to the wave (LDS float adds; the band planes of neighbouring waves overlap by two rows and are summed in
-//     wave order by the reader), so the result does not depend on timing: deterministic like the gather form, at a
-//     ninth of its loads;
-//   * G: the lane that warped an item of one of the tile's own texels reads its accumulated texel gradient, applies
-//     d warped / d (ix, iy) from its registers, chains to depth and to the 12 entries of P; one reduce-scatter per chunk.
-// Per pass: 4 barriers (list | x planes | accumulators | partials) instead of 9 per candidate.
-// LDS 52.5 KB -> three workgroups per CU.
-// Measured (profiles/r03/bwd3_v*_*.txt, phase_stamps_bwd3_*.txt): bit-identical gradients to the dense form within the
-// tests' bars on all 128 GPU tests, but NOT faster - m = 7 with per-pixel random disparities 0.339 vs 0.353 ms, inside
-// the training step 0.316 vs 0.262 ms, MD2 0.386 vs 0.283 ms: the item machinery (lists, padding, per-item index
-// arithmetic, a C phase at 17 of 64 lanes) issues as many instructions per tile as the dense form's twelve warps, and
-// with fp32 issue at 4 cycles per wave-instruction per SIMD (valu_rate.txt) instructions are the currency.  Kept as
-// the starting point for a packed (two-candidates-per-register-pair) form.
-// ------------------------------------------------------------------------------------------
-constexpr int B3_CELLS = BH * BS2;                  // 720 staged cells (20 x 36, halo 2)
-constexpr int B3_LPIX = CH * CW2;                   // 612 loss pixels (18 x 34, halo 1)
-constexpr int B3_MAXCH = 6;                         // chunks per wave and pass: 2 members x 720 cells -> 24 chunks / 4
-constexpr int B3_LIST = 4 * B3_MAXCH * 64;          // 1536 list entries
-constexpr int B3_NCELL = (B3_CELLS + NT2 - 1) / NT2;   // 3 cells per thread
-// loss-row bands of the four waves and the own-texel rows (cell rows 2..17) their winners' windows can reach
-__device__ __constant__ const int b3_band0[5] = {0, 5, 9, 14, 18};
-constexpr int B3_R0[4] = {2, 5, 9, 14};             // first own cell row of a band's accumulation planes
-constexpr int B3_ROWS[4] = {5, 6, 7, 4};            // rows of them
-constexpr int B3_BASE[4] = {0, 5 * 192, 11 * 192, 18 * 192};   // float offset of a band's planes [member][ch][row][32]
-constexpr int B3_ACC = 22 * 192;                    // 4224 floats
-
-__device__ __forceinline__ int lane_prefix(unsigned long long m) {    // set bits of m below this lane
-  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-
-struct PassCand {
-  int id;                // arg-min id of the candidate, -1 = no member
-  int kind, slot, row, pose;
-};
-// Next pass: the lowest warp candidate not done yet and its partner - the table's pairing hint (bits 16-23 of `kind` =
-// 1 + index of the candidate that samples the same source image) if it names one that is still to do, else the next
-// lowest.  The sample's candidate table sits in LDS (staged once per workgroup): no scalar-memory round trips per pass.
-__device__ __forceinline__ void load_pass_cand(const int* s_cand, int id, PassCand* m) {
-  m->id = id;
-  m->kind = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 0]);
-  m->slot = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 1]);
-  m->row = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 2]);
-  m->pose = __builtin_amdgcn_readfirstlane(s_cand[4 * id + 3]);
-}
-__device__ __forceinline__ bool next_pass(const int* s_cand, unsigned* todo, PassCand* m0, PassCand* m1) {
-  m0->id = m1->id = -1;
-  if (*todo == 0u) return false;
-  const int a0 = __builtin_ctz(*todo);
-  *todo &= *todo - 1u;
-  load_pass_cand(s_cand, a0, m0);
-  const int hint = ((m0->kind >> 16) & 0xff) - 1;
-  int a1 = -1;
-  if (hint >= 0 && hint < 32 && ((*todo >> hint) & 1u)) a1 = hint;
-  else if (*todo != 0u) a1 = __builtin_ctz(*todo);
-  if (a1 >= 0) {
-    *todo &= ~(1u << a1);
-    load_pass_cand(s_cand, a1, m1);
-  } else {
-    *m1 = *m0;
-    m1->id = -1;
-  }
-  return true;
-}
-
-#ifndef BBD_BWD3_WAVES
-#define BBD_BWD3_WAVES 3
-#endif
-__global__ __launch_bounds__(NT2, BBD_BWD3_WAVES) void warp_ssim_min_bwd3_kernel(BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_y[3][B3_CELLS];
-  __shared__ __attribute__((aligned(16))) float s_x[2][3][B3_CELLS];
-  __shared__ __attribute__((aligned(16))) float s_acc[B3_ACC];
-  __shared__ __attribute__((aligned(16))) float s_gd[2][TH * TW2];
-  __shared__ uint16_t s_list[B3_LIST];
-  __shared__ uint16_t s_wlist[4][192];
-  __shared__ uint8_t s_id[640];
-  __shared__ float s_red[4][2][12];
-  __shared__ int s_cnt[4][2];
-  __shared__ int s_cand[BBD_MAX_CAND * 4];
-  const BbdDims dm = a.dm;
-  const int H = dm.H, W = dm.W, hw = H * W;
-  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
-  const size_t img = (size_t)3 * hw;
-  const size_t sb = (size_t)s * a.B + b;
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  const uint8_t* am = a.argmin + sb * hw;
-  const float g = uniform_load(a.gscale + s);
-  const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
-  const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
-  const int tid = (int)threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // image borders inside the staged region: reflected window taps may then land on ONE texel from two winners
-  const bool interior = tc.tx0 >= 2 && tc.tx0 + TW2 + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
-
-  BBD_STAMP(0);
-  int pass_no = 0;
-  // ---- set-up: candidate table, arg-min ids of the loss pixels, target cells, accumulators
-  const int nc = uniform_load(a.ncand + b);
-  unsigned warpmask;
-  {
-    const int* ctab = reinterpret_cast<const int*>(a.cand + b * BBD_MAX_CAND);
-    int cw = 0;
-    if (tid < BBD_MAX_CAND * 4) cw = ctab[tid];
-    const float* tg = a.target + (size_t)b * img;
-    float tv[B3_NCELL][3];
-    unsigned idw = 0u;
-#pragma unroll
-    for (int k = 0; k < B3_NCELL; ++k) {
-      const int i = k * NT2 + tid;
-      const int ii = i < B3_LPIX ? i : B3_LPIX - 1;
-      const int lr = ii / CW2, lc = ii - lr * CW2;
-      const int py = tc.ty0 + lr - 1, px = tc.tx0 + lc - 1;
-      const bool in = py >= 0 && py < H && px >= 0 && px < W;
-      idw |= (in ? (unsigned)am[py * W + px] : 255u) << (8 * k);
-      const int ci = i < B3_CELLS ? i : B3_CELLS - 1;
-      const int r = ci / BS2, c = ci - r * BS2;
-      const int yy = min(max(tc.ty0 + r - 2, 0), H - 1), xx = min(max(tc.tx0 + c - 2, 0), W - 1);
-      tv[k][0] = tg[yy * W + xx];
-      tv[k][1] = tg[yy * W + xx + hw];
-      tv[k][2] = tg[yy * W + xx + 2 * hw];
-    }
-    for (int i = tid; i < B3_ACC / 4; i += NT2) reinterpret_cast<float4*>(s_acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < 2 * TH * TW2 / 4; i += NT2) reinterpret_cast<float4*>(&s_gd[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < BBD_MAX_CAND * 4) s_cand[tid] = cw;
-    // warp candidates: lanes 4 c of wave 0 hold `kind` of candidate c
-    const unsigned long long wb = __ballot(tid < 4 * nc && (tid & 3) == 0 && (cw & KIND_MASK) == BBD_KIND_WARP);
-    if (tid == 0) s_cnt[0][0] = 0;
-    unsigned wm = 0u;
-    if (wv == 0) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) wm |= (unsigned)((wb >> (4 * c)) & 1ull) << c;
-    }
-    // candidates 16..19 sit in wave 1 (lanes 0, 4, 8, 12 of tid 64..79)
-    if (wv == 1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) wm |= (unsigned)((wb >> (4 * c)) & 1ull) << (16 + c);
-    }
-    if (lane == 0 && wv < 2) reinterpret_cast<unsigned*>(&s_red[0][0][0])[wv] = wm;
-#pragma unroll
-    for (int k = 0; k < B3_NCELL; ++k) {
-      const int i = k * NT2 + tid;
-      if (i < B3_LPIX) s_id[i] = (uint8_t)(idw >> (8 * k));
-      if (i < B3_CELLS) {
-        s_y[0][i] = tv[k][0];
-        s_y[1][i] = tv[k][1];
-        s_y[2][i] = tv[k][2];
-      }
-    }
-  }
-  // own pixels of this thread (2-pixel strip): gradient accumulators
-  const int ly = tid / SPR2, lx0 = (tid % SPR2) * PPT2;
-  const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
-  const bool q_row_ok = qy < H;
-  float gdepth[PPT2] = {0.0f, 0.0f};
-  __syncthreads();
-  BBD_STAMP(1);
-  warpmask = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(&s_red[0][0][0])[0] |
-                                            reinterpret_cast<const unsigned*>(&s_red[0][0][0])[1]);
-
-  // ---- per-cell candidate masks (which candidates' warps the cell's neighbourhood needs) and this wave's band ids
-  unsigned cmask[B3_NCELL];
-#pragma unroll
-  for (int k = 0; k < B3_NCELL; ++k) {
-    const int i = k * NT2 + tid;
-    const int ci = i < B3_CELLS ? i : B3_CELLS - 1;
-    const int r = ci / BS2, c = ci - r * BS2;
-    const int py = tc.ty0 + r - 2, px = tc.tx0 + c - 2;
-    unsigned m = 0u;
-    if (i < B3_CELLS && py >= 0 && py < H && px >= 0 && px < W) {
-#pragma unroll
-      for (int dr = 0; dr < 3; ++dr) {
-        const int lr = r - 2 + dr;             // loss row of image row py - 1 + dr
-        if (lr < 0 || lr >= CH) continue;
-#pragma unroll
-        for (int dc = 0; dc < 3; ++dc) {
-          const int lc = c - 2 + dc;
-          if (lc < 0 || lc >= CW2) continue;
-          const unsigned id = s_id[lr * CW2 + lc];
-          if (id < 32u) m |= 1u << id;
-        }
-      }
-    }
-    cmask[k] = m & warpmask;
-  }
-  const int band0 = b3_band0[wv], band_n = (b3_band0[wv + 1] - band0) * CW2;      // this wave's loss pixels
-  unsigned bidw = 0xffffffu;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int idx = lane + 64 * k;
-    if (idx < band_n) bidw = (bidw & ~(0xffu << (8 * k))) | ((unsigned)s_id[band0 * CW2 + idx] << (8 * k));
-  }
-  const int acc_r0 = B3_R0[0] * (wv == 0) + B3_R0[1] * (wv == 1) + B3_R0[2] * (wv == 2) + B3_R0[3] * (wv == 3);
-  const int acc_rows = B3_ROWS[0] * (wv == 0) + B3_ROWS[1] * (wv == 1) + B3_ROWS[2] * (wv == 2) + B3_ROWS[3] * (wv == 3);
-  const int acc_base = B3_BASE[0] * (wv == 0) + B3_BASE[1] * (wv == 1) + B3_BASE[2] * (wv == 2) + B3_BASE[3] * (wv == 3);
-
-  // item counts of a pass's two members in this wave -> s_cnt
-  auto publish_counts = [&](const PassCand& m0, const PassCand& m1) {
-    int n0 = 0, n1 = 0;
-#pragma unroll
-    for (int k = 0; k < B3_NCELL; ++k) {
-      n0 += __popcll(__ballot(m0.id >= 0 && ((cmask[k] >> m0.id) & 1u)));
-      n1 += __popcll(__ballot(m1.id >= 0 && ((cmask[k] >> m1.id) & 1u)));
-    }
-    if (lane == 0) { s_cnt[wv][0] = n0; s_cnt[wv][1] = n1; }
-  };
-
-  unsigned todo = warpmask;
-  PassCand m0, m1;
-  bool more = next_pass(s_cand, &todo, &m0, &m1);
-  if (more) publish_counts(m0, m1);
-  __syncthreads();
-  BBD_STAMP(2);
-
-  while (more) {
-    const int sp = 3 + 6 * pass_no;      // stamps of the first two passes only
-    const bool stamp_pass = pass_no < 2;
-    ++pass_no;
-    // ---- item lists of the pass: [member 0 | pad to 64][member 1 | pad to 64]
-    int n0 = 0, n1 = 0, before0 = 0, before1 = 0;
-#pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) {
-      const int c0 = s_cnt[w4][0], c1 = s_cnt[w4][1];
-      before0 += w4 < wv ? c0 : 0;
-      before1 += w4 < wv ? c1 : 0;
-      n0 += c0;
-      n1 += c1;
-    }
-    n0 = __builtin_amdgcn_readfirstlane(n0);
-    n1 = __builtin_amdgcn_readfirstlane(n1);
-    const int n0p = (n0 + 63) & ~63, n1p = (n1 + 63) & ~63;
-    const int nchunk = (n0p + n1p) >> 6;
-    const PassCand c0 = m0, c1 = m1;
-    float* gp0 = a.grad_proj + (((size_t)s * a.NP + c0.pose) * a.ntiles + tc.tile) * 12;
-    float* gp1 = a.grad_proj + (((size_t)s * a.NP + c1.pose) * a.ntiles + tc.tile) * 12;
-    more = next_pass(s_cand, &todo, &m0, &m1);
-    if (nchunk == 0) {
-      // nobody's window needs these candidates here: their pose gradient of this tile is zero
-      if (tid < 12) gp0[tid] = 0.0f;
-      if (c1.id >= 0 && tid >= 64 && tid < 76) gp1[tid - 64] = 0.0f;
-      __syncthreads();                     // every wave has read s_cnt
-      if (more) publish_counts(m0, m1);
-      __syncthreads();
-      continue;
-    }
-    {
-      int p0 = before0, p1 = n0p + before1;
-#pragma unroll
-      for (int k = 0; k < B3_NCELL; ++k) {
-        const int i = k * NT2 + tid;
-        const bool f0 = (cmask[k] >> c0.id) & 1u;
-        const bool f1 = c1.id >= 0 && ((cmask[k] >> c1.id) & 1u);
-        const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
-        if (f0) s_list[p0 + lane_prefix(b0)] = (uint16_t)i;
-        if (f1) s_list[p1 + lane_prefix(b1)] = (uint16_t)i;
-        p0 += __popcll(b0);
-        p1 += __popcll(b1);
-      }
-      if (tid < n0p - n0) s_list[n0 + tid] = (uint16_t)0xffff;
-      if (tid >= 64 && tid - 64 < n1p - n1) s_list[n0p + n1 + tid - 64] = (uint16_t)0xffff;
-    }
-    __syncthreads();
-    if (stamp_pass) BBD_STAMP(sp);
-
-    // ---- W: warp the items.  Chunk j (64 items of ONE member) goes to wave j % 4; slot i of a wave = chunk wv + 4 i:
-    //      a wave's member-0 chunks come first, so each member's projection row is read (scalar loads) once per phase.
-    const int nslot = nchunk > wv ? (nchunk - wv + 3) >> 2 : 0;
-    const int nslot0 = (n0p >> 6) > wv ? ((n0p >> 6) - wv + 3) >> 2 : 0;      // slots that hold member-0 chunks
-    float dvx[B3_MAXCH][3], dvy[B3_MAXCH][3], idep[B3_MAXCH];
-    int icell[B3_MAXCH];
-    const float* src0 = a.frames.base[c0.slot] + (size_t)c0.row * img;
-    const float* src1 = a.frames.base[c1.slot] + (size_t)c1.row * img;
-    const float* prow0 = a.pose + (size_t)c0.pose * BBD_PROJ_STRIDE;
-    const float* prow1 = a.pose + (size_t)c1.pose * BBD_PROJ_STRIDE;
-    // first the list entries and the depths of every slot (independent loads, all in flight together) ...
-#pragma unroll
-    for (int i = 0; i < B3_MAXCH; ++i) {
-      icell[i] = 2 * BS2 + 2;
-      idep[i] = 1.0f;
-      if (i >= nslot) continue;
-      const unsigned e = s_list[((wv + 4 * i) << 6) + lane];
-      const int cell = e != 0xffffu ? (int)e : -1;
-      icell[i] = cell;
-      const int cc = cell >= 0 ? cell : 2 * BS2 + 2;          // padding lanes: the tile's first own texel (never stored)
-      const int r = cc / BS2, c = cc - r * BS2;
-      idep[i] = depth_at(dsrc, tc.ty0 + r - 2, tc.tx0 + c - 2, H, W);
-    }
-    // ... then one member at a time: projection with the forward's arithmetic, gathers, blend
-#pragma unroll
-    for (int mem = 0; mem < 2; ++mem) {
-      const int lo = mem ? nslot0 : 0, hi = mem ? nslot : nslot0;
-      if (lo >= hi) continue;
-      const float* src = mem ? src1 : src0;
-      const float* prow = mem ? prow1 : prow0;
-      float pj[21];
-#pragma unroll
-      for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
-#pragma unroll
-      for (int i = 0; i < B3_MAXCH; ++i) {
-        if (i < lo || i >= hi) continue;
-        const bool valid = icell[i] >= 0;
-        const int cell = valid ? icell[i] : 2 * BS2 + 2;
-        const int r = cell / BS2, c = cell - r * BS2;
-        const int py = tc.ty0 + r - 2, px = tc.tx0 + c - 2;
-        BbdSample sm;
-        bbd_project_bwd(pj, px, py, idep[i], dm, &sm);
-        BbdTaps t;
-        bbd_taps(sm.ix, sm.iy, dm, &t);
-        float v[3][4];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) bbd_fetch4(src + ch * hw, &t, v[ch]);
-        const bool own = valid && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2;
-        icell[i] = own ? cell : -1;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          const float val = bbd_bilerp(v[ch], &t);
-          if (valid) s_x[mem][ch][cell] = val;
-          dvx[i][ch] = sm.clipx ? 0.0f : (v[ch][1] - v[ch][0]) * t.s + (v[ch][3] - v[ch][2]) * t.n;
-          dvy[i][ch] = sm.clipy ? 0.0f : (v[ch][2] - v[ch][0]) * t.e + (v[ch][3] - v[ch][1]) * t.w;
-        }
-      }
-    }
-    if (stamp_pass) BBD_STAMP(sp + 1);
-    __syncthreads();
-    if (stamp_pass) BBD_STAMP(sp + 2);
-
-    // ---- C: this wave's winners of the two members -> SSIM partials -> scatter onto the window texels
-    {
-      int nwin = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const unsigned id = (bidw >> (8 * k)) & 0xffu;
-        const int memb = id == (unsigned)c0.id ? 0 : ((c1.id >= 0 && id == (unsigned)c1.id) ? 1 : -1);
-        const unsigned long long bm = __ballot(memb >= 0);
-        if (memb >= 0) s_wlist[wv][nwin + lane_prefix(bm)] = (uint16_t)((lane + 64 * k) | (memb << 15));
-        nwin += __popcll(bm);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int base = 0; base < nwin; base += 64) {
-        const bool act = base + lane < nwin;
-        const unsigned e = s_wlist[wv][act ? base + lane : 0];
-        const int memb = (int)(e >> 15), idx = (int)(e & 0x7fffu);
-        const int lrr = idx / CW2;
-        const int lr = band0 + lrr, lc = idx - lrr * CW2;
-        const int py = tc.ty0 + lr - 1, px = tc.tx0 + lc - 1;
-        int rr[3], cc[3];
-        unsigned refl = 0u;              // bit d: row tap d is a reflected one; bit 4 + d: column tap d
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int ry = bbd_reflect(py + d - 1, H), rx = bbd_reflect(px + d - 1, W);
-          refl |= (unsigned)(ry != py + d - 1) << d;
-          refl |= (unsigned)(rx != px + d - 1) << (4 + d);
-          rr[d] = ry - tc.ty0 + 2;
-          cc[d] = rx - tc.tx0 + 2;
-        }
-        const float* xp = &s_x[0][0][0] + memb * 3 * B3_CELLS;
-        float* ap = s_acc + acc_base + memb * 3 * acc_rows * 32;
-        float val[3][9];                 // this winner's contribution to the 9 texels of its window, per channel
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float xv[3][3], yv[3][3];
-#pragma unroll
-          for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-            for (int dc = 0; dc < 3; ++dc) {
-              xv[dr][dc] = xp[ch * B3_CELLS + rr[dr] * BS2 + cc[dc]];
-              yv[dr][dc] = s_y[ch][rr[dr] * BS2 + cc[dc]];
-            }
-          float A = 0.0f, Bc = 0.0f, Cc = 0.0f;
-          if (!a.no_ssim) {
-            float sx_ = 0.0f, sxx = 0.0f, sxy = 0.0f, sy_ = 0.0f, syy = 0.0f;
-#pragma unroll
-            for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-              for (int dc = 0; dc < 3; ++dc) {
-                const float xq = xv[dr][dc], yq = yv[dr][dc];
-                sx_ += xq; sxx += xq * xq; sxy += xq * yq; sy_ += yq; syy += yq * yq;
-              }
-            float mu_y, sg_y;
-            bbd_ystats(sy_, syy, &mu_y, &sg_y);
-            bbd_ssim_grad(sx_, sxx, sxy, mu_y, sg_y, &A, &Bc, &Cc);
-            A *= w_ssim * (1.0f / 9.0f); Bc *= w_ssim * (1.0f / 9.0f); Cc *= w_ssim * (1.0f / 9.0f);
-          }
-#pragma unroll
-          for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-            for (int dc = 0; dc < 3; ++dc) val[ch][dr * 3 + dc] = A + Bc * xv[dr][dc] + Cc * yv[dr][dc];
-          const float df = xv[1][1] - yv[1][1];
-          val[ch][4] += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
-        }
-        // scatter.  The planes are private to this wave and LDS operations of a wave execute in program order.  For one
-        // window offset the winners of a step hit DIFFERENT texels (distinct pixels, one translation), so a plain
-        // read-add-write per offset - the three channels in flight together - is exact and deterministic; a
-        // ds_add_f32 costs 192 cycles per wave-instruction against ~6 for the three plain instructions
-        // (profiles/r03/lds_rate.txt).  At an image border a reflected tap folds onto the texel of an unreflected one:
-        // there the step runs once per reflection class (row reflected / column reflected), inside a class the map
-        // winner -> texel is a translation again.
-#pragma unroll
-        for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-          for (int dc = 0; dc < 3; ++dc) {
-            if (a.no_ssim && !(dr == 1 && dc == 1)) continue;
-            const int r = rr[dr], c = cc[dc];
-            const bool ok = act && r >= 2 && r < TH + 2 && c >= 2 && c < TW2 + 2;
-            float* q = &ap[(r - acc_r0) * 32 + (c - 2)];
-            if (interior) {
-              if (ok) {
-                const float q0 = q[0], q1 = q[acc_rows * 32], q2 = q[2 * acc_rows * 32];
-                q[0] = q0 + val[0][dr * 3 + dc];
-                q[acc_rows * 32] = q1 + val[1][dr * 3 + dc];
-                q[2 * acc_rows * 32] = q2 + val[2][dr * 3 + dc];
-              }
-            } else {
-              const int cls = (int)(((refl >> dr) & 1u) << 1 | ((refl >> (4 + dc)) & 1u));
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                if ((dr == 1 && (k & 2)) || (dc == 1 && (k & 1))) continue;      // the centre tap never reflects
-                const bool mine = ok && cls == k;
-                if (__ballot(mine) == 0ull) continue;
-                if (mine) {
-                  const float q0 = q[0], q1 = q[acc_rows * 32], q2 = q[2 * acc_rows * 32];
-                  q[0] = q0 + val[0][dr * 3 + dc];
-                  q[acc_rows * 32] = q1 + val[1][dr * 3 + dc];
-                  q[2 * acc_rows * 32] = q2 + val[2][dr * 3 + dc];
-                }
-              }
-            }
-          }
-      }
-    }
-    if (stamp_pass) BBD_STAMP(sp + 3);
-    __syncthreads();
-    if (stamp_pass) BBD_STAMP(sp + 4);
-
-    // ---- G: own-texel items: accumulated texel gradient -> sampling coordinates -> depth and P
-    {
-      float tot[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int mem = 0; mem < 2; ++mem) {
-        const int lo = mem ? nslot0 : 0, hi = mem ? nslot : nslot0;
-        if (lo >= hi) continue;
-        const float* prow = mem ? prow1 : prow0;
-        const int nopose = (mem ? c1.kind : c0.kind) & FLAG_NO_POSE_GRAD;
-        float pj[21];
-#pragma unroll
-        for (int q = 0; q < 21; ++q) pj[q] = uniform_load(prow + q);
-        float gP[12];                      // summed over this member's items of the lane, reduced once per member
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < B3_MAXCH; ++i) {
-          if (i < lo || i >= hi) continue;
-          const int cell = icell[i];
-          if (cell >= 0) {
-            const int r = cell / BS2, c = cell - r * BS2;
-            float gx[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-              if (r < B3_R0[w4] || r >= B3_R0[w4] + B3_ROWS[w4]) continue;
-              float* ap = s_acc + B3_BASE[w4] + (mem * 3 * B3_ROWS[w4] + (r - B3_R0[w4])) * 32 + (c - 2);
-#pragma unroll
-              for (int ch = 0; ch < 3; ++ch) {
-                gx[ch] += ap[ch * B3_ROWS[w4] * 32];
-                ap[ch * B3_ROWS[w4] * 32] = 0.0f;
-              }
-            }
-            if (gx[0] != 0.0f || gx[1] != 0.0f || gx[2] != 0.0f) {
-              const float gix = gx[0] * dvx[i][0] + gx[1] * dvx[i][1] + gx[2] * dvx[i][2];
-              const float giy = gx[0] * dvy[i][0] + gx[1] * dvy[i][1] + gx[2] * dvy[i][2];
-              BbdSample sm;
-              bbd_sample_smooth(pj, tc.tx0 + c - 2, tc.ty0 + r - 2, idep[i], &sm);
-              float gd, g1[12];
-              bbd_project_grad(pj, &sm, gix, giy, &gd, g1);
-              s_gd[mem][(r - 2) * TW2 + (c - 2)] = gd;
-#pragma unroll
-              for (int k = 0; k < 12; ++k) gP[k] += g1[k];
-            }
-          }
-        }
-        if (!nopose) wave_sum12(gP, tot[mem]);
-      }
-      if ((lane & 15) == 15) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          s_red[wv][0][wave_sum12_index(k, lane)] = tot[0][k];
-          s_red[wv][1][wave_sum12_index(k, lane)] = tot[1][k];
-        }
-      }
-    }
-    if (more) publish_counts(m0, m1);
-    if (stamp_pass) BBD_STAMP(sp + 5);
-    __syncthreads();
-
-    // ---- end of pass: pose-gradient partials of the tile, depth gradient of the own pixels
-    if (tid < 24) {
-      const int mem = tid >= 12, k = tid - 12 * mem;
-      if (mem == 0 || c1.id >= 0) {
-        const int nopose = (mem ? c1.kind : c0.kind) & FLAG_NO_POSE_GRAD;
-        float t = 0.0f;
-        if (!nopose) t = ((s_red[0][mem][k] + s_red[1][mem][k]) + s_red[2][mem][k]) + s_red[3][mem][k];
-        (mem ? gp1 : gp0)[k] = t;
-      }
-    }
-    {
-      float2* g0 = reinterpret_cast<float2*>(&s_gd[0][ly * TW2 + lx0]);
-      float2* g1 = reinterpret_cast<float2*>(&s_gd[1][ly * TW2 + lx0]);
-      const float2 u = *g0, v2 = *g1;
-      gdepth[0] += u.x + v2.x;
-      gdepth[1] += u.y + v2.y;
-      *g0 = make_float2(0.f, 0.f);
-      *g1 = make_float2(0.f, 0.f);
-    }
-  }
-
-  if (q_row_ok) {
-    if (a.ds.grad_wrt_disp) {
-#pragma unroll
-      for (int j = 0; j < PPT2; ++j)
-        if (qx0 + j < W) {
-          const float qd = depth_at(dsrc, qy, qx0 + j, H, W);
-          gdepth[j] *= -dsrc.span * qd * qd;
-        }
-    }
-    float* o = a.grad_depth + sb * hw + qy * W + qx0;
-    if ((qx0 + PPT2 <= W) && ((W & 1) == 0)) {
-      *reinterpret_cast<float2*>(o) = make_float2(gdepth[0], gdepth[1]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPT2; ++j)
-        if (qx0 + j < W) o[j] = gdepth[j];
-    }
-  }
-  BBD_STAMP(20);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2973,21 +2117,15 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
   a.remap = xcd_remap_enabled(S);
-  // BBD_FWD=2: the paired-candidate / packed-SSIM form (experimental, slower so far: profiles/r03/fwdp_ab.txt)
-  static const int form = [] { const char* e = getenv("BBD_FWD"); return e ? atoi(e) : 1; }();
+  // (a paired-candidate / packed-SSIM form of this kernel was built and measured slower - profiles/r03/fwdp_ab.txt; its
+  // source is kept under tools/experiments/paired_packed_forward.hip.txt)
   // BBD_FWD_SCALE_LOOP=1: one workgroup per (sample, tile) walks the scales (set-up once).  Measured neutral inside the
   // training step (0.1760 vs 0.1761 ms) and 15 % slower on the micro-benchmark (4x fewer, 4x longer workgroups: the
   // set-up it saves was already hidden by the other resident workgroups) - off (profiles/r03/fwd_scale_loop_ab.txt)
   static const int scale_loop = [] { const char* e = getenv("BBD_FWD_SCALE_LOOP"); return e ? atoi(e) : 0; }();
-  a.scale_loop = 0;
-  if (form == 2) {
-    hipLaunchKernelGGL(warp_ssim_min_fwdp_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
-                       static_cast<hipStream_t>(stream), a);
-  } else {
-    a.scale_loop = (S > 1 && scale_loop) ? 1 : 0;
-    hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)((a.scale_loop ? 1 : S) * B * a.ntiles)), dim3(NT), 0,
-                       static_cast<hipStream_t>(stream), a);
-  }
+  a.scale_loop = (S > 1 && scale_loop) ? 1 : 0;
+  hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)((a.scale_loop ? 1 : S) * B * a.ntiles)), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 
@@ -3011,14 +2149,8 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
   a.remap = xcd_remap_enabled(S);
-  // BBD_BWD=3: the sparse-item form (experimental: equal on per-pixel random disparities, slower inside the training
-  // step - profiles/r03/bwd3_*.txt)
-  static const int form = [] { const char* e = getenv("BBD_BWD"); return e ? atoi(e) : 2; }();
-  if (form == 3) {
-    hipLaunchKernelGGL(warp_ssim_min_bwd3_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
-                       static_cast<hipStream_t>(stream), a);
-    return launch_status();
-  }
+  // (a sparse-item form of this kernel - per-candidate winner lists, scatter instead of the dense phases - was built and
+  // measured slower inside the training step: profiles/r03/bwd3_*.txt, tools/experiments/sparse_item_backward.hip.txt)
   hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
                      static_cast<hipStream_t>(stream), a);
   return launch_status();
