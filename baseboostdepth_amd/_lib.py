@@ -95,7 +95,7 @@ SIGNATURES = {
     "bbd_token_ln_fwd": [_p] * 8 + [_i, _i, _i, _d, _p],
     "bbd_token_ln_bwd": [_p] * 11 + [_i, _i, _i, _p],
     "bbd_dwconv_tokens_wgrad_scratch_floats": [_i, _i, _i, _i, _i],
-    "bbd_dwconv_tokens_wgrad": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "bbd_dwconv_tokens_wgrad": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
 }
 RESAMPLE_JOB, RESAMPLE_FLIP, JITTER_JOB, CONVERT_JOB = 12, 1, 12, 4
 EVAL_DESC, EVAL_OUT = 8, 12

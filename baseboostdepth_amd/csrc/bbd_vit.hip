@@ -149,7 +149,7 @@ constexpr int RL = NT / 64;        // row lanes of the 256-thread combine kernel
 constexpr int WRL = 16;            // row lanes of the weight-gradient column sum (1 024-thread blocks)
 __global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
                                                                            float* __restrict__ dw, float* __restrict__ dbias,
-                                                                           int rows, int C, int kk) {
+                                                                           int rows, int C, int kk, int accumulate) {
   __shared__ double sh[WRL][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int id = blockIdx.x * 64 + cl;
@@ -164,8 +164,10 @@ __global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_kernel(con
 #pragma unroll
   for (int q = 1; q < WRL; ++q) t += sh[q][cl];
   const int c = id / (kk + 1), tap = id - c * (kk + 1);
-  if (tap < kk) dw[c * kk + tap] = (float)t;
-  else if (dbias) dbias[c] = (float)t;
+  // `accumulate`: added to what the gradient buffers hold (a parameter shared by several layers: the layers' launches
+  // run one after the other on one stream, in backward order, so the sum has a fixed order)
+  if (tap < kk) dw[c * kk + tap] = (accumulate ? dw[c * kk + tap] : 0.0f) + (float)t;
+  else if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.0f) + (float)t;
 }
 
 // partial rows of the weight-gradient launch: enough workgroups to fill the chip (~768 with the channel tiles), at most
@@ -456,7 +458,8 @@ long bbd_dwconv_tokens_wgrad_scratch_floats(int B, int H, int W, int C, int k) {
 }
 
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
-                            float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, void* stream) {
+                            float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, int accumulate,
+                            void* stream) {
   if (!x || !grad_y || !partial || !grad_weight || B <= 0 || H <= 0 || W <= 0 || C <= 0) return BBD_E_BADARG;
   if (k != 3 && k != 5 && k != 7) return BBD_E_BADARG;
   const long segs = (long)B * H * ((W + WCH - 1) / WCH);
@@ -468,7 +471,7 @@ int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int 
   else hipLaunchKernelGGL(dwconv_tokens_wgrad_kernel<7>, grid, dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial, B, H, W, C);
   const int cols = C * (k * k + 1);
   hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64 * WRL), 0, st, partial,
-                     grad_weight, grad_bias, rows, C, k * k);
+                     grad_weight, grad_bias, rows, C, k * k, accumulate);
   return launch_status();
 }
 

@@ -217,9 +217,9 @@ class ConvPosEnc(nn.Module):
         super().__init__()
         self.proj = nn.Conv2d(dim, dim, k, 1, k // 2, groups=dim)
 
-    def forward(self, x, size):
+    def forward(self, x, size, share=None):
         if _hip_tokens(x):           # one HIP launch, residual folded in (csrc/bbd_vit.hip)
-            return ops.dwconv_tokens(x, size, [self.proj], add_input=True)
+            return ops.dwconv_tokens(x, size, [self.proj], add_input=True, share=share)
         img = _as_image(x, size)
         return _as_tokens(self.proj(img) + img)
 
@@ -272,7 +272,7 @@ class FactorAtt_ConvRelPosEnc(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.crpe = shared_crpe
 
-    def forward(self, x, size):
+    def forward(self, x, size, share=None):
         B, N, C = x.shape
         h = self.num_heads
         hip = _hip_tokens(x)
@@ -281,7 +281,7 @@ class FactorAtt_ConvRelPosEnc(nn.Module):
             # two HIP ops on the packed activation: conv(v) read in place from the v third, then column
             # statistics of k + [Ch x Ch] contexts + the token-parallel output (csrc/bbd_vit.hip)
             if ops.FUSED_TOKEN_GLUE:     # one autograd node: the conv's data gradient lands in gqkv's v third in place
-                out = ops.factor_attention_crpe(qkv, size, list(self.crpe.conv_list), h, self.scale)
+                out = ops.factor_attention_crpe(qkv, size, list(self.crpe.conv_list), h, self.scale, share=share)
             else:
                 convv = self.crpe.conv_v(qkv[:, :, 2 * C:], size)
                 out = ops.factor_attention(qkv, convv, h, self.scale)
@@ -313,14 +313,17 @@ class MHCABlock(nn.Module):
     def _drop_scale(self, x):
         return self.drop_path.scale(x) if isinstance(self.drop_path, DropPath) else None
 
-    def forward(self, x, size):
+    def forward(self, x, size, share=None):
+        """`share` = (cpe sink, crpe sink, layer index, layer count) from the MHCAEncoder whose blocks share the position
+        encodings: their weight gradients are summed inside the HIP launches (ops.SharedGrads)."""
         if self.cpe is not None:
-            x = self.cpe(x, size)
+            x = self.cpe(x, size, (share[0], share[2], share[3])) if share is not None else self.cpe(x, size)
         if _hip_tokens(x) and ops.FUSED_TOKEN_GLUE and ops.token_glue_supported(x):
             # residual + stochastic depth + the NEXT LayerNorm as one pass each way (csrc/bbd_tokens.hip); the two
             # stochastic-depth draws happen in the reference's order
-            x, z = ops.layernorm_tokens(x, self.norm1, passthrough=True)     # x comes back as an output of the node: the
-            att = self.factoratt_crpe(z, size)                                # residual's gradient meets LayerNorm's inside
+            # (x comes back as an output of the LayerNorm node: the residual's gradient meets LayerNorm's inside the kernel)
+            x, z = ops.layernorm_tokens(x, self.norm1, passthrough=True)
+            att = self.factoratt_crpe(z, size, (share[1], share[2], share[3]) if share is not None else None)
             x, z = ops.residual_layernorm(x, att, self._drop_scale(x), self.norm2)
             return ops.residual_add(x, self.mlp(z), self._drop_scale(x))
         x = x + self.drop_path(self.factoratt_crpe(self.norm1(x), size))
@@ -339,11 +342,14 @@ class MHCAEncoder(nn.Module):
         self.MHCA_layers = nn.ModuleList([
             MHCABlock(dim, num_heads=num_heads, mlp_ratio=mlp_ratio, drop_path=drop_path_list[i], qk_scale=qk_scale,
                       shared_cpe=self.cpe, shared_crpe=self.crpe) for i in range(num_layers)])
+        self._cpe_grads, self._crpe_grads = ops.SharedGrads(), ops.SharedGrads()
 
     def forward(self, x, size):
         """[B, N, C] tokens -> [B, C, H, W] feature map (channels-last memory, zero-copy)."""
-        for layer in self.MHCA_layers:
-            x = layer(x, size)
+        fused = _hip_tokens(x) and ops.FUSED_TOKEN_GLUE and ops.token_glue_supported(x) and torch.is_grad_enabled()
+        n = len(self.MHCA_layers)
+        for i, layer in enumerate(self.MHCA_layers):
+            x = layer(x, size, (self._cpe_grads, self._crpe_grads, i, n) if (fused and n > 1) else None)
         return _as_image(x, size)
 
 

@@ -609,6 +609,42 @@ def _slice_ptr(t, c0):
     return ctypes.c_void_p(t.data_ptr() + 4 * c0)
 
 
+class SharedGrads:
+    """Gradient accumulation for parameters that several layers of one sequential chain share (MPViT's MHCAEncoder: the
+    blocks of a path share one ConvPosEnc and one ConvRelPosEnc).  As plain autograd every extra use costs an
+    AccumulateGrad add per parameter - ~270 tiny launches per MonoViT step, each a cross-stream fork/join inside the
+    step graph.  Here the layers' weight-gradient launches add into ONE buffer per parameter (the kernel's `accumulate`
+    mode; backward runs the layers last to first, on one stream) and only the chain's first layer hands it to autograd."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def target(self, key, like, index, count):
+        """(buffer to write the gradient into, accumulate flag) for layer `index` of `count`."""
+        if index == count - 1 or key not in self.buf:       # the layer whose backward runs first starts the sum
+            self.buf[key] = torch.empty_like(like)
+            return self.buf[key], 0
+        return self.buf[key], 1
+
+    def result(self, key, index):
+        """What the layer returns to autograd for this parameter: the finished sum from layer 0, nothing from the others."""
+        return self.buf.pop(key) if index == 0 else None
+
+
+def _wgrad_target(share, tag, like):
+    if share is None:
+        return torch.empty_like(like), 0
+    sink, index, count = share
+    return sink.target(tag, like, index, count)
+
+
+def _wgrad_result(share, tag, tensor):
+    if share is None:
+        return tensor
+    sink, index, _ = share
+    return sink.result(tag, index)
+
+
 class _DepthwiseTokens(torch.autograd.Function):
     """Depth-wise k x k convolutions over token-layout activations [B, H*W, C] (csrc/bbd_vit.hip): channel
     groups `splits` use their own (weight [n,1,k,k], bias [n]) - MPViT's ConvRelPosEnc gives head groups
@@ -616,7 +652,7 @@ class _DepthwiseTokens(torch.autograd.Function):
     channel-slice view of wider rows (v inside the packed qkv activation)."""
 
     @staticmethod
-    def forward(ctx, x, H, W, add_input, backend, splits, *params):
+    def forward(ctx, x, H, W, add_input, backend, splits, share, *params):
         B, N, C = x.shape
         assert N == H * W and sum(splits) == C and x.dtype == torch.float32
         if x.stride(2) != 1 or x.stride(0) != N * x.stride(1):
@@ -630,13 +666,13 @@ class _DepthwiseTokens(torch.autograd.Function):
                         B, H, W, n, w.shape[-1], int(add_input), 0)
             c0 += n
         ctx.save_for_backward(x, *params)
-        ctx.meta = (H, W, bool(add_input), backend, tuple(splits))
+        ctx.meta = (H, W, bool(add_input), backend, tuple(splits), share)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        H, W, add_input, backend, splits = ctx.meta
+        H, W, add_input, backend, splits, share = ctx.meta
         B, N, C = x.shape
         gy = gy.contiguous()
         gx = torch.empty(B, N, C, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
@@ -647,23 +683,24 @@ class _DepthwiseTokens(torch.autograd.Function):
             if gx is not None:
                 backend.run("bbd_dwconv_tokens_fwd", gy, _slice_ptr(gy, c0), C, ptr(w), ptr(None), _slice_ptr(gx, c0), C,
                             B, H, W, n, k, int(add_input), 1)
-            gw = torch.empty_like(w)
-            gb = torch.empty_like(b) if b is not None else None
+            gw, acc = _wgrad_target(share, ("w", i), w)
+            gb = _wgrad_target(share, ("b", i), b)[0] if b is not None else None
             scratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, n, k), device=x.device, dtype=torch.float32)
             backend.run("bbd_dwconv_tokens_wgrad", x, _slice_ptr(x, c0), x.stride(1), _slice_ptr(gy, c0), C, ptr(scratch),
-                        ptr(gw), ptr(gb), B, H, W, n, k)
-            grads += [gw, gb]
+                        ptr(gw), ptr(gb), B, H, W, n, k, acc)
+            grads += [_wgrad_result(share, ("w", i), gw), _wgrad_result(share, ("b", i), gb) if b is not None else None]
             c0 += n
-        return (gx, None, None, None, None, None) + tuple(grads)
+        return (gx, None, None, None, None, None, None) + tuple(grads)
 
 
-def dwconv_tokens(x, size, convs, add_input=False, backend=None):
-    """`convs`: list of nn.Conv2d (depth-wise, stride 1, padding k//2) covering consecutive channel groups."""
+def dwconv_tokens(x, size, convs, add_input=False, backend=None, share=None):
+    """`convs`: list of nn.Conv2d (depth-wise, stride 1, padding k//2) covering consecutive channel groups.
+    `share` = (SharedGrads, layer index, layer count) when the convs' parameters are shared by a chain of layers."""
     params, splits = [], []
     for conv in convs:
         params += [conv.weight, conv.bias]
         splits.append(conv.weight.shape[0])
-    return _DepthwiseTokens.apply(x, size[0], size[1], add_input, backend or default_backend(), tuple(splits), *params)
+    return _DepthwiseTokens.apply(x, size[0], size[1], add_input, backend or default_backend(), tuple(splits), share, *params)
 
 
 class _FactorAttention(torch.autograd.Function):
@@ -715,7 +752,7 @@ class _FactorAttentionCRPE(torch.autograd.Function):
     [B,N,3C] tensors: three passes over the widest activation of the block, per block."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, scale, H, W, backend, splits, *params):
+    def forward(ctx, qkv, heads, scale, H, W, backend, splits, share, *params):
         B, N, C3 = qkv.shape
         C = C3 // 3
         Ch = C // heads
@@ -738,14 +775,14 @@ class _FactorAttentionCRPE(torch.autograd.Function):
         backend.run("bbd_factor_att_fwd", qkv, ptr(qkv), ptr(convv), ptr(kmax), ptr(krsum), ptr(ctxs), ptr(scratch),
                     ptr(out), B, N, C, Ch, float(scale))
         ctx.save_for_backward(qkv, convv, kmax, krsum, ctxs, *params)
-        ctx.meta = (heads, float(scale), H, W, backend, tuple(splits))
+        ctx.meta = (heads, float(scale), H, W, backend, tuple(splits), share)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         qkv, convv, kmax, krsum, ctxs = ctx.saved_tensors[:5]
         params = ctx.saved_tensors[5:]
-        heads, scale, H, W, backend, splits = ctx.meta
+        heads, scale, H, W, backend, splits, share = ctx.meta
         B, N, C3 = qkv.shape
         C = C3 // 3
         Ch = C // heads
@@ -763,23 +800,25 @@ class _FactorAttentionCRPE(torch.autograd.Function):
             k = w.shape[-1]
             backend.run("bbd_dwconv_tokens_fwd", gconvv, _slice_ptr(gconvv, c0), C, ptr(w), ptr(None), _slice_ptr(gqkv, 2 * C + c0),
                         C3, B, H, W, n, k, 2, 1)                    # accumulate into the v third
-            gw = torch.empty_like(w)
-            gb = torch.empty_like(b) if b is not None else None
+            gw, acc = _wgrad_target(share, ("w", i), w)
+            gb = _wgrad_target(share, ("b", i), b)[0] if b is not None else None
             wscratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, n, k), device=dev, dtype=torch.float32)
             backend.run("bbd_dwconv_tokens_wgrad", qkv, _slice_ptr(qkv, 2 * C + c0), C3, _slice_ptr(gconvv, c0), C, ptr(wscratch),
-                        ptr(gw), ptr(gb), B, H, W, n, k)
-            grads += [gw, gb]
+                        ptr(gw), ptr(gb), B, H, W, n, k, acc)
+            grads += [_wgrad_result(share, ("w", i), gw), _wgrad_result(share, ("b", i), gb) if b is not None else None]
             c0 += n
-        return (gqkv, None, None, None, None, None, None) + tuple(grads)
+        return (gqkv, None, None, None, None, None, None, None) + tuple(grads)
 
 
-def factor_attention_crpe(qkv, size, convs, heads, scale, backend=None):
-    """Factorised attention with MPViT's ConvRelPosEnc of v computed inside (`convs`: its depth-wise nn.Conv2d list)."""
+def factor_attention_crpe(qkv, size, convs, heads, scale, backend=None, share=None):
+    """Factorised attention with MPViT's ConvRelPosEnc of v computed inside (`convs`: its depth-wise nn.Conv2d list;
+    `share`: see dwconv_tokens)."""
     params, splits = [], []
     for conv in convs:
         params += [conv.weight, conv.bias]
         splits.append(conv.weight.shape[0])
-    return _FactorAttentionCRPE.apply(qkv, heads, scale, size[0], size[1], backend or default_backend(), tuple(splits), *params)
+    return _FactorAttentionCRPE.apply(qkv, heads, scale, size[0], size[1], backend or default_backend(), tuple(splits), share,
+                                      *params)
 
 
 def factor_attention(qkv, convv, heads, scale, backend=None):

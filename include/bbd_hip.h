@@ -390,12 +390,15 @@ int bbd_bias_elu_bwd(const float* y, const float* grad_y, float* grad_x, float* 
  *           residual's gradient, bit 1 lets it land in a slice that already holds another contribution).
  *   wgrad : grad_weight [C,k,k], grad_bias [C] (or NULL); partial = scratch of
  *           bbd_dwconv_tokens_wgrad_scratch_floats(B,H,W,C,k) floats.  Deterministic (one partial row per
- *           workgroup, a fixed-order column sum in fp64).                                                */
+ *           workgroup, a fixed-order column sum in fp64).  accumulate != 0: added to grad_weight / grad_bias
+ *           (a parameter shared by several layers - MPViT's MHCAEncoder shares its position encodings - whose
+ *           launches follow each other on one stream).                                                   */
 long bbd_dwconv_tokens_wgrad_scratch_floats(int B, int H, int W, int C, int k);
 int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const float* bias, float* y, int y_row,
                           int B, int H, int W, int C, int k, int add_input, int flip, void* stream);
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
-                            float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, void* stream);
+                            float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, int accumulate,
+                            void* stream);
 
 /* Residual + stochastic depth + LayerNorm on token-layout activations [rows = B*N, C] (csrc/bbd_tokens.hip), the glue of
  * the reference's MHCABlock (networksvit/mpvit.py:397-440: x = x + drop_path(branch); z = norm(x)) as one pass each way.
