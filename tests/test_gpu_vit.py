@@ -152,7 +152,8 @@ def test_factorised_attention_matches_torch(B, H, W, C, heads):
 
 @pytest.mark.parametrize("B,N,C,branch,drop", [(3, 37, 64, True, True), (2, 130, 128, True, False), (2, 61, 216, True, True),
                                                (5, 9, 288, True, True), (1, 7, 512, True, False), (3, 50, 64, False, False),
-                                               (2, 33, 216, False, False)])
+                                               (2, 33, 216, False, False), (1, 5, 8, True, True), (2, 3, 1024, True, True),
+                                               (1, 1, 4, False, False), (12, 1920, 128, True, True)])
 def test_residual_droppath_layernorm_matches_torch(B, N, C, branch, drop):
     """csrc/bbd_tokens.hip against the eager formulation of reference networksvit/mpvit.py:397-440
     (x + drop_path(branch), LayerNorm): both outputs and all five gradients, 2e-5 of each tensor's maximum."""
@@ -251,7 +252,8 @@ def test_shipped_gemm_table_drives_tunableop_without_tuning():
     assert tunable.get_filename() == path
 
 
-@pytest.mark.parametrize("B,N,cin,cout", [(3, 37, 64, 192), (2, 129, 216, 648), (1, 3, 288, 1152), (12, 480, 216, 216), (2, 50, 64, 62)])
+@pytest.mark.parametrize("B,N,cin,cout", [(3, 37, 64, 192), (2, 129, 216, 648), (1, 3, 288, 1152), (12, 480, 216, 216), (2, 50, 64, 62),
+                                          (1, 1, 8, 4), (12, 7680, 64, 256)])
 def test_linear_on_tokens_with_column_sum_bias_gradient(B, N, cin, cout):
     """ops.linear_tokens (bias gradient by bbd_colsum) against nn.Linear's own autograd; an output width that is not a
     multiple of 4 takes the module itself."""
