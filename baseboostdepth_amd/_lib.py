@@ -94,6 +94,9 @@ SIGNATURES = {
     "bbd_token_ln_scratch_floats": [_i, _i],
     "bbd_token_ln_fwd": [_p] * 8 + [_i, _i, _i, _d, _p],
     "bbd_token_ln_bwd": [_p] * 11 + [_i, _i, _i, _p],
+    "bbd_dwconv_tokens_groups_fwd": [_p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "bbd_dwconv_tokens_groups_wgrad_scratch_floats": [_i, _i, _i, _i, _p, _p],
+    "bbd_dwconv_tokens_groups_wgrad": [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_dwconv_tokens_wgrad_scratch_floats": [_i, _i, _i, _i, _i],
     "bbd_dwconv_tokens_wgrad": [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
 }
@@ -141,6 +144,9 @@ class HipLibrary:
 
     def bn_grouped_scratch_doubles(self, max_rows, G, C, HW):
         return self._dll.bbd_bn_grouped_scratch_doubles(max_rows, G, C, HW)
+
+    def dwconv_groups_wgrad_scratch_floats(self, B, H, W, n, cn, k):
+        return self._dll.bbd_dwconv_tokens_groups_wgrad_scratch_floats(B, H, W, n, cn, k)
 
     def dwconv_wgrad_scratch_floats(self, B, H, W, C, k):
         return self._dll.bbd_dwconv_tokens_wgrad_scratch_floats(B, H, W, C, k)

@@ -26,14 +26,13 @@ constexpr int PW = 4;     // output pixels per thread along W
 // (add_in & 2: added to what y already holds - a data gradient landing in a slice that has another contribution)
 // FLIP reads the taps mirrored: the same kernel is the data gradient (x := dy, no bias).
 template <int K, bool FLIP>
-__global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restrict__ x, int x_row,
-                                                           const float* __restrict__ wt, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int y_row, int B, int H, int W, int C,
-                                                           int add_in) {
+__device__ __forceinline__ void dwconv_tokens_body(const float* __restrict__ x, int x_row, const float* __restrict__ wt,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int y_row, int B,
+                                                   int H, int W, int C, int add_in, long block) {
   constexpr int P = K / 2;
   const int wq = (W + PW - 1) / PW;
   const long total = (long)B * H * wq * C;
-  const long id = (long)blockIdx.x * NT + threadIdx.x;
+  const long id = block * NT + threadIdx.x;
   if (id >= total) return;
   const int c = (int)(id % C);
   long t = id / C;
@@ -75,6 +74,50 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restri
     if (w0 + q < W) yo[(long)q * y_row] = (add_in & 2) ? yo[(long)q * y_row] + acc[q] : acc[q];     // bit 1: accumulate into y
 }
 
+template <int K, bool FLIP>
+__global__ __launch_bounds__(NT) void dwconv_tokens_kernel(const float* __restrict__ x, int x_row,
+                                                           const float* __restrict__ wt, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int y_row, int B, int H, int W, int C,
+                                                           int add_in) {
+  dwconv_tokens_body<K, FLIP>(x, x_row, wt, bias, y, y_row, B, H, W, C, add_in, (long)blockIdx.x);
+}
+
+// Several channel groups with their own window size in ONE launch (MPViT's ConvRelPosEnc: head groups with windows 3 / 5 /
+// 7): a workgroup belongs to one group (block ranges of the 1-D grid), so there is no divergence inside a wave.
+constexpr int DW_MAX_GROUPS = 4;
+struct DwGroups {
+  int n;
+  int c0[DW_MAX_GROUPS], cn[DW_MAX_GROUPS], k[DW_MAX_GROUPS];
+  const float* w[DW_MAX_GROUPS];
+  const float* b[DW_MAX_GROUPS];
+  float* gw[DW_MAX_GROUPS];
+  float* gb[DW_MAX_GROUPS];
+  unsigned block0[DW_MAX_GROUPS + 1];      // first block of every group in the launch's x dimension
+  unsigned fblock0[DW_MAX_GROUPS + 1];     // the same for the weight gradient's column-sum launch
+  long part0[DW_MAX_GROUPS];               // weight gradient: float offset of the group's partial rows
+};
+__device__ __forceinline__ int dw_group_of(const DwGroups& g, unsigned block) {
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < DW_MAX_GROUPS; ++i)
+    if (i < g.n && block >= g.block0[i]) gi = i;
+  return gi;
+}
+
+template <bool FLIP>
+__global__ __launch_bounds__(NT) void dwconv_tokens_groups_kernel(const float* __restrict__ x, int x_row, float* __restrict__ y,
+                                                                  int y_row, DwGroups g, int B, int H, int W, int add_in) {
+  const int gi = dw_group_of(g, blockIdx.x);
+  const long block = (long)(blockIdx.x - g.block0[gi]);
+  const float* xs = x + g.c0[gi];
+  float* ys = y + g.c0[gi];
+  switch (g.k[gi]) {
+    case 3: dwconv_tokens_body<3, FLIP>(xs, x_row, g.w[gi], g.b[gi], ys, y_row, B, H, W, g.cn[gi], add_in, block); break;
+    case 5: dwconv_tokens_body<5, FLIP>(xs, x_row, g.w[gi], g.b[gi], ys, y_row, B, H, W, g.cn[gi], add_in, block); break;
+    default: dwconv_tokens_body<7, FLIP>(xs, x_row, g.w[gi], g.b[gi], ys, y_row, B, H, W, g.cn[gi], add_in, block); break;
+  }
+}
+
 // Weight / bias gradient.  A workgroup = 64 channels x 4 segment lanes: a thread walks row segments of WCH pixels
 // (seg = blockIdx.y * 4 + lane, stride 4 * gridDim.y), sliding the k-wide window of x through registers, and keeps its
 // k*k + 1 sums in registers over ALL its segments; the four segment lanes combine through LDS in a fixed order and the
@@ -85,15 +128,15 @@ constexpr int WCH = 8;
 constexpr int WG_SEG_LANES = NT / 64;
 constexpr int WGRAD_MAX_ROWS = 256;
 template <int K>
-__global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __restrict__ x, int x_row,
-                                                                 const float* __restrict__ dy, int dy_row,
-                                                                 float* __restrict__ partial, int B, int H, int W, int C) {
+__device__ __forceinline__ void dwconv_tokens_wgrad_body(const float* __restrict__ x, int x_row, const float* __restrict__ dy,
+                                                         int dy_row, float* __restrict__ partial, int B, int H, int W, int C,
+                                                         int tile, float* sh_raw) {
   constexpr int P = K / 2;
-  __shared__ float sh[WG_SEG_LANES - 1][K * K + 1][64];
+  float (*sh)[K * K + 1][64] = reinterpret_cast<float (*)[K * K + 1][64]>(sh_raw);      // [WG_SEG_LANES - 1][K*K+1][64]
   const int wseg = (W + WCH - 1) / WCH;
   const long segs = (long)B * H * wseg;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = tile * 64 + cl;
   const bool live = c < C;
   float acc[K * K + 1];
 #pragma unroll
@@ -144,15 +187,40 @@ __global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __
   }
 }
 
+template <int K>
+__global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_kernel(const float* __restrict__ x, int x_row,
+                                                                 const float* __restrict__ dy, int dy_row,
+                                                                 float* __restrict__ partial, int B, int H, int W, int C) {
+  __shared__ float sh[(WG_SEG_LANES - 1) * (K * K + 1) * 64];
+  dwconv_tokens_wgrad_body<K>(x, x_row, dy, dy_row, partial, B, H, W, C, (int)blockIdx.x, sh);
+}
+
+__global__ __launch_bounds__(NT) void dwconv_tokens_wgrad_groups_kernel(const float* __restrict__ x, int x_row,
+                                                                        const float* __restrict__ dy, int dy_row,
+                                                                        float* __restrict__ partial, DwGroups g, int B, int H,
+                                                                        int W) {
+  __shared__ float sh[(WG_SEG_LANES - 1) * (7 * 7 + 1) * 64];
+  const int gi = dw_group_of(g, blockIdx.x);
+  const int tile = (int)(blockIdx.x - g.block0[gi]);
+  const float* xs = x + g.c0[gi];
+  const float* ds = dy + g.c0[gi];
+  float* ps = partial + g.part0[gi];
+  switch (g.k[gi]) {
+    case 3: dwconv_tokens_wgrad_body<3>(xs, x_row, ds, dy_row, ps, B, H, W, g.cn[gi], tile, sh); break;
+    case 5: dwconv_tokens_wgrad_body<5>(xs, x_row, ds, dy_row, ps, B, H, W, g.cn[gi], tile, sh); break;
+    default: dwconv_tokens_wgrad_body<7>(xs, x_row, ds, dy_row, ps, B, H, W, g.cn[gi], tile, sh); break;
+  }
+}
+
 // column sums with WRL row lanes per column: block = 64 columns x WRL rows, fixed-order combine through LDS
 constexpr int RL = NT / 64;        // row lanes of the 256-thread combine kernels below
 constexpr int WRL = 16;            // row lanes of the weight-gradient column sum (1 024-thread blocks)
-__global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
-                                                                           float* __restrict__ dw, float* __restrict__ dbias,
-                                                                           int rows, int C, int kk, int accumulate) {
+__device__ __forceinline__ void dwconv_tokens_wgrad_final_body(const float* __restrict__ partial, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int rows, int C, int kk,
+                                                               int accumulate, int block) {
   __shared__ double sh[WRL][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int id = blockIdx.x * 64 + cl;
+  const int id = block * 64 + cl;
   const bool live = id < C * (kk + 1);
   double s = 0.0;
   if (live)
@@ -168,6 +236,22 @@ __global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_kernel(con
   // run one after the other on one stream, in backward order, so the sum has a fixed order)
   if (tap < kk) dw[c * kk + tap] = (accumulate ? dw[c * kk + tap] : 0.0f) + (float)t;
   else if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.0f) + (float)t;
+}
+
+__global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_kernel(const float* __restrict__ partial,
+                                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                                           int rows, int C, int kk, int accumulate) {
+  dwconv_tokens_wgrad_final_body(partial, dw, dbias, rows, C, kk, accumulate, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(64 * WRL) void dwconv_tokens_wgrad_final_groups_kernel(const float* __restrict__ partial, DwGroups g,
+                                                                                  int rows, int accumulate) {
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < DW_MAX_GROUPS; ++i)
+    if (i < g.n && blockIdx.x >= g.fblock0[i]) gi = i;
+  dwconv_tokens_wgrad_final_body(partial + g.part0[gi], g.gw[gi], g.gb[gi], rows, g.cn[gi], g.k[gi] * g.k[gi], accumulate,
+                                 (int)(blockIdx.x - g.fblock0[gi]));
 }
 
 // partial rows of the weight-gradient launch: enough workgroups to fill the chip (~768 with the channel tiles), at most
@@ -472,6 +556,83 @@ int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int 
   const int cols = C * (k * k + 1);
   hipLaunchKernelGGL(dwconv_tokens_wgrad_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64 * WRL), 0, st, partial,
                      grad_weight, grad_bias, rows, C, k * k, accumulate);
+  return launch_status();
+}
+
+// ---- several channel groups in one launch ----------------------------------------------------------------------------
+static int fill_groups(DwGroups* g, int n, const int32_t* c0, const int32_t* cn, const int32_t* k, const void* const* w,
+                       const void* const* b) {
+  if (n < 1 || n > DW_MAX_GROUPS || !c0 || !cn || !k || !w) return 1;
+  g->n = n;
+  for (int i = 0; i < DW_MAX_GROUPS; ++i) {
+    const bool on = i < n;
+    g->c0[i] = on ? c0[i] : 0; g->cn[i] = on ? cn[i] : 0; g->k[i] = on ? k[i] : 3;
+    g->w[i] = on ? static_cast<const float*>(w[i]) : nullptr;
+    g->b[i] = (on && b) ? static_cast<const float*>(b[i]) : nullptr;
+    g->gw[i] = nullptr; g->gb[i] = nullptr; g->part0[i] = 0;
+    if (on && (g->cn[i] <= 0 || !g->w[i] || (g->k[i] != 3 && g->k[i] != 5 && g->k[i] != 7))) return 1;
+  }
+  return 0;
+}
+
+int bbd_dwconv_tokens_groups_fwd(const float* x, int x_row, float* y, int y_row, int n_groups, const int32_t* c0,
+                                 const int32_t* cn, const int32_t* k, const void* const* weights, const void* const* biases,
+                                 int B, int H, int W, int add_input, int flip, void* stream) {
+  DwGroups g;
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || fill_groups(&g, n_groups, c0, cn, k, weights, biases)) return BBD_E_BADARG;
+  unsigned at = 0;
+  for (int i = 0; i < n_groups; ++i) {
+    if (c0[i] + cn[i] > x_row || c0[i] + cn[i] > y_row) return BBD_E_BADARG;
+    g.block0[i] = at;
+    const long total = (long)B * H * ((W + PW - 1) / PW) * cn[i];
+    at += (unsigned)((total + NT - 1) / NT);
+  }
+  for (int i = n_groups; i <= DW_MAX_GROUPS; ++i) g.block0[i] = at;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (flip) hipLaunchKernelGGL(dwconv_tokens_groups_kernel<true>, dim3(at), dim3(NT), 0, st, x, x_row, y, y_row, g, B, H, W, add_input);
+  else hipLaunchKernelGGL(dwconv_tokens_groups_kernel<false>, dim3(at), dim3(NT), 0, st, x, x_row, y, y_row, g, B, H, W, add_input);
+  return launch_status();
+}
+
+static int groups_wgrad_rows(long segs, int n, const int32_t* cn) {
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (cn[i] + 63) / 64;
+  return wgrad_rows(segs, tiles * 64);
+}
+
+long bbd_dwconv_tokens_groups_wgrad_scratch_floats(int B, int H, int W, int n_groups, const int32_t* cn, const int32_t* k) {
+  if (n_groups < 1 || n_groups > DW_MAX_GROUPS || !cn || !k) return 0;
+  const long segs = (long)B * H * ((W + WCH - 1) / WCH);
+  const int rows = groups_wgrad_rows(segs, n_groups, cn);
+  long total = 0;
+  for (int i = 0; i < n_groups; ++i) total += (long)rows * cn[i] * (k[i] * k[i] + 1);
+  return total;
+}
+
+int bbd_dwconv_tokens_groups_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial, int n_groups,
+                                   const int32_t* c0, const int32_t* cn, const int32_t* k, const void* const* grad_weights,
+                                   const void* const* grad_biases, int B, int H, int W, int accumulate, void* stream) {
+  DwGroups g;
+  if (!x || !grad_y || !partial || B <= 0 || H <= 0 || W <= 0 || fill_groups(&g, n_groups, c0, cn, k, grad_weights, grad_biases))
+    return BBD_E_BADARG;
+  const long segs = (long)B * H * ((W + WCH - 1) / WCH);
+  const int rows = groups_wgrad_rows(segs, n_groups, cn);
+  unsigned at = 0, fat = 0;
+  long part = 0;
+  for (int i = 0; i < n_groups; ++i) {
+    g.gw[i] = const_cast<float*>(g.w[i]);          // fill_groups parked the gradient pointers in w / b
+    g.gb[i] = const_cast<float*>(g.b[i]);
+    g.w[i] = nullptr; g.b[i] = nullptr;
+    g.block0[i] = at; g.fblock0[i] = fat; g.part0[i] = part;
+    at += (unsigned)((cn[i] + 63) / 64);
+    fat += (unsigned)((cn[i] * (k[i] * k[i] + 1) + 63) / 64);
+    part += (long)rows * cn[i] * (k[i] * k[i] + 1);
+  }
+  for (int i = n_groups; i <= DW_MAX_GROUPS; ++i) { g.block0[i] = at; g.fblock0[i] = fat; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dwconv_tokens_wgrad_groups_kernel, dim3(at, (unsigned)rows), dim3(NT), 0, st, x, x_row, grad_y, gy_row, partial,
+                     g, B, H, W);
+  hipLaunchKernelGGL(dwconv_tokens_wgrad_final_groups_kernel, dim3(fat), dim3(64 * WRL), 0, st, partial, g, rows, accumulate);
   return launch_status();
 }
 

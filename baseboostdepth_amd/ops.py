@@ -645,6 +645,42 @@ def _wgrad_result(share, tag, tensor):
     return sink.result(tag, index)
 
 
+def _i32_array(values):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def _addr_array(tensors):
+    """Host array of device addresses (0 for None)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t is not None:
+            assert t.is_contiguous() and t.dtype == torch.float32
+            arr[i] = t.data_ptr()
+    return arr
+
+
+def _dw_group_args(splits, weights):
+    c0, at = [], 0
+    for n in splits:
+        c0.append(at)
+        at += n
+    return len(splits), _i32_array(c0), _i32_array(splits), _i32_array([w.shape[-1] for w in weights])
+
+
+def _dwconv_groups_fwd(backend, x, x_base, x_row, y, y_base, y_row, splits, weights, biases, B, H, W, add_input, flip):
+    """One launch for all channel groups (several window sizes); `*_base`: first channel of the slice inside the rows."""
+    n, c0, cn, k = _dw_group_args(splits, weights)
+    backend.run("bbd_dwconv_tokens_groups_fwd", x, _slice_ptr(x, x_base), x_row, _slice_ptr(y, y_base), y_row, n, c0, cn, k,
+                _addr_array(weights), _addr_array(biases), B, H, W, int(add_input), int(flip))
+
+
+def _dwconv_groups_wgrad(backend, x, x_base, x_row, gy, gy_base, gy_row, splits, weights, gws, gbs, B, H, W, accumulate):
+    n, c0, cn, k = _dw_group_args(splits, weights)
+    scratch = torch.empty(backend.lib.dwconv_groups_wgrad_scratch_floats(B, H, W, n, cn, k), device=x.device, dtype=torch.float32)
+    backend.run("bbd_dwconv_tokens_groups_wgrad", x, _slice_ptr(x, x_base), x_row, _slice_ptr(gy, gy_base), gy_row, ptr(scratch),
+                n, c0, cn, k, _addr_array(gws), _addr_array(gbs), B, H, W, int(accumulate))
+
+
 class _DepthwiseTokens(torch.autograd.Function):
     """Depth-wise k x k convolutions over token-layout activations [B, H*W, C] (csrc/bbd_vit.hip): channel
     groups `splits` use their own (weight [n,1,k,k], bias [n]) - MPViT's ConvRelPosEnc gives head groups
@@ -659,12 +695,13 @@ class _DepthwiseTokens(torch.autograd.Function):
             x = x.contiguous()
         backend._check(x, *params)
         y = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
-        c0 = 0
-        for i, n in enumerate(splits):
-            w, b = params[2 * i].contiguous(), params[2 * i + 1]
-            backend.run("bbd_dwconv_tokens_fwd", x, _slice_ptr(x, c0), x.stride(1), ptr(w), ptr(b), _slice_ptr(y, c0), C,
-                        B, H, W, n, w.shape[-1], int(add_input), 0)
-            c0 += n
+        if len(splits) > 1:
+            _dwconv_groups_fwd(backend, x, 0, x.stride(1), y, 0, C, splits, [params[2 * i].contiguous() for i in range(len(splits))],
+                               [params[2 * i + 1] for i in range(len(splits))], B, H, W, add_input, 0)
+        else:
+            w, b = params[0].contiguous(), params[1]
+            backend.run("bbd_dwconv_tokens_fwd", x, ptr(x) if x.is_contiguous() else _slice_ptr(x, 0), x.stride(1), ptr(w), ptr(b),
+                        ptr(y), C, B, H, W, C, w.shape[-1], int(add_input), 0)
         ctx.save_for_backward(x, *params)
         ctx.meta = (H, W, bool(add_input), backend, tuple(splits), share)
         return y
@@ -676,20 +713,27 @@ class _DepthwiseTokens(torch.autograd.Function):
         B, N, C = x.shape
         gy = gy.contiguous()
         gx = torch.empty(B, N, C, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        grads, c0 = [], 0
-        for i, n in enumerate(splits):
-            w, b = params[2 * i].contiguous(), params[2 * i + 1]
-            k = w.shape[-1]
-            if gx is not None:
-                backend.run("bbd_dwconv_tokens_fwd", gy, _slice_ptr(gy, c0), C, ptr(w), ptr(None), _slice_ptr(gx, c0), C,
-                            B, H, W, n, k, int(add_input), 1)
+        ws = [params[2 * i].contiguous() for i in range(len(splits))]
+        bs = [params[2 * i + 1] for i in range(len(splits))]
+        gws, gbs, acc = [], [], 0
+        for i, (w, b) in enumerate(zip(ws, bs)):
             gw, acc = _wgrad_target(share, ("w", i), w)
-            gb = _wgrad_target(share, ("b", i), b)[0] if b is not None else None
-            scratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, n, k), device=x.device, dtype=torch.float32)
-            backend.run("bbd_dwconv_tokens_wgrad", x, _slice_ptr(x, c0), x.stride(1), _slice_ptr(gy, c0), C, ptr(scratch),
-                        ptr(gw), ptr(gb), B, H, W, n, k, acc)
-            grads += [_wgrad_result(share, ("w", i), gw), _wgrad_result(share, ("b", i), gb) if b is not None else None]
-            c0 += n
+            gws.append(gw)
+            gbs.append(_wgrad_target(share, ("b", i), b)[0] if b is not None else None)
+        if len(splits) > 1:
+            if gx is not None:
+                _dwconv_groups_fwd(backend, gy, 0, C, gx, 0, C, splits, ws, [None] * len(ws), B, H, W, add_input, 1)
+            _dwconv_groups_wgrad(backend, x, 0, x.stride(1), gy, 0, C, splits, ws, gws, gbs, B, H, W, acc)
+        else:
+            k = ws[0].shape[-1]
+            if gx is not None:
+                backend.run("bbd_dwconv_tokens_fwd", gy, ptr(gy), C, ptr(ws[0]), ptr(None), ptr(gx), C, B, H, W, C, k, int(add_input), 1)
+            scratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, C, k), device=x.device, dtype=torch.float32)
+            backend.run("bbd_dwconv_tokens_wgrad", x, _slice_ptr(x, 0), x.stride(1), ptr(gy), C, ptr(scratch), ptr(gws[0]), ptr(gbs[0]),
+                        B, H, W, C, k, acc)
+        grads = []
+        for i, b in enumerate(bs):
+            grads += [_wgrad_result(share, ("w", i), gws[i]), _wgrad_result(share, ("b", i), gbs[i]) if b is not None else None]
         return (gx, None, None, None, None, None, None) + tuple(grads)
 
 
@@ -761,12 +805,8 @@ class _FactorAttentionCRPE(torch.autograd.Function):
         backend._check(qkv, *params)
         dev = qkv.device
         convv = torch.empty(B, N, C, device=dev, dtype=torch.float32)
-        c0 = 0
-        for i, n in enumerate(splits):
-            w, b = params[2 * i].contiguous(), params[2 * i + 1]
-            backend.run("bbd_dwconv_tokens_fwd", qkv, _slice_ptr(qkv, 2 * C + c0), C3, ptr(w), ptr(b), _slice_ptr(convv, c0), C,
-                        B, H, W, n, w.shape[-1], 0, 0)
-            c0 += n
+        _dwconv_groups_fwd(backend, qkv, 2 * C, C3, convv, 0, C, splits, [params[2 * i].contiguous() for i in range(len(splits))],
+                           [params[2 * i + 1] for i in range(len(splits))], B, H, W, 0, 0)
         kmax = torch.empty(B, C, device=dev, dtype=torch.float32)
         krsum = torch.empty(B, C, device=dev, dtype=torch.float32)
         ctxs = torch.empty(B, C * Ch, device=dev, dtype=torch.float32)
@@ -794,19 +834,19 @@ class _FactorAttentionCRPE(torch.autograd.Function):
         gconvv = torch.empty_like(convv)
         backend.run("bbd_factor_att_bwd", qkv, ptr(qkv), ptr(convv), ptr(kmax), ptr(krsum), ptr(ctxs), ptr(gout),
                     ptr(dctx), ptr(scratch), ptr(gqkv), ptr(gconvv), B, N, C, Ch, scale)
-        grads, c0 = [], 0
-        for i, n in enumerate(splits):
-            w, b = params[2 * i].contiguous(), params[2 * i + 1]
-            k = w.shape[-1]
-            backend.run("bbd_dwconv_tokens_fwd", gconvv, _slice_ptr(gconvv, c0), C, ptr(w), ptr(None), _slice_ptr(gqkv, 2 * C + c0),
-                        C3, B, H, W, n, k, 2, 1)                    # accumulate into the v third
+        ws = [params[2 * i].contiguous() for i in range(len(splits))]
+        bs = [params[2 * i + 1] for i in range(len(splits))]
+        gws, gbs, acc = [], [], 0
+        for i, (w, b) in enumerate(zip(ws, bs)):
             gw, acc = _wgrad_target(share, ("w", i), w)
-            gb = _wgrad_target(share, ("b", i), b)[0] if b is not None else None
-            wscratch = torch.empty(backend.lib.dwconv_wgrad_scratch_floats(B, H, W, n, k), device=dev, dtype=torch.float32)
-            backend.run("bbd_dwconv_tokens_wgrad", qkv, _slice_ptr(qkv, 2 * C + c0), C3, _slice_ptr(gconvv, c0), C, ptr(wscratch),
-                        ptr(gw), ptr(gb), B, H, W, n, k, acc)
-            grads += [_wgrad_result(share, ("w", i), gw), _wgrad_result(share, ("b", i), gb) if b is not None else None]
-            c0 += n
+            gws.append(gw)
+            gbs.append(_wgrad_target(share, ("b", i), b)[0] if b is not None else None)
+        # data gradient of the convolutions, accumulated into the v third of gqkv; then the weight gradients - one launch each
+        _dwconv_groups_fwd(backend, gconvv, 0, C, gqkv, 2 * C, C3, splits, ws, [None] * len(ws), B, H, W, 2, 1)
+        _dwconv_groups_wgrad(backend, qkv, 2 * C, C3, gconvv, 0, C, splits, ws, gws, gbs, B, H, W, acc)
+        grads = []
+        for i, b in enumerate(bs):
+            grads += [_wgrad_result(share, ("w", i), gws[i]), _wgrad_result(share, ("b", i), gbs[i]) if b is not None else None]
         return (gqkv, None, None, None, None, None, None, None) + tuple(grads)
 
 

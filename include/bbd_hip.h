@@ -399,6 +399,17 @@ int bbd_dwconv_tokens_fwd(const float* x, int x_row, const float* weight, const 
 int bbd_dwconv_tokens_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial,
                             float* grad_weight, float* grad_bias, int B, int H, int W, int C, int k, int accumulate,
                             void* stream);
+/* The same for n_groups <= 4 consecutive-or-not channel groups with their own window sizes in ONE launch each (the head
+ * groups of MPViT's ConvRelPosEnc, networksvit/mpvit.py:262-330): group g covers channels [c0[g], c0[g] + cn[g]) of the
+ * x / y / grad_y rows with window k[g]; weights / biases / grad_weights / grad_biases are HOST arrays of device pointers
+ * (a NULL biases array or entry: no bias).  c0 / cn / k are host arrays.                                              */
+int bbd_dwconv_tokens_groups_fwd(const float* x, int x_row, float* y, int y_row, int n_groups, const int32_t* c0,
+                                 const int32_t* cn, const int32_t* k, const void* const* weights, const void* const* biases,
+                                 int B, int H, int W, int add_input, int flip, void* stream);
+long bbd_dwconv_tokens_groups_wgrad_scratch_floats(int B, int H, int W, int n_groups, const int32_t* cn, const int32_t* k);
+int bbd_dwconv_tokens_groups_wgrad(const float* x, int x_row, const float* grad_y, int gy_row, float* partial, int n_groups,
+                                   const int32_t* c0, const int32_t* cn, const int32_t* k, const void* const* grad_weights,
+                                   const void* const* grad_biases, int B, int H, int W, int accumulate, void* stream);
 
 /* Residual + stochastic depth + LayerNorm on token-layout activations [rows = B*N, C] (csrc/bbd_tokens.hip), the glue of
  * the reference's MHCABlock (networksvit/mpvit.py:397-440: x = x + drop_path(branch); z = norm(x)) as one pass each way.
