@@ -270,3 +270,32 @@ def test_linear_on_tokens_with_column_sum_bias_gradient(B, N, cin, cout):
         res.append([y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()])
     for name, a, b in zip(("y", "grad x", "grad weight", "grad bias"), *res):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6, name
+
+
+@pytest.mark.parametrize("dim,layers,H,W", [(64, 3, 6, 10), (216, 2, 5, 7)])
+def test_encoder_path_with_fused_glue_equals_the_eager_glue(dim, layers, H, W, monkeypatch):
+    """One path of a stage (MHCAEncoder: `layers` blocks sharing their position encodings) with every round-3 fusion on -
+    residual + LayerNorm passes, attention with the position encoding inside, column-sum bias gradients, grouped
+    depth-wise launches, in-kernel accumulation of the shared parameters' gradients - against the same modules with
+    BBD_FUSED_TOKEN_GLUE off (eager ATen glue, autograd's own accumulation): output and every parameter gradient."""
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.networksvit.mpvit import MHCAEncoder
+    torch.manual_seed(dim + layers)
+    enc = MHCAEncoder(dim, num_layers=layers, num_heads=8, mlp_ratio=4, drop_path_list=[0.0] * layers).to(DEV)
+    for p in enc.parameters():                      # non-trivial LayerNorm / bias values
+        with torch.no_grad():
+            p.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(2, H * W, dim, device=DEV, requires_grad=True)
+    w = torch.randn(2, dim, H, W, device=DEV)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "FUSED_TOKEN_GLUE", fused)
+        x.grad = None
+        for p in enc.parameters():
+            p.grad = None
+        y = enc(x, (H, W))
+        (y * w).sum().backward()
+        res.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in enc.parameters()])
+    names = ["output", "grad x"] + [n for n, _ in enc.named_parameters()]
+    for name, a, b in zip(names, *res):
+        assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()) + 1e-7, name
