@@ -720,7 +720,7 @@ struct FwdArgs {
   float* depth_out;     // optional [S,B,H,W]: the depth this launch used (outputs[("depth",0,s)] of the reference)
   DispSrc ds;
   BbdDims dm;
-  int S, B, NP, ntiles, no_ssim, remap, scale_loop;
+  int S, B, NP, ntiles, no_ssim, remap;
 };
 
 #ifndef BBD_FWD_WAVES
@@ -735,16 +735,15 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   int buf = 0;
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
-  // grid order: sample-major, then scale, then tile - or, with the scale loop (S > 1), one workgroup per (sample, tile)
-  // that walks the scales itself: everything that does not depend on the scale (cell tables, the staged target tile,
-  // its window statistics - a quarter of a workgroup's life, profiles/r02/phase_stamps_final.txt) is set up once.
+  // grid order: sample-major, then scale, then tile.  (A form in which one workgroup per (sample, tile) walked the scales
+  // itself - cell tables, staged target tile and window statistics set up once - measured neutral inside the training
+  // step and 15 % slower on the micro-benchmark, and its loop structure alone cost this kernel 14 VGPRs and 19 spilled
+  // SGPRs: removed, profiles/r03/fwd_scale_loop_ab.txt.)
   int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int per_sample = a.scale_loop ? a.ntiles : a.S * a.ntiles;
-  const int b = bid / per_sample;
-  bid -= b * per_sample;
-  const int s_first = a.scale_loop ? 0 : bid / a.ntiles;
-  const int s_end = a.scale_loop ? a.S : s_first + 1;
-  const TileCoord tc = decode_tile(bid - (a.scale_loop ? 0 : s_first * a.ntiles), W);
+  const int b = bid / (a.S * a.ntiles);
+  bid -= b * a.S * a.ntiles;
+  const int s = bid / a.ntiles;
+  const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
   const size_t img = (size_t)3 * hw;
 
   BBD_STAMP_RT(30);
@@ -766,7 +765,6 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
   const int nc = uniform_load(a.ncand + b);
 
-  for (int s = s_first; s < s_end; ++s) {
   const size_t sb = (size_t)s * a.B + b;
   float dcell[Cells<LH, LW, LS, 1>::N];
   const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
@@ -848,7 +846,6 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = wsum;
   __syncthreads();
   if (threadIdx.x == 0) a.partial[sb * a.ntiles + tc.tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-  }     // scales
   BBD_STAMP(20);
   BBD_STAMP_RT(31);
 }
@@ -2119,12 +2116,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.remap = xcd_remap_enabled(S);
   // (a paired-candidate / packed-SSIM form of this kernel was built and measured slower - profiles/r03/fwdp_ab.txt; its
   // source is kept under tools/experiments/paired_packed_forward.hip.txt)
-  // BBD_FWD_SCALE_LOOP=1: one workgroup per (sample, tile) walks the scales (set-up once).  Measured neutral inside the
-  // training step (0.1760 vs 0.1761 ms) and 15 % slower on the micro-benchmark (4x fewer, 4x longer workgroups: the
-  // set-up it saves was already hidden by the other resident workgroups) - off (profiles/r03/fwd_scale_loop_ab.txt)
-  static const int scale_loop = [] { const char* e = getenv("BBD_FWD_SCALE_LOOP"); return e ? atoi(e) : 0; }();
-  a.scale_loop = (S > 1 && scale_loop) ? 1 : 0;
-  hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)((a.scale_loop ? 1 : S) * B * a.ntiles)), dim3(NT), 0,
+  hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
