@@ -331,6 +331,20 @@ __global__ __launch_bounds__(NT) void fa_kstats_combine_kernel(const float* __re
   kmax[id] = m;
   krsum[id] = 1.0f / sum;
 }
+// (token, channel) of element e = threadIdx.x + k * NT of a [tokens, C] tile without a division per element: one division
+// at the start, then NT is added in radix C.
+struct TokChan {
+  int tt, c, q, r;
+  __device__ __forceinline__ TokChan(int C) {
+    q = NT / C; r = NT - q * C;
+    tt = (int)threadIdx.x / C; c = (int)threadIdx.x - tt * C;
+  }
+  __device__ __forceinline__ void next(int C) {
+    c += r; tt += q;
+    if (c >= C) { c -= C; tt += 1; }
+  }
+};
+
 // partial[b, seg, o] = sum over the segment's tokens of A[n, hk(o)] * Bm[n, hv(o)],  o = (h, kc, vc) flattened.
 // SOFTMAX: A = exp(k - kmax) * krsum (the softmax over tokens), Bm = v      -> forward contexts
 // else   : A = q,                                               Bm = dout   -> their gradient
@@ -347,28 +361,43 @@ __global__ __launch_bounds__(NT) void fa_context_kernel(const float* __restrict_
   const int nout = C * Ch;
   float acc[MAXO];
   int ia[MAXO], ib[MAXO];
+  {
+    // output o = threadIdx.x + i * NT = (h, kc, vc): the thread's first output by two divisions, the next ones by adding
+    // NT in mixed radix (Ch, Ch) - the unrolled form with two runtime divisions per output spent more instructions here
+    // (2 x 48 divisions per thread) than in the token loop of a short segment
+    const int q1 = NT / Ch, r1 = NT - q1 * Ch;          // NT = q1 * Ch + r1
+    const int q2 = q1 / Ch, r2 = q1 - q2 * Ch;          // q1 = q2 * Ch + r2
+    int hk0 = threadIdx.x / Ch;
+    int vc = threadIdx.x - hk0 * Ch;
+    int h = hk0 / Ch;
+    int kc = hk0 - h * Ch;
 #pragma unroll
-  for (int i = 0; i < MAXO; ++i) {
-    const int o = threadIdx.x + i * NT;
-    const int oo = o < nout ? o : 0;
-    const int hk = oo / Ch, vc = oo - hk * Ch;
-    ia[i] = hk;
-    ib[i] = (hk / Ch) * Ch + vc;
-    acc[i] = 0.0f;
+    for (int i = 0; i < MAXO; ++i) {
+      const bool on = threadIdx.x + i * NT < nout;
+      ia[i] = on ? h * Ch + kc : 0;
+      ib[i] = on ? h * Ch + vc : 0;
+      acc[i] = 0.0f;
+      vc += r1;
+      kc += r2;
+      if (vc >= Ch) { vc -= Ch; kc += 1; }
+      h += q2;
+      if (kc >= Ch) { kc -= Ch; h += 1; }
+    }
   }
   const float* row0 = qkv + ((long)b * N) * 3 * C;
   const float* bsrc = bm_src + ((long)b * N) * bm_row;
   for (int t0 = n0; t0 < n1; t0 += FA_TOK) {
     const int tn = min(FA_TOK, n1 - t0);
     __syncthreads();
-    for (int e = threadIdx.x; e < tn * C; e += NT) {
-      const int tt = e / C, c = e - tt * C;
+    TokChan tc(C);
+    for (int e = threadIdx.x; e < tn * C; e += NT, tc.next(C)) {
+      const int tt = tc.tt, c = tc.c;
       const long n = t0 + tt;
       float av;
       if (SOFTMAX) av = __expf(row0[n * 3 * C + C + c] - kmax[b * C + c]) * krsum[b * C + c];
       else av = row0[n * 3 * C + c];
-      s_a[tt * C + c] = av;
-      s_b[tt * C + c] = bsrc[n * bm_row + c];
+      s_a[e] = av;
+      s_b[e] = bsrc[n * bm_row + c];
     }
     __syncthreads();
     for (int tt = 0; tt < tn; ++tt) {
@@ -411,17 +440,20 @@ __global__ __launch_bounds__(NT) void fa_apply_kernel(const float* __restrict__ 
   extern __shared__ float fa_lds[];
   float* s_ctx = fa_lds;                           // [C][Ch]  (entry (h,kc,vc) at (h*Ch+kc)*Ch + vc)
   float* s_q = fa_lds + C * Ch;                    // [tok_per_block][C]
+  int* s_head = reinterpret_cast<int*>(s_q + tok_per_block * C);     // [C] head of a channel (one division per channel)
   const int b = blockIdx.y, n0 = blockIdx.x * tok_per_block, tn = min(tok_per_block, N - n0);
   for (int e = threadIdx.x; e < C * Ch; e += NT) s_ctx[e] = ctxs[(long)b * C * Ch + e];
+  for (int c = threadIdx.x; c < C; c += NT) s_head[c] = c / Ch;
   const float* row0 = qkv + ((long)b * N + n0) * 3 * C;
-  for (int e = threadIdx.x; e < tn * C; e += NT) {
-    const int tt = e / C, c = e - tt * C;
-    s_q[e] = row0[(long)tt * 3 * C + c];
+  {
+    TokChan tc(C);
+    for (int e = threadIdx.x; e < tn * C; e += NT, tc.next(C)) s_q[e] = row0[(long)tc.tt * 3 * C + tc.c];
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < tn * C; e += NT) {
-    const int tt = e / C, c = e - tt * C;
-    const int h = c / Ch, vc = c - h * Ch;
+  TokChan tc(C);
+  for (int e = threadIdx.x; e < tn * C; e += NT, tc.next(C)) {
+    const int tt = tc.tt, c = tc.c;
+    const int h = s_head[c], vc = c - h * Ch;
     const float* qh = s_q + tt * C + h * Ch;
     const float* cx = s_ctx + (h * Ch) * Ch + vc;
     float acc = 0.0f;
@@ -449,18 +481,29 @@ __global__ __launch_bounds__(NT) void fa_bwd_token_kernel(const float* __restric
   float* s_p = s_r + C;                            // [tok][C] softmax(k)
   float* s_v = s_p + tok_per_block * C;            // [tok][C]
   float* s_g = s_v + tok_per_block * C;            // [tok][C] dout
+  int* s_head = reinterpret_cast<int*>(s_g + tok_per_block * C);     // [C] head of a channel
   const int b = blockIdx.y, n0 = blockIdx.x * tok_per_block, tn = min(tok_per_block, N - n0);
-  for (int e = threadIdx.x; e < C * Ch; e += NT) {
-    const int hk = e / Ch, vc = e - hk * Ch;
-    s_ctx[hk * Chp + vc] = ctxs[(long)b * C * Ch + e];
-    s_d[hk * Chp + vc] = dctx[(long)b * C * Ch + e];
+  {
+    // (row hk, column vc) of context entry e = threadIdx.x + k * NT: NT added in radix Ch
+    const int q = NT / Ch, r = NT - q * Ch;
+    int hk = (int)threadIdx.x / Ch, vc = (int)threadIdx.x - hk * Ch;
+    for (int e = threadIdx.x; e < C * Ch; e += NT) {
+      s_ctx[hk * Chp + vc] = ctxs[(long)b * C * Ch + e];
+      s_d[hk * Chp + vc] = dctx[(long)b * C * Ch + e];
+      vc += r; hk += q;
+      if (vc >= Ch) { vc -= Ch; hk += 1; }
+    }
   }
+  for (int c = threadIdx.x; c < C; c += NT) s_head[c] = c / Ch;
   const float* row0 = qkv + ((long)b * N + n0) * 3 * C;
-  for (int e = threadIdx.x; e < tn * C; e += NT) {
-    const int tt = e / C, c = e - tt * C;
-    s_p[e] = __expf(row0[(long)tt * 3 * C + C + c] - kmax[b * C + c]) * krsum[b * C + c];
-    s_v[e] = row0[(long)tt * 3 * C + 2 * C + c];
-    s_g[e] = dout[((long)b * N + n0 + tt) * C + c];
+  {
+    TokChan tc(C);
+    for (int e = threadIdx.x; e < tn * C; e += NT, tc.next(C)) {
+      const int tt = tc.tt, c = tc.c;
+      s_p[e] = __expf(row0[(long)tt * 3 * C + C + c] - kmax[b * C + c]) * krsum[b * C + c];
+      s_v[e] = row0[(long)tt * 3 * C + 2 * C + c];
+      s_g[e] = dout[((long)b * N + n0 + tt) * C + c];
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += NT) {
@@ -469,9 +512,10 @@ __global__ __launch_bounds__(NT) void fa_bwd_token_kernel(const float* __restric
     s_r[c] = r * inv_scale;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < tn * C; e += NT) {
-    const int tt = e / C, c = e - tt * C;
-    const int h = c / Ch, x = c - h * Ch;
+  TokChan tc(C);
+  for (int e = threadIdx.x; e < tn * C; e += NT, tc.next(C)) {
+    const int tt = tc.tt, c = tc.c;
+    const int h = s_head[c], x = c - h * Ch;
     const float* gh = s_g + tt * C + h * Ch;
     const float* ph = s_p + tt * C + h * Ch;
     const float* vh = s_v + tt * C + h * Ch;
@@ -659,7 +703,7 @@ int bbd_factor_att_fwd(const float* qkv, const float* convv, float* kmax, float*
                      ctxs, nseg, nout, B * nout, (float)scale);
   const int tpb = 8;
   hipLaunchKernelGGL(fa_apply_kernel, dim3((unsigned)((N + tpb - 1) / tpb), B), dim3(NT),
-                     (size_t)(nout + tpb * C) * sizeof(float), st, qkv, ctxs, convv, out, N, C, Ch, tpb);
+                     (size_t)(nout + tpb * C + C) * sizeof(float), st, qkv, ctxs, convv, out, N, C, Ch, tpb);
   return launch_status();
 }
 
@@ -682,7 +726,7 @@ int bbd_factor_att_bwd(const float* qkv, const float* convv, const float* kmax, 
   hipLaunchKernelGGL(fa_context_reduce_kernel, dim3((unsigned)(((long)B * nout + 63) / 64)), dim3(NT), 0, st, part,
                      dctx, nseg, nout, B * nout, (float)scale);
   const int tpb = 8, Chp = Ch | 1;
-  const size_t lds = (size_t)(2 * C * Chp + C + 3 * tpb * C) * sizeof(float);
+  const size_t lds = (size_t)(2 * C * Chp + C + 3 * tpb * C + C) * sizeof(float);
   if (lds > 64 * 1024) {      // up to 114 KB for C = 288, Ch = 36: above the default dynamic-LDS limit
     static size_t granted = 0;
     if (lds > granted) {
