@@ -413,6 +413,70 @@ __global__ __launch_bounds__(NT) void fa_context_kernel(const float* __restrict_
   }
 }
 
+// The same partial sums with a thread per context ROW (h, kc): the row's a-value is one LDS read per token and the head's
+// Ch b-values arrive as 16-byte reads (each head's slice padded to CHP = a multiple of 4 floats), so a token costs
+// 1 + CHP / 4 LDS reads for Ch multiply-adds - the entry-per-thread form above needs two reads for each - and the Ch
+// sums of a row live in registers without index arrays.  Block = C rounded up to whole waves (<= 512 threads).
+template <bool SOFTMAX, int CHP>
+__global__ __launch_bounds__(512) void fa_context_rows_kernel(const float* __restrict__ qkv, const float* __restrict__ bm_src,
+                                                              int bm_row, const float* __restrict__ kmax,
+                                                              const float* __restrict__ krsum, float* __restrict__ partial,
+                                                              int N, int C, int Ch, int seg_tokens) {
+  extern __shared__ float fa_lds[];
+  const int heads = C / Ch;
+  float* s_a = fa_lds;                               // [FA_TOK][C]
+  float* s_b = fa_lds + FA_TOK * C;                  // [FA_TOK][heads][CHP]
+  const int seg = blockIdx.x, b = blockIdx.y, nseg = gridDim.x;
+  const int n0 = seg * seg_tokens, n1 = min(N, n0 + seg_tokens);
+  const int nt = (int)blockDim.x;
+  const int hk = threadIdx.x;                        // this thread's row (idle beyond C)
+  const int h = hk < C ? hk / Ch : 0;
+  float acc[CHP];
+#pragma unroll
+  for (int i = 0; i < CHP; ++i) acc[i] = 0.0f;
+  const float* row0 = qkv + ((long)b * N) * 3 * C;
+  const float* bsrc = bm_src + ((long)b * N) * bm_row;
+  // (token, channel) walker for the staging loops: blockDim.x added in radix C, channel -> (head, vc) by a second walker
+  const int q = nt / C, r = nt - q * C;
+  for (int t0 = n0; t0 < n1; t0 += FA_TOK) {
+    const int tn = min(FA_TOK, n1 - t0);
+    __syncthreads();
+    int tt = (int)threadIdx.x / C, c = (int)threadIdx.x - tt * C;
+    for (int e = threadIdx.x; e < tn * C; e += nt) {
+      const long n = t0 + tt;
+      float av;
+      if (SOFTMAX) av = __expf(row0[n * 3 * C + C + c] - kmax[b * C + c]) * krsum[b * C + c];
+      else av = row0[n * 3 * C + c];
+      s_a[e] = av;
+      const int ch = c / Ch;                          // (one division per staged element; 16 tokens per pass)
+      s_b[(tt * heads + ch) * CHP + (c - ch * Ch)] = bsrc[n * bm_row + c];
+      c += r; tt += q;
+      if (c >= C) { c -= C; tt += 1; }
+    }
+    __syncthreads();
+    if (hk < C) {
+      for (int t = 0; t < tn; ++t) {
+        const float av = s_a[t * C + hk];
+        const float4* bp = reinterpret_cast<const float4*>(s_b + (t * heads + h) * CHP);
+#pragma unroll
+        for (int i = 0; i < CHP / 4; ++i) {
+          const float4 bv = bp[i];
+          acc[4 * i + 0] = fmaf(av, bv.x, acc[4 * i + 0]);
+          acc[4 * i + 1] = fmaf(av, bv.y, acc[4 * i + 1]);
+          acc[4 * i + 2] = fmaf(av, bv.z, acc[4 * i + 2]);
+          acc[4 * i + 3] = fmaf(av, bv.w, acc[4 * i + 3]);
+        }
+      }
+    }
+  }
+  if (hk < C) {
+    float* po = partial + ((long)b * nseg + seg) * C * Ch + (long)hk * Ch;
+#pragma unroll
+    for (int i = 0; i < CHP; ++i)
+      if (i < Ch) po[i] = acc[i];
+  }
+}
+
 // ctx[b, o] = scale * sum_seg partial[b, seg, o]   (fixed order)
 __global__ __launch_bounds__(NT) void fa_context_reduce_kernel(const float* __restrict__ partial, float* __restrict__ ctx,
                                                                int nseg, int nout, int total, float scale) {
@@ -539,6 +603,23 @@ __global__ __launch_bounds__(NT) void fa_bwd_token_kernel(const float* __restric
 template <bool SOFTMAX>
 void fa_launch_context(dim3 grid, size_t lds, hipStream_t st, const float* qkv, const float* bsrc, int brow,
                               const float* kmax, const float* krsum, float* part, int N, int C, int Ch, int seg_tokens) {
+  // row form: heads of up to 48 channels, up to 512 rows; the padded b tile must not contain stale values that matter:
+  // the pad lanes of a head only feed accumulators that are never stored
+  // (narrow token rows - C <= 128, one or two waves of rows per block - stay with the entry-per-thread form: measured
+  // 19-25 us there against 22-51 us for the row form; wide rows 16-23 us against 23-38 us)
+  if (Ch <= 48 && C <= 512 && C > 128) {
+    const int chp = (Ch + 3) & ~3, heads = C / Ch;
+    const size_t lds2 = (size_t)FA_TOK * (C + heads * chp) * sizeof(float);
+    const dim3 block((unsigned)((C + 63) / 64 * 64));
+#define BBD_FAR(P) hipLaunchKernelGGL((fa_context_rows_kernel<SOFTMAX, P>), grid, block, lds2, st, qkv, bsrc, brow, kmax, krsum, part, N, C, Ch, seg_tokens)
+    switch (chp) {
+      case 4: BBD_FAR(4); break;    case 8: BBD_FAR(8); break;    case 12: BBD_FAR(12); break;  case 16: BBD_FAR(16); break;
+      case 20: BBD_FAR(20); break;  case 24: BBD_FAR(24); break;  case 28: BBD_FAR(28); break;  case 32: BBD_FAR(32); break;
+      case 36: BBD_FAR(36); break;  case 40: BBD_FAR(40); break;  case 44: BBD_FAR(44); break;  default: BBD_FAR(48); break;
+    }
+#undef BBD_FAR
+    return;
+  }
   const int nacc = (C * Ch + NT - 1) / NT;
 #define BBD_FA(M) hipLaunchKernelGGL((fa_context_kernel<SOFTMAX, M>), grid, dim3(NT), lds, st, qkv, bsrc, brow, kmax, krsum, part, N, C, Ch, seg_tokens)
   if (nacc <= 2) BBD_FA(2);
