@@ -447,6 +447,12 @@ def main(argv=None):
                         floor_ms = tj[k]["valu_wave_instructions"] * share / 1024 * (4.1 / 2.4e9) * 1e3
                         kernels[k]["fp32_issue_floor_ms"] = round(floor_ms, 4)
                         kernels[k]["frac_of_issue_floor"] = round(floor_ms / kernels[k]["mean_ms"], 3)
+                        # upper variant of the same bound: EVERY vector instruction at 4.1 cycles (no overlap of the integer
+                        # pipe).  The PMC pass's SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.04-4.16 cycles says this is the one
+                        # the hardware actually charged these kernels (finding 20)
+                        all_ms = tj[k]["valu_wave_instructions"] / 1024 * (4.1 / 2.4e9) * 1e3
+                        kernels[k]["valu_issue_bound_ms"] = round(all_ms, 4)
+                        kernels[k]["frac_of_valu_issue_bound"] = round(all_ms / kernels[k]["mean_ms"], 3)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
                     "traffic_source": os.path.relpath(tpath, ROOT) if (traffic is not None) else None}
