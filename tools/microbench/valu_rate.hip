@@ -13,12 +13,17 @@
 #include <cstdio>
 #include <vector>
 
-enum Kind { FMA = 0, MULADD, CMPSEL, RCP, IMUL, ADD64, CVT, FLOOR, DPP, PKFMA, PKADD, PKMUL, IADD, MOVXOR, FMA_IADD, FMA_FLOOR, MAXMIN, KINDS };
+enum Kind { FMA = 0, MULADD, CMPSEL, RCP, IMUL, ADD64, CVT, FLOOR, DPP, PKFMA, PKADD, PKMUL, IADD, MOVXOR, FMA_IADD, FMA_FLOOR, MAXMIN,
+            FMA_VVV, PKFMA_VVV, PKADD_VV, PKMUL_VV, FMA_VSV, FMA_VV_INLINE, FMA_VV_LITERAL, MULADD_VV, MUL_VS, ADD_V_LITERAL, KINDS };
 static const char* kind_name[KINDS] = {"v_fma_f32", "v_mul_f32+v_add_f32", "v_cmp+v_cndmask(+add,mul)", "v_rcp_f32",
                                        "v_mul_lo_u32", "v_lshl_add_u64", "v_mul+v_cvt_i32_f32+v_cvt_f32_i32", "v_mul+v_floor_f32",
                                        "v_add_f32 dpp row_shr", "v_pk_fma_f32 (2 fp32 per lane)", "v_pk_add_f32", "v_pk_mul_f32",
                                        "v_add_u32", "v_xor_b32", "v_fma_f32 / v_add_u32 alternating", "v_fma_f32 / v_floor_f32 alternating",
-                                       "v_max_f32 / v_min_f32"};
+                                       "v_max_f32 / v_min_f32", "v_fma_f32, three distinct VGPR operands", "v_pk_fma_f32, three distinct VGPR pairs",
+                                       "v_pk_add_f32, two distinct VGPR pairs", "v_pk_mul_f32, two distinct VGPR pairs",
+                                       "v_fma_f32 v, s, v (one SGPR operand)", "v_fma_f32 v, v, 2.0 (inline constant)",
+                                       "v_fma_f32 v, v, literal (v_fmaak)", "v_mul_f32 v, v / v_add_f32 v, v", "v_mul_f32 s, v",
+                                       "v_add_f32 literal, v"};
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int REPS = 16;     // 128 vector instructions per loop iteration: the loop's own s_add / s_cmp / taken branch
@@ -53,6 +58,17 @@ __global__ __launch_bounds__(256) void chain(float* out, unsigned long long* clk
       else if (KIND == FMA_IADD) { if (i & 1) u[i] = u[i] + u[(i + 2) & 7]; else a[i] = fmaf(a[i], b, c); }
       else if (KIND == FMA_FLOOR) { if (i & 1) a[i] = floorf(a[i - 1]); else a[i] = fmaf(a[i], b, a[i + 1]); }
       else if (KIND == MAXMIN) a[i] = (i & 1) ? fmaxf(a[i], a[(i + 1) & 7]) : fminf(a[i], a[(i + 3) & 7]);
+      // operands that are all per-lane registers (the kernels' case), not the broadcast constants of the kinds above
+      else if (KIND == FMA_VVV) a[i] = fmaf(a[i], a[(i + 1) & 7], a[(i + 3) & 7]);
+      else if (KIND == PKFMA_VVV) pk[i] = __builtin_elementwise_fma(pk[i], pk[(i + 1) & 7], pk[(i + 3) & 7]);
+      else if (KIND == FMA_VSV) a[i] = fmaf(a[i], b, a[(i + 3) & 7]);
+      else if (KIND == FMA_VV_INLINE) a[i] = fmaf(a[i], a[(i + 1) & 7], 2.0f);
+      else if (KIND == FMA_VV_LITERAL) a[i] = fmaf(a[i], a[(i + 1) & 7], 0.1111111f);
+      else if (KIND == MULADD_VV) a[i] = (i & 1) ? a[i] + a[(i + 3) & 7] : a[i] * a[(i + 1) & 7];
+      else if (KIND == MUL_VS) a[i] = a[i] * b;
+      else if (KIND == ADD_V_LITERAL) a[i] = a[i] + 0.1111111f;
+      else if (KIND == PKADD_VV) pk[i] = pk[i] + pk[(i + 1) & 7];
+      else if (KIND == PKMUL_VV) pk[i] = pk[i] * pk[(i + 3) & 7];
       else if (KIND == ADD64) w[i] = (w[i] << 2) + (unsigned long long)u[i];
       else if (KIND == CVT) a[i] = (float)(int)(a[i] * b);          // v_mul + v_cvt_i32_f32 + v_cvt_f32_i32
       else if (KIND == FLOOR) a[i] = floorf(a[i] * b);               // v_mul + v_floor
@@ -123,6 +139,16 @@ int main() {
   run_kind<FMA_IADD>(out, clk, iters);
   run_kind<FMA_FLOOR>(out, clk, iters);
   run_kind<MAXMIN>(out, clk, iters);
+  run_kind<FMA_VVV>(out, clk, iters);
+  run_kind<PKFMA_VVV>(out, clk, iters);
+  run_kind<PKADD_VV>(out, clk, iters);
+  run_kind<PKMUL_VV>(out, clk, iters);
+  run_kind<FMA_VSV>(out, clk, iters);
+  run_kind<FMA_VV_INLINE>(out, clk, iters);
+  run_kind<FMA_VV_LITERAL>(out, clk, iters);
+  run_kind<MULADD_VV>(out, clk, iters);
+  run_kind<MUL_VS>(out, clk, iters);
+  run_kind<ADD_V_LITERAL>(out, clk, iters);
   // a long run of the densest kind: the clock the chip settles at after ~2 s of back-to-back launches
   for (int rep = 0; rep < 40; ++rep) hipLaunchKernelGGL(chain<FMA>, dim3(256 * 4), dim3(256), 0, 0, out, clk, 20000, 1.0001f, 0.5f);
   hipDeviceSynchronize();
