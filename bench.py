@@ -439,20 +439,15 @@ def main(argv=None):
                 if k in tj:
                     kernels[k]["pmc_traffic_MB_per_launch"] = round(tj[k]["traffic_bytes"] / 1e6, 1)
                     if "valu_wave_instructions" in tj[k]:
-                        # issue floor of the fp32 pipe: counter-measured vector instructions of the launch
-                        # (a committed PMC pass, not this run) x the kernel's static fp32-pipe share
-                        # (profiles/r03/isa_mix.json) x 4.1 cycles per wave-instruction per SIMD at 2.4 GHz
-                        # (profiles/r03/valu_rate.txt: the same at 1..8 waves per SIMD), 1024 SIMDs
-                        share = isa_mix.get(alias(k), {}).get("fp32_share", 0.75)
-                        floor_ms = tj[k]["valu_wave_instructions"] * share / 1024 * (4.1 / 2.4e9) * 1e3
-                        kernels[k]["fp32_issue_floor_ms"] = round(floor_ms, 4)
-                        kernels[k]["frac_of_issue_floor"] = round(floor_ms / kernels[k]["mean_ms"], 3)
-                        # upper variant of the same bound: EVERY vector instruction at 4.1 cycles (no overlap of the integer
-                        # pipe).  The PMC pass's SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.04-4.16 cycles says this is the one
-                        # the hardware actually charged these kernels (finding 20)
-                        all_ms = tj[k]["valu_wave_instructions"] / 1024 * (4.1 / 2.4e9) * 1e3
-                        kernels[k]["valu_issue_bound_ms"] = round(all_ms, 4)
-                        kernels[k]["frac_of_valu_issue_bound"] = round(all_ms / kernels[k]["mean_ms"], 3)
+                        # vector-issue bound (finding 14): counter-measured vector instructions of the launch
+                        # (a committed PMC pass, not this run) x the kernel's mean cycles per instruction by issue class
+                        # (profiles/r03/isa_mix.json: 2.2 cycles with register / constant operands, 4.1 with an SGPR / vcc
+                        # operand or packed, 8.2 for reciprocals - profiles/r03/valu_rate.txt) at 2.4 GHz over 1024 SIMDs,
+                        # i.e. the time the launch would take if two waves were always ready to issue on every SIMD
+                        cyc = isa_mix.get(alias(k), {}).get("cycles_per_valu_instruction", 3.0)
+                        bound_ms = tj[k]["valu_wave_instructions"] * cyc / 1024 / 2.4e9 * 1e3
+                        kernels[k]["issue_bound_ms"] = round(bound_ms, 4)
+                        kernels[k]["frac_of_issue_bound"] = round(bound_ms / kernels[k]["mean_ms"], 3)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
                     "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
                     "traffic_source": os.path.relpath(tpath, ROOT) if (traffic is not None) else None}
@@ -491,9 +486,9 @@ def main(argv=None):
                                                            and torch.cuda.tunable.is_enabled())}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
             # what in `kernels` is measured by THIS run (mean_ms, achieved_GBps, frac) and what is read from committed files
-            "kernels_constants": "pmc_traffic_MB_per_launch and the instruction count behind fp32_issue_floor_ms come from the "
-                                 "committed rocprofv3 PMC pass of this workload (roofline.traffic_source); the fp32 share from "
-                                 "profiles/r03/isa_mix.json; 4.1 cycles per wave-instruction from profiles/r03/valu_rate.txt",
+            "kernels_constants": "pmc_traffic_MB_per_launch and the instruction count behind issue_bound_ms come from the "
+                                 "committed rocprofv3 PMC pass of this workload (roofline.traffic_source); the cycles per "
+                                 "instruction from profiles/r03/isa_mix.json (issue classes of profiles/r03/valu_rate.txt)",
             "step_graph": (graph_note if graph_note is not None else
                            (("one graph per step, bucketed RCCL all-reduces captured inside" if trainer.dp_capture else
                              "split: forward+backward+pack graph | eager all-reduce | optimizer graph")

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Static instruction mix of the hot-path kernels from hipcc's assembly (no GPU needed): how many of a kernel's vector
-instructions go to the fp32 pipe (4.1 cycles per wave-instruction per SIMD, profiles/r03/valu_rate.txt) and how many
-to the integer / convert pipe that runs beside it (2.1 cycles).  bench.py prices the kernels' issue floor with the
-fp32 share printed here.   usage: tools/isa_mix.py [out.json]"""
+"""Static instruction mix of the hot-path kernels from hipcc's assembly (no GPU needed): the vector instructions by issue
+class (see CYCLES below).  bench.py prices the kernels' issue bound with the mean cycles per instruction printed here.
+usage: tools/isa_mix.py [out.json]"""
 import collections
 import json
 import os
@@ -14,12 +13,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "baseboostdepth_amd", "csrc", "bbd_kernels.hip")
 KERNELS = {"bbd_warp_ssim_min_fwd": "warp_ssim_min_fwd_kernel", "bbd_warp_ssim_min_bwd": "warp_ssim_min_bwd2_kernel",
            "bbd_identity_loss_fwd": "identity_loss_grouped_kernel"}
-# vector opcodes of the fp32 pipe (measured kinds: fma / mul / add / cmp / cndmask / dpp / max / min / v_mul_lo at ~4.1
-# cycles, v_rcp 8.2; packed forms included); everything else (integer add / logic / shifts, 64-bit shift-add,
-# conversions, floor) issues at ~2.1 cycles on the second pipe
-FP = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32",
-      "v_max_f32", "v_min_f32", "v_cndmask_b32", "v_cmp", "v_rcp_f32", "v_pk_", "v_med3_f32", "v_div_", "v_mul_lo_u32",
-      "v_mul_hi_u32", "v_mad_u64_u32", "v_permlane", "v_mul_legacy_f32", "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_rsq_f32")
+# Issue cost classes measured by tools/microbench/valu_rate.hip (profiles/r03/valu_rate.txt), cycles a wave64 instruction
+# occupies a SIMD when at least two waves share it:
+#   A  2.2  fp32 / integer / convert instructions whose operands are VGPRs, inline constants or literals
+#   B  4.1  the same with an SGPR (or vcc / exec) operand; v_cmp / v_cndmask; every packed v_pk_* (two results);
+#           v_max / v_min, v_mul_lo / v_mul_hi / v_mad_u64, DPP forms, lane reads / writes
+#   C  8.2  v_rcp / v_rsq / v_sqrt / v_exp / v_log
+B_OPS = ("v_pk_", "v_max_f32", "v_min_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_readlane", "v_writelane",
+         "v_readfirstlane", "v_cmp", "v_cndmask", "v_permlane", "v_med3")
+C_OPS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_")
+DORMANT = ("v_div_",)       # the compiler's full IEEE division sequence: only on the guarded fall-back paths, not counted
+SCALAR_OPERAND = re.compile(r"(?<![a-z_0-9])s\d+|s\[\d+:\d+\]|vcc|exec")
+CYCLES = {"A": 2.2, "B": 4.1, "C": 8.2}
+
+
+def issue_class(op, operands):
+    if any(op.startswith(x) for x in C_OPS):
+        return "C"
+    if any(op.startswith(x) for x in B_OPS) or "dpp" in operands or SCALAR_OPERAND.search(operands):
+        return "B"
+    return "A"
 
 
 def main():
@@ -39,24 +52,26 @@ def main():
             if not t or t[0] in ";." or t.endswith(":"):
                 continue
             op = t.split()[0]
+            if op.startswith(DORMANT):
+                continue
             if op.startswith("v_"):
-                c["fp" if any(op.startswith(f) for f in FP) else "int"] += 1
-                if "dpp" in t and not any(op.startswith(f) for f in FP):
-                    c["int"] -= 1
-                    c["fp"] += 1
+                c[issue_class(op, t[len(op):])] += 1
             elif op.startswith("s_"):
                 c["salu"] += 1
             elif op.startswith("ds_"):
                 c["lds"] += 1
             elif op.startswith(("global_", "scratch_", "buffer_")):
                 c["vmem"] += 1
-        valu = c["fp"] + c["int"]
-        res[entry] = {"kernel": kern, "valu": valu, "fp32_pipe": c["fp"], "int_pipe": c["int"],
-                      "fp32_share": round(c["fp"] / valu, 3), "salu": c["salu"], "lds": c["lds"], "vmem": c["vmem"]}
+        valu = c["A"] + c["B"] + c["C"]
+        cyc = sum(c[k] * CYCLES[k] for k in "ABC") / valu
+        res[entry] = {"kernel": kern, "valu": valu, "class_A": c["A"], "class_B": c["B"], "class_C": c["C"],
+                      "cycles_per_valu_instruction": round(cyc, 3), "salu": c["salu"], "lds": c["lds"], "vmem": c["vmem"]}
         print(entry, res[entry])
-    res["_note"] = ("static counts over each kernel's whole code (unrolled bodies dominate); fp32 pipe = instructions that "
-                    "issue at ~4.1 cycles per wave-instruction per SIMD, int pipe = ~2.1 cycles on a pipe that runs beside it "
-                    "(profiles/r03/valu_rate.txt)")
+    res["_note"] = ("static counts over each kernel's whole code (unrolled bodies dominate), vector instructions by issue class: "
+                    "A = 2.2 cycles (register / constant operands), B = 4.1 (an SGPR / vcc operand, packed, compare / select, ...), "
+                    "C = 8.2 (reciprocal etc.) per wave-instruction per SIMD with >= 2 waves resident (profiles/r03/valu_rate.txt); "
+                    "cycles_per_valu_instruction = their weighted mean, what bench.py prices the launch's counter-measured "
+                    "instruction count with")
     if out:
         json.dump(res, open(out, "w"), indent=1)
 
