@@ -353,12 +353,18 @@ __device__ __forceinline__ void project_pair(const float* pj, int xy0, int xy1, 
 #endif
 }
 
+struct NoWork {
+  __device__ __forceinline__ void operator()() const {}
+};
 // XS = element stride of the staged planes (2: the backward interleaves (x, y) pairs, see its kernel).
-template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int XS = 1>
+// `under_gathers`: work of the caller that does not depend on the warp, run once after the first batch's gathers have been
+// issued and before their values are consumed (the wave would otherwise only wait there).
+template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int XS = 1, typename Work = NoWork>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float* __restrict__ pose_row, const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
-                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr) {
+                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
+                                              Work under_gathers = Work()) {
   // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   float pj[21];
@@ -406,6 +412,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
       for (int ch = 0; ch < 3; ++ch) {
         bbd_fetch4(src + ch * hw, &t[kk], v[kk][ch]);
       }
+    if (k0 == 0) under_gathers();
 #pragma unroll
     for (int kk = 0; kk < BATCH; ++kk) {
       if (k0 + kk >= CellsT::N) break;
@@ -1045,21 +1052,25 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
     const float* pose_row = a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE;
 
-    // ---- phase W
-    if (!a.no_ssim) {
+    // ---- phase W; the winners' list of this candidate and the clearing of the previous one's coefficient entries are
+    // LDS work that does not depend on the warp: done while the first batch of gathers is in flight
+    const int prev_c = prev;
+    auto lists = [&]() {
+      if (!a.no_ssim) {
 #pragma unroll
-      for (int k = 0; k < NP_CELLS; ++k) {
-        if ((int)BBD_PARG(k) == prev) {
+        for (int k = 0; k < NP_CELLS; ++k) {
+          if ((int)BBD_PARG(k) == prev_c) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
+            for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
+          }
+          if (BBD_PARG(k) == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
         }
-        if (BBD_PARG(k) == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
       }
-    }
+    };
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
     warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_xy, nullptr,
-                                                                               s_dv);
+                                                                               s_dv, lists);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
