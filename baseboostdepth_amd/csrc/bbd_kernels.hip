@@ -35,6 +35,9 @@
 #ifndef BBD_BWD_WARP_BATCH
 #define BBD_BWD_WARP_BATCH 2
 #endif
+#ifndef BBD_IDENT_PASS2
+#define BBD_IDENT_PASS2 1
+#endif
 
 namespace {
 
@@ -255,27 +258,43 @@ __device__ __forceinline__ DepthSrc depth_source(const float* depth_planes, cons
   d.lo = ds.lo; d.span = ds.span;
   return d;
 }
-__device__ __forceinline__ float depth_at(const DepthSrc& d, int yy, int xx, int H, int W) {
-  if (d.depth != nullptr) return d.depth[yy * W + xx];
-  float v;
-  if (d.h == H && d.w == W) {
-    v = d.disp[yy * W + xx];
-  } else {
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
-    bbd_up_src(yy, d.h, H, &y0, &y1, &ly0, &ly1);
-    bbd_up_src(xx, d.w, W, &x0, &x1, &lx0, &lx1);
-    v = bbd_up_blend(d.disp[y0 * d.w + x0], d.disp[y0 * d.w + x1], d.disp[y1 * d.w + x0], d.disp[y1 * d.w + x1], ly0, ly1,
-                     lx0, lx1, d.small);
+// Depth of N pixels in two halves.  issue() starts every global load with no branch between them, so they travel together
+// and the caller's other set-up work runs under them; finish() turns the loaded values into depth.  (The earlier
+// per-pixel form chose between "depth plane / same-size disparity / 2x2 up-sampling" with a branch per pixel: each branch
+// region ended in s_waitcnt vmcnt(0), i.e. one full memory round trip per staged cell, five in a row in each kernel's
+// set-up - profiles/r04/phase_stamps_*.txt.)  PLANE = read a full-resolution depth plane; otherwise the decoder's
+// disparity map through the four-tap form: for a same-size map the taps' lambdas are exactly (1, 0) and the value is
+// the first tap itself (selected, not blended, so that it stays an exact copy).
+template <int N, bool PLANE>
+struct DepthFetch {
+  static constexpr int TAPS = PLANE ? 1 : 4, NL = PLANE ? 1 : N;
+  float v[N][TAPS];
+  float ly1[NL], lx1[NL];
+  __device__ __forceinline__ void issue(const DepthSrc& d, int k, int yy, int xx, int H, int W) {
+    if constexpr (PLANE) {
+      v[k][0] = d.depth[yy * W + xx];
+    } else {
+      int y0, y1, x0, x1;
+      float ly0, lx0;
+      bbd_up_src(yy, d.h, H, &y0, &y1, &ly0, &ly1[k]);
+      bbd_up_src(xx, d.w, W, &x0, &x1, &lx0, &lx1[k]);
+      v[k][0] = d.disp[y0 * d.w + x0];
+      v[k][1] = d.disp[y0 * d.w + x1];
+      v[k][2] = d.disp[y1 * d.w + x0];
+      v[k][3] = d.disp[y1 * d.w + x1];
+    }
   }
-  return 1.0f / (d.lo + d.span * v);
-}
-
-template <typename CellsT>
-__device__ __forceinline__ void load_depth(const DepthSrc& src, int H, int W, const CellsT& cl, float (&d)[CellsT::N]) {
-#pragma unroll
-  for (int k = 0; k < CellsT::N; ++k) d[k] = depth_at(src, cl.xy[k] >> 16, cl.xy[k] & 0xffff, H, W);
-}
+  __device__ __forceinline__ float finish(const DepthSrc& d, int k, int H, int W) const {
+    if constexpr (PLANE) {
+      return v[k][0];
+    } else {
+      float val = v[k][0];
+      if (!(d.h == H && d.w == W))      // (bbd_up_src: l0 = 1 - l1)
+        val = bbd_up_blend(v[k][0], v[k][1], v[k][2], v[k][3], 1.0f - ly1[k], ly1[k], 1.0f - lx1[k], lx1[k], d.small);
+      return 1.0f / (d.lo + d.span * val);
+    }
+  }
+};
 
 // Warp one source image into the staged region for one pose-table row (after the packed helpers below).
 // ---- packed fp32 (two values per lane) ------------------------------------------------------------------------
@@ -361,15 +380,12 @@ struct NoWork {
 // issued and before their values are consumed (the wave would otherwise only wait there).
 template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int XS = 1, typename Work = NoWork>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
-                                              const float* __restrict__ pose_row, const BbdDims dm, int hw,
+                                              const float (&pj)[21], const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
                                               float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
                                               Work under_gathers = Work()) {
-  // P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table, so the
+  // pj = P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table by the caller, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
-  float pj[21];
-#pragma unroll
-  for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
   // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
   // its gathers are in flight together (6 x 8-byte loads per cell), then the blends.  The batch
   // size trades loads in flight against VGPRs (occupancy): measured best at 3 cells for the forward
@@ -675,11 +691,14 @@ struct CandOrder {
     if (forced >= 0) { c = forced; forced = -1; }
     else { c = __builtin_ctz(todo); todo &= todo - 1u; }
     *cd = load_cand(tab + c);
-    if ((cd->kind & KIND_MASK) == BBD_KIND_WARP) {
-      const int hint = ((cd->kind >> 16) & 0xff) - 1;
+    pair_up(*cd);
+    return c;
+  }
+  __device__ __forceinline__ void pair_up(const bbd_cand_t& cd) {
+    if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
+      const int hint = ((cd.kind >> 16) & 0xff) - 1;
       if (hint >= 0 && hint < 32 && ((todo >> hint) & 1u)) { forced = hint; todo &= ~(1u << hint); }
     }
-    return c;
   }
 };
 
@@ -733,6 +752,7 @@ struct FwdArgs {
 #ifndef BBD_FWD_WAVES
 #define BBD_FWD_WAVES 3   // <= 168 VGPRs (154 used since the pose rows moved to SGPRs); 2 waves/SIMD is 15 % slower
 #endif
+template <bool PLANE>
 __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(FwdArgs a) {
   // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
   // still read candidate c, so one barrier per warp candidate is enough
@@ -752,12 +772,37 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   const int s = bid / a.ntiles;
   const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
   const size_t img = (size_t)3 * hw;
+  const size_t sb = (size_t)s * a.B + b;
 
   BBD_STAMP_RT(30);
   BBD_STAMP(0);
-  Cells<LH, LW, LS, 1> cl;
+  // set-up: every global load is issued before anything waits - the sample's candidate tables, the target tile, the
+  // depth sources of the staged cells
+  typedef Cells<LH, LW, LS, 1> CellsF;
+  const int nc = uniform_load(a.ncand + b);
+  CellsF cl;
   cl.init(H, W, tc.tx0, tc.ty0);
-  stage_image(a.target + (size_t)b * img, hw, W, cl, s_y);
+  float tv[CellsF::N][3];
+  {
+    const float* tg = a.target + (size_t)b * img;
+#pragma unroll
+    for (int k = 0; k < CellsF::N; ++k) {
+      const int px = cl.pix(k, W);
+      tv[k][0] = tg[px];
+      tv[k][1] = tg[px + hw];
+      tv[k][2] = tg[px + 2 * hw];
+    }
+  }
+  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
+  DepthFetch<CellsF::N, PLANE> dfetch;
+#pragma unroll
+  for (int k = 0; k < CellsF::N; ++k) dfetch.issue(dsrc, k, cl.xy[k] >> 16, cl.xy[k] & 0xffff, H, W);
+#pragma unroll
+  for (int k = 0; k < CellsF::N; ++k) {
+    s_y[0][cl.lds[k]] = tv[k][0];
+    s_y[1][cl.lds[k]] = tv[k][1];
+    s_y[2][cl.lds[k]] = tv[k][2];
+  }
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
@@ -770,15 +815,13 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
 
   float mu_y[3][PPT], sg_y[3][PPT];
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
-  const int nc = uniform_load(a.ncand + b);
 
-  const size_t sb = (size_t)s * a.B + b;
-  float dcell[Cells<LH, LW, LS, 1>::N];
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  load_depth(dsrc, H, W, cl, dcell);
+  float dcell[CellsF::N];
+#pragma unroll
+  for (int k = 0; k < CellsF::N; ++k) dcell[k] = dfetch.finish(dsrc, k, H, W);
   if (a.depth_out != nullptr) {
 #pragma unroll
-    for (int k = 0; k < Cells<LH, LW, LS, 1>::N; ++k)
+    for (int k = 0; k < CellsF::N; ++k)
       if (cl.own(k)) a.depth_out[sb * hw + cl.pix(k, W)] = dcell[k];
   }
 
@@ -790,45 +833,85 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
+  // pass 1: the warp candidates (a frame's two warps back to back); identity candidates are only noted
   CandOrder order;
   order.init(nc);
+  unsigned idents = 0u;
   int visit = 0;
   while (order.more()) {
     bbd_cand_t cd;
     const int c = order.next(a.cand + b * BBD_MAX_CAND, &cd);
-    const int vs = visit++;
-    (void)vs;
-    float loss[PPT];
-    if ((cd.kind & KIND_MASK) == BBD_KIND_WARP) {
-      const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
-      float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
-      BBD_STAMP(4 + 4 * (vs & 3));
-      warp_into_lds<BBD_WARP_BATCH, Cells<LH, LW, LS, 1>, FPLANE>(
-          src, dcell, a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE, dm, hw, cl, s_xx[buf], wout);
-      BBD_STAMP(5 + 4 * (vs & 3));
-      __syncthreads();
-      BBD_STAMP(6 + 4 * (vs & 3));
-      strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
-      BBD_STAMP(7 + 4 * (vs & 3));
-      buf ^= 1;
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) loss[j] = 0.0f;
+    if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) {
+#if BBD_IDENT_PASS2
+      idents |= 1u << c;
+#else
+      float il[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (row_ok) {
-        load_strip(a.ident + (size_t)cd.row * hw + pix, xx, W, vec_ok, loss);
+        load_strip(a.ident + (size_t)cd.row * hw + pix, xx, W, vec_ok, il);
         if (a.noise != nullptr) {
           float nz[PPT];
           load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
 #pragma unroll
-          for (int j = 0; j < PPT; ++j) loss[j] += nz[j];
+          for (int j = 0; j < PPT; ++j) il[j] += nz[j];
         }
       }
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        int aj = (int)((argw >> (8 * j)) & 0xffu);
+        min_update_any_order(il[j], c, &best[j], &aj);
+        argw = (argw & ~(0xffu << (8 * j))) | ((unsigned)aj << (8 * j));
+      }
+#endif
+      continue;
     }
+    const int vs = visit++;
+    (void)vs;
+    float loss[PPT];
+    const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
+    float* wout = a.warped ? a.warped + ((size_t)s * a.NP + cd.pose) * img : nullptr;
+    float pj[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
+    BBD_STAMP(4 + 4 * (vs & 3));
+    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dm, hw, cl, s_xx[buf], wout);
+    BBD_STAMP(5 + 4 * (vs & 3));
+    __syncthreads();
+    BBD_STAMP(6 + 4 * (vs & 3));
+    strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+    BBD_STAMP(7 + 4 * (vs & 3));
+    buf ^= 1;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       int aj = (int)((argw >> (8 * j)) & 0xffu);
       min_update_any_order(loss[j], c, &best[j], &aj);
       argw = (argw & ~(0xffu << (8 * j))) | ((unsigned)aj << (8 * j));
+    }
+  }
+  // pass 2: the identity candidates (trainer.py:501-508, :518-523: identity map + the sample's noise).  The running minimum
+  // is order-free, so they can all come last, and then the next candidate's strip travels while this one is compared -
+  // inside the loop above each of them was a global round trip of its own.
+  if (idents != 0u) {
+    float nz[PPT] = {0.0f, 0.0f, 0.0f, 0.0f}, cur[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (row_ok && a.noise != nullptr) load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
+    int c = __builtin_ctz(idents);
+    idents &= idents - 1u;
+    if (row_ok) load_strip(a.ident + (size_t)uniform_load(&a.cand[b * BBD_MAX_CAND + c].row) * hw + pix, xx, W, vec_ok, cur);
+    while (true) {
+      const int cn = idents != 0u ? __builtin_ctz(idents) : -1;
+      float nxt[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (cn >= 0 && row_ok) load_strip(a.ident + (size_t)uniform_load(&a.cand[b * BBD_MAX_CAND + cn].row) * hw + pix, xx, W, vec_ok, nxt);
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        int aj = (int)((argw >> (8 * j)) & 0xffu);
+        const float lj = a.noise != nullptr ? cur[j] + nz[j] : cur[j];
+        min_update_any_order(row_ok ? lj : 0.0f, c, &best[j], &aj);
+        argw = (argw & ~(0xffu << (8 * j))) | ((unsigned)aj << (8 * j));
+      }
+      if (cn < 0) break;
+      idents &= idents - 1u;
+      c = cn;
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) cur[j] = nxt[j];
     }
   }
 
@@ -931,6 +1014,7 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 #ifndef BBD_BWD2_WARP_BATCH
 #define BBD_BWD2_WARP_BATCH 3
 #endif
+template <bool PLANE>
 __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(BwdArgs a) {
   // warped (x) and target (y) texels of a staged cell sit side by side - planes of (x, y) pairs: every window read of
   // the coefficient phase is one 8-byte load that lands in a register pair, and its five running sums become three
@@ -961,6 +1045,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   BBD_STAMP_RT(30);
   BBD_STAMP(0);
   // setup: issue every global load first, then the LDS work that does not depend on them
+  const int nc = uniform_load(a.ncand + b);
   constexpr int NP_CELLS = (CH * CW2 + NT2 - 1) / NT2;
   static_assert(NP_CELLS <= 4, "arg-min ids of the loss pixels are packed four to a word");
   int pcell[NP_CELLS];
@@ -990,25 +1075,24 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       tcell[k][2] = tg[px + 2 * hw];
     }
   }
-  float dcell[CellsB::N];
-  load_depth(dsrc, H, W, cl, dcell);         // depth of the halo'd cells is only needed to project them
-
-  BBD_STAMP(22);
   const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
   const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
   const bool q_row_ok = qy < H;
   const bool q_vec_ok = (qx0 + PPT2 <= W) && ((W & 1) == 0);
+  // depth of the halo'd cells (only needed to project them) and of the strip's own pixels: one batch of loads (pixels
+  // beyond the image read a clamped address, their value is never used)
+  DepthFetch<CellsB::N + PPT2, PLANE> dfetch;
+#pragma unroll
+  for (int k = 0; k < CellsB::N; ++k) dfetch.issue(dsrc, k, cl.xy[k] >> 16, cl.xy[k] & 0xffff, H, W);
+#pragma unroll
+  for (int j = 0; j < PPT2; ++j) dfetch.issue(dsrc, CellsB::N + j, min(qy, H - 1), min(qx0 + j, W - 1), H, W);
+
+  BBD_STAMP(22);
   unsigned qargw = 0u;                 // byte j = arg-min id of own pixel j
 #pragma unroll
   for (int j = 0; j < PPT2; ++j) qargw |= ((q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u) << (8 * j);
   const bool interior = tc.tx0 >= 2 && tc.tx0 + TW2 + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
   float gdepth[PPT2] = {0.0f, 0.0f};
-  float qdepth[PPT2] = {1.0f, 1.0f};
-  if (q_row_ok) {
-#pragma unroll
-    for (int j = 0; j < PPT2; ++j)
-      if (qx0 + j < W) qdepth[j] = depth_at(dsrc, qy, qx0 + j, H, W);
-  }
 
   BBD_STAMP(23);
   if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
@@ -1031,12 +1115,16 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     s_xy[1][2 * cl.lds[k] + 1] = tcell[k][1];
     s_xy[2][2 * cl.lds[k] + 1] = tcell[k][2];
   }
+  float dcell[CellsB::N], qdepth[PPT2];
+#pragma unroll
+  for (int k = 0; k < CellsB::N; ++k) dcell[k] = dfetch.finish(dsrc, k, H, W);
+#pragma unroll
+  for (int j = 0; j < PPT2; ++j) qdepth[j] = (q_row_ok && qx0 + j < W) ? dfetch.finish(dsrc, CellsB::N + j, H, W) : 1.0f;
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
   const unsigned present = s_present;
 
-  const int nc = uniform_load(a.ncand + b);
   int prev = -1;
   CandOrder order;                       // a frame's true-pose and error-induced warps back to back (cache locality)
   order.init(nc);
@@ -1050,7 +1138,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
       continue;
     }
     const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
-    const float* pose_row = a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE;
+    float pj[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
 
     // ---- phase W; the winners' list of this candidate and the clearing of the previous one's coefficient entries are
     // LDS work that does not depend on the warp: done while the first batch of gathers is in flight
@@ -1069,7 +1159,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
     };
     prev = c;
     BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, TH * TW2, true, 2>(src, dcell, pose_row, dm, hw, cl, s_xy, nullptr,
+    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, TH * TW2, true, 2>(src, dcell, pj, dm, hw, cl, s_xy, nullptr,
                                                                                s_dv, lists);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
@@ -1175,9 +1265,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
 #pragma unroll
     for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
     if (q_row_ok) {
-      float pj[21];
+      // (a fresh scalar load instead of 21 SGPRs held across the C / G phases)
 #pragma unroll
-      for (int i = 0; i < 21; ++i) pj[i] = uniform_load(pose_row + i);
+      for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
       v2f dxy[6];
 #pragma unroll
       for (int pl = 0; pl < 6; ++pl) {
@@ -2127,8 +2217,12 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.remap = xcd_remap_enabled(S);
   // (a paired-candidate / packed-SSIM form of this kernel was built and measured slower - profiles/r03/fwdp_ab.txt; its
   // source is kept under tools/experiments/paired_packed_forward.hip.txt)
-  hipLaunchKernelGGL(warp_ssim_min_fwd_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (depth != nullptr)
+    hipLaunchKernelGGL(warp_ssim_min_fwd_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(warp_ssim_min_fwd_kernel<false>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
+                       static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 
@@ -2154,8 +2248,12 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.remap = xcd_remap_enabled(S);
   // (a sparse-item form of this kernel - per-candidate winner lists, scatter instead of the dense phases - was built and
   // measured slower inside the training step: profiles/r03/bwd3_*.txt, tools/experiments/sparse_item_backward.hip.txt)
-  hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (depth != nullptr)
+    hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<false>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT2), 0,
+                       static_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 

@@ -22,6 +22,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", 
          "-std=c++17"]
 
 
+def source_sha16():
+    """First 16 hex digits of sha256 over the fused kernels' sources (bbd_kernels.hip + bbd_math.h): stamped into the
+    committed counter / instruction-mix files (tools/pmc_summary.py, tools/isa_mix.py) so that bench.py can say when the
+    constants it quotes from them were taken from other code than the one it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("bbd_kernels.hip", "bbd_math.h"):
+        with open(os.path.join(HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Static instruction mix of the hot-path kernels from hipcc's assembly (no GPU needed): the vector instructions by issue
 class (see CYCLES below).  bench.py prices the kernels' issue bound with the mean cycles per instruction printed here.
-usage: tools/isa_mix.py [out.json]"""
+usage: tools/isa_mix.py [out.json]
+       tools/isa_mix.py --check committed.json    exit 1 when the committed file was not generated from the shipped source
+                                                  (source hash) or its counts differ from a fresh compile"""
 import collections
 import json
 import os
@@ -36,7 +38,13 @@ def issue_class(op, operands):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else None
+    check = None
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--check":
+        check, argv = argv[1], argv[2:]
+    out = argv[0] if argv else None
+    sys.path.insert(0, ROOT)
+    from baseboostdepth_amd.csrc.build import source_sha16
     asm = "/tmp/bbd_isa_mix.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math",
                     "-fno-slp-vectorize", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, SRC], check=True,
@@ -72,8 +80,20 @@ def main():
                     "C = 8.2 (reciprocal etc.) per wave-instruction per SIMD with >= 2 waves resident (profiles/r03/valu_rate.txt); "
                     "cycles_per_valu_instruction = their weighted mean, what bench.py prices the launch's counter-measured "
                     "instruction count with")
+    res["kernel_source_sha16"] = source_sha16()
     if out:
         json.dump(res, open(out, "w"), indent=1)
+    if check:
+        old = json.load(open(check))
+        bad = []
+        if old.get("kernel_source_sha16") != res["kernel_source_sha16"]:
+            bad.append("source hash %s != shipped %s" % (old.get("kernel_source_sha16"), res["kernel_source_sha16"]))
+        for k in KERNELS:
+            for f in ("valu", "class_A", "class_B", "class_C"):
+                if old.get(k, {}).get(f) != res[k][f]:
+                    bad.append("%s.%s: committed %s, fresh %s" % (k, f, old.get(k, {}).get(f), res[k][f]))
+        print("isa_mix --check:", "STALE: " + "; ".join(bad) if bad else "up to date")
+        sys.exit(1 if bad else 0)
 
 
 if __name__ == "__main__":

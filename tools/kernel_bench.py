@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--smooth", action="store_true",
+                    help="spatially smooth disparities (17x17 box filter of the random maps), like the training step's "
+                         "network outputs: per-pixel random disparities scatter the gathers and overstate the times")
     args = ap.parse_args()
     dev = "cuda:0"
     H, W, B = 192, 640, args.batch
@@ -60,6 +63,9 @@ def main():
     be = tr._backend()
     plan = tr.valid_frames_trimin(inputs)
     disp = synthetic_disp(B, H, W, scales, device=dev, seed=1)
+    if args.smooth:
+        import torch.nn.functional as F
+        disp = {s: F.avg_pool2d(F.pad(d, (8, 8, 8, 8), mode="replicate"), 17, 1) for s, d in disp.items()}
     poses = synthetic_poses(plan, device=dev, seed=2, pose_error=5.5)
     outputs = {("disp", s): disp[s].requires_grad_(True) for s in scales}
     outputs.update(poses)
@@ -105,7 +111,7 @@ def main():
     def k_bwd():
         torch.autograd.grad(ls, dd + [t2], gsum, retain_graph=True)
 
-    res = {"config": args.config, "batch": B, "scales": scales, "NP": plan.NP, "NI": plan.NI,
+    res = {"config": args.config, "smooth": bool(args.smooth), "batch": B, "scales": scales, "NP": plan.NP, "NI": plan.NI,
            "cands_per_sample": [len(n) for n in plan.cand_names]}
     # HIP events directly around each C-ABI launch (python overhead excluded)
     timer = ops.KernelTimer()

@@ -40,4 +40,7 @@ if len(sys.argv) > 2:
             if "SQ_INSTS_VALU" in cs:
                 out[names[k]]["valu_wave_instructions"] = round(sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"]))
                 out[names[k]]["waves"] = round(sum(cs["SQ_WAVES"]) / len(cs["SQ_WAVES"]))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from baseboostdepth_amd.csrc.build import source_sha16
+    out["kernel_source_sha16"] = source_sha16()     # bench.py: "kernels_constants_stale" when the shipped source differs
     json.dump(out, open(sys.argv[2], "w"), indent=1)

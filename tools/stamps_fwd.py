@@ -25,6 +25,8 @@ tr.opt, tr.device, tr.num_scales, tr.backend, tr.maxing_valid_frames = opt, torc
 be = tr._backend()
 plan = tr.valid_frames_trimin(inputs)
 disp = synthetic_disp(B, H, W, scales, device=dev, seed=1)
+if os.environ.get("SMOOTH_DISP"):      # spatially smooth disparities, like the training step's network outputs
+    disp = {s: torch.nn.functional.avg_pool2d(torch.nn.functional.pad(d, (8, 8, 8, 8), mode="replicate"), 17, 1) for s, d in disp.items()}
 outputs = {("disp", s): disp[s] for s in scales}
 outputs.update(synthetic_poses(plan, device=dev, seed=2))
 nblocks_f = 4 * B * be.num_tiles_fwd(H, W)
