@@ -20,7 +20,7 @@ PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
 COMPOSE_STRIDE, COMPOSE_ERROR, COMPOSE_REPLACE = 12, 1, 2
 PAIR_SHIFT = 16        # bits 16-23 of bbd_cand_t.kind: 1 + index of the pass partner (hint), 0 = none
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -39,8 +39,9 @@ SIGNATURES = {
     "bbd_identity_loss_grouped_fwd": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p],
     "bbd_warp_ssim_min_fwd": [_p] * 12 + [_i] * 6 + [_p],
     "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],
-    "bbd_warp_ssim_min_disp_fwd": [_p, _p, _p, _p, _d, _d] + [_p] * 10 + [_i] * 6 + [_p],
-    "bbd_warp_ssim_min_disp_bwd": [_p, _p, _p, _p, _d, _d] + [_p] * 8 + [_i] * 6 + [_p],
+    "bbd_fused_work_items": [_i, _i, _i, _i, _i, _p, _p],
+    "bbd_warp_ssim_min_disp_fwd": [_p, _p, _p, _p, _d, _d] + [_p] * 11 + [_i] * 6 + [_p],
+    "bbd_warp_ssim_min_disp_bwd": [_p, _p, _p, _p, _d, _d] + [_p] * 9 + [_i] * 6 + [_p],
     "bbd_disp_upsample_adjoint": [_p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_disp_to_depth_fwd": [_p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
     "bbd_disp_to_depth_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _p],

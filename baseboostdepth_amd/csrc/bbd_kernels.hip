@@ -38,6 +38,21 @@
 #ifndef BBD_IDENT_PASS2
 #define BBD_IDENT_PASS2 1
 #endif
+#ifndef BBD_FWD_RAYS
+#define BBD_FWD_RAYS 0     // forward: camera-space points of the staged cells kept across the candidate loop
+#endif
+#ifndef BBD_FWD_SINGLE_BUF
+#define BBD_FWD_SINGLE_BUF 0   // experiment: warped tile single-buffered (4 workgroups per CU fit in LDS)
+#endif
+#ifndef BBD_FWD_RESTAT
+#define BBD_FWD_RESTAT 0       // experiment: target-window statistics re-derived per candidate, not held
+#endif
+#ifndef BBD_FWD_VDIMS
+#define BBD_FWD_VDIMS 0    // forward: image-dimension constants of the projection in VGPRs (issue class A instead of B)
+#endif
+#ifndef BBD_FWD_VPOSE
+#define BBD_FWD_VPOSE 0    // forward: the 12 entries of P in VGPRs per candidate
+#endif
 
 namespace {
 
@@ -146,6 +161,34 @@ __device__ __forceinline__ TileCoord decode_tile(int t, int W) {
 __device__ __forceinline__ int xcd_work_item(int bid, int n) {
   const int q = n >> 3, r = n & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Slab order of the fused launches (round 4): a host-built table `work[blockIdx.x]` = (sample, scale, tile, tile origin),
+// bbd_fused_work_items below.  The image's tiles are cut into 8 slabs of consecutive tiles, one per XCD, and XCD x walks:
+// for every target sample (in the caller's order: most candidates first) - for every scale - the tiles of slab x.  So
+// (1) all scales of a sample's slab run on ONE XCD back to back and share its L2 (they read the same source / target
+// region; the plain range split of xcd_work_item could not be used with several scales, it gave whole scales of
+// different cost to different XCDs), (2) every XCD gets the same work whatever the samples cost, and (3) inside an XCD
+// the expensive samples start first, so the launch's tail is made of cheap workgroups (boosted batches mix 8-, 14- and
+// 18-candidate samples: mono_dataset.py:87-109).  A table instead of arithmetic: decoding a block index takes 3-5
+// scalar integer divisions (v_rcp + v_readfirstlane round trips, serial, in front of the first load of a workgroup that
+// lives ~50 k cycles) - measured 2.7 % of the MD2 backward (profiles/r04/work_order_ab.txt); the table is one s_load_dwordx2.
+struct WorkItem {
+  int b, s, tile, tx0, ty0;
+};
+constexpr int WORK_B_BITS = 12, WORK_S_BITS = 3;       // word 0 = b | s << 12 | tile << 15; word 1 = tx0 | ty0 << 16
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p);
+__device__ __forceinline__ WorkItem load_work_item(const int32_t* work) {
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  const v2i w = uniform_load(reinterpret_cast<const v2i*>(work) + blockIdx.x);
+  WorkItem it;
+  it.b = w.x & ((1 << WORK_B_BITS) - 1);
+  it.s = (w.x >> WORK_B_BITS) & ((1 << WORK_S_BITS) - 1);
+  it.tile = (int)((unsigned)w.x >> (WORK_B_BITS + WORK_S_BITS));
+  it.tx0 = w.y & 0xffff;
+  it.ty0 = (int)((unsigned)w.y >> 16);
+  return it;
 }
 
 // Strip owned by a thread: row ly, first tile-local column lx0 (rotated by the row, see header).
@@ -383,7 +426,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
                                               const float (&pj)[21], const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
                                               float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
-                                              Work under_gathers = Work()) {
+                                              Work under_gathers = Work(), float (*ray)[3] = nullptr) {
   // pj = P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table by the caller, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
@@ -409,8 +452,14 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
 #pragma unroll
       for (int kk = 2 * NPAIR; kk < BATCH; ++kk) {
         const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-        if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
-        else bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
+        if (BWD) {
+          bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
+        } else if (ray != nullptr) {      // the cell's camera-space point is candidate-independent: kept by the caller
+          smp[kk].X = ray[k][0]; smp[kk].Y = ray[k][1]; smp[kk].Z = ray[k][2];
+          bbd_project_point(pj, dm, &smp[kk]);
+        } else {
+          bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
+        }
       }
     }
 #pragma unroll
@@ -520,6 +569,7 @@ __device__ __forceinline__ void strip_ystats(const float (*sy)[FPLANE], int ly, 
 }
 
 // Photometric loss of the strip's 4 pixels given the staged prediction (sx) and target (sy).
+template <bool RESTAT = false>
 __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const float (*sy)[FPLANE],
                                            int ly, int lx0, const float mu_y[3][PPT],
                                            const float sg_y[3][PPT], int no_ssim, float out[PPT]) {
@@ -532,7 +582,7 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
     float nn[PPT], dd[PPT], qq[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      float s = 0.0f, ss = 0.0f, sxy = 0.0f;
+      float s = 0.0f, ss = 0.0f, sxy = 0.0f, ty = 0.0f, tyy = 0.0f;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -541,8 +591,15 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
           s += v;
           ss += v * v;
           sxy += v * y[r][j + c];
+          if (RESTAT) {
+            ty += y[r][j + c];
+            tyy += y[r][j + c] * y[r][j + c];
+          }
         }
-      bbd_ssim_nd(s, ss, sxy, mu_y[ch][j], sg_y[ch][j], &nn[j], &dd[j]);
+      float my = 0.0f, gy = 0.0f;
+      if (RESTAT) bbd_ystats(ty, tyy, &my, &gy);
+      else { my = mu_y[ch][j]; gy = sg_y[ch][j]; }
+      bbd_ssim_nd(s, ss, sxy, my, gy, &nn[j], &dd[j]);
       l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
     }
 #pragma unroll
@@ -723,6 +780,12 @@ static unsigned long long* g_stamps_host_ptr = nullptr;
   do {                                                                                       \
     if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = (unsigned long long)(v); \
   } while (0)
+#elif defined(BBD_MARKS)
+// static-profile build (tools/isa_phases.py): every stamp site leaves a comment in the assembly, so the instruction mix can
+// be summed per phase without running anything
+#define BBD_STAMP(k) asm volatile("; bbd_mark " #k)
+#define BBD_STAMP_RT(k) do { } while (0)
+#define BBD_STAMP_VAL(k, v) do { } while (0)
 #else
 #define BBD_STAMP(k) do { } while (0)
 #define BBD_STAMP_RT(k) do { } while (0)
@@ -739,6 +802,7 @@ struct FwdArgs {
   const float* noise;
   const bbd_cand_t* cand;
   const int32_t* ncand;
+  const int32_t* work;     // optional [S*B*ntiles][2]: bbd_fused_work_items' table (NULL: grid order, decoded here)
   float* min_loss;
   uint8_t* argmin;
   float* partial;
@@ -757,7 +821,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
   // still read candidate c, so one barrier per warp candidate is enough
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
-  __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE];
+  __shared__ __attribute__((aligned(16))) float s_xx[BBD_FWD_SINGLE_BUF ? 1 : 2][3][FPLANE];
   __shared__ float s_red[4];
   int buf = 0;
   const BbdDims dm = a.dm;
@@ -766,11 +830,19 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   // itself - cell tables, staged target tile and window statistics set up once - measured neutral inside the training
   // step and 15 % slower on the micro-benchmark, and its loop structure alone cost this kernel 14 VGPRs and 19 spilled
   // SGPRs: removed, profiles/r03/fwd_scale_loop_ab.txt.)
-  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile(bid - s * a.ntiles, W);
+  int b, s;
+  TileCoord tc;
+  if (a.work != nullptr) {
+    const WorkItem it = load_work_item(a.work);
+    b = it.b; s = it.s;
+    tc.tile = it.tile; tc.tx0 = it.tx0; tc.ty0 = it.ty0;
+  } else {
+    int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    b = bid / (a.S * a.ntiles);
+    bid -= b * a.S * a.ntiles;
+    s = bid / a.ntiles;
+    tc = decode_tile(bid - s * a.ntiles, W);
+  }
   const size_t img = (size_t)3 * hw;
   const size_t sb = (size_t)s * a.B + b;
 
@@ -814,7 +886,9 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   const int pix = yy * W + xx;
 
   float mu_y[3][PPT], sg_y[3][PPT];
+#if !BBD_FWD_RESTAT
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
+#endif
 
   float dcell[CellsF::N];
 #pragma unroll
@@ -833,6 +907,20 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
+#if BBD_FWD_RAYS
+  // camera-space point depth * inv_K (x, y, 1) of every staged cell (layers.py:163-164): it depends on the candidate only
+  // through inv_K, which is the same matrix for every candidate of a sample unless the caller's K rows differ (the
+  // reference slices K by count, trainer.py:431-432) - kept across the loop and redone when a candidate's inv_K bits differ
+  float ray[CellsF::N][3];
+  float ray_ik[9];
+  bool have_rays = false;
+#endif
+#if BBD_FWD_VDIMS
+  BbdDims dmv = dm;       // image-dimension constants as vector registers: SGPR operands double an instruction's issue cost
+  asm volatile("" : "+v"(dmv.wm1), "+v"(dmv.hm1), "+v"(dmv.rw), "+v"(dmv.rh));
+#else
+  const BbdDims dmv = dm;
+#endif
   // pass 1: the warp candidates (a frame's two warps back to back); identity candidates are only noted
   CandOrder order;
   order.init(nc);
@@ -872,14 +960,44 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
     float pj[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
+#if BBD_FWD_RAYS
+    {
+      bool same = have_rays;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) same = same && (__float_as_uint(pj[12 + i]) == __float_as_uint(ray_ik[i]));
+      if (!same) {
+#pragma unroll
+        for (int k = 0; k < CellsF::N; ++k) {
+          BbdSample t;
+          bbd_backproject(pj + 12, cl.xy[k] & 0xffff, cl.xy[k] >> 16, dcell[k], &t);
+          ray[k][0] = t.X; ray[k][1] = t.Y; ray[k][2] = t.Z;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ray_ik[i] = pj[12 + i];
+        have_rays = true;
+      }
+    }
+#endif
+#if BBD_FWD_VPOSE
+#pragma unroll
+    for (int i = 0; i < 12; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(pj[i]) : "s"(pj[i]));
+#endif
     BBD_STAMP(4 + 4 * (vs & 3));
-    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dm, hw, cl, s_xx[buf], wout);
+#if BBD_FWD_RAYS
+    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dmv, hw, cl, s_xx[buf], wout, static_cast<float (*)[TH * TW]>(nullptr), NoWork(), ray);
+#else
+    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dmv, hw, cl, s_xx[buf], wout);
+#endif
     BBD_STAMP(5 + 4 * (vs & 3));
     __syncthreads();
     BBD_STAMP(6 + 4 * (vs & 3));
-    strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+    strip_loss<BBD_FWD_RESTAT != 0>(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
     BBD_STAMP(7 + 4 * (vs & 3));
+#if BBD_FWD_SINGLE_BUF
+    __syncthreads();
+#else
     buf ^= 1;
+#endif
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       int aj = (int)((argw >> (8 * j)) & 0xffu);
@@ -951,6 +1069,7 @@ struct BwdArgs {
   const float* pose;
   const bbd_cand_t* cand;
   const int32_t* ncand;
+  const int32_t* work;
   const uint8_t* argmin;
   const float* gscale;
   float* grad_depth;    // depth-plane mode: d loss / d depth; disparity mode: d loss / d up-sampled disparity
@@ -1029,11 +1148,19 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   float (*s_xy)[2 * BPLANE2] = reinterpret_cast<float (*)[2 * BPLANE2]>(s_xybuf);      // [ch][2 * cell + {0: x, 1: y}]
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
-  int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int b = bid / (a.S * a.ntiles);
-  bid -= b * a.S * a.ntiles;
-  const int s = bid / a.ntiles;
-  const TileCoord tc = decode_tile2(bid - s * a.ntiles, W);
+  int b, s;
+  TileCoord tc;
+  if (a.work != nullptr) {
+    const WorkItem it = load_work_item(a.work);
+    b = it.b; s = it.s;
+    tc.tile = it.tile; tc.tx0 = it.tx0; tc.ty0 = it.ty0;
+  } else {
+    int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    b = bid / (a.S * a.ntiles);
+    bid -= b * a.S * a.ntiles;
+    s = bid / a.ntiles;
+    tc = decode_tile2(bid - s * a.ntiles, W);
+  }
   const size_t img = (size_t)3 * hw;
   const size_t sb = (size_t)s * a.B + b;
   const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
@@ -2133,16 +2260,14 @@ int fill_frames(const void* const* frames, FramePtrs* out) {
   return 0;
 }
 
-// XCD-aware work order: on for single-scale launches (the boosted recipe's epoch >= 10 regime), off for the 4-scale
-// launches; BBD_XCD_REMAP=0 / 1 forces it.  Measured (profiles/r03/xcd_remap_ab.txt, traffic_boosted*.json): m = 7 with
-// per-pixel random disparities forward -11 %, backward -3 %; inside the training step the time is unchanged but the
-// fabric-side traffic drops (neighbouring tiles, and a frame's two warps, then meet in ONE XCD's L2); with four scales the
-// forward is 2.5 % slower (the scales of a sample no longer run side by side on all XCDs).
+// XCD-aware work order without a table (xcd_work_item: a contiguous range of work items per XCD): the identity pre-pass
+// (always: in-step fabric traffic 124 -> 65 MB and -6 % time for MD2, profiles/r04/work_order_ab.txt) and the fused launches
+// when the caller passes no work-item table and there is one scale (round 3: profiles/r03/xcd_remap_ab.txt; with several
+// scales a range split hands whole scales of different cost to different XCDs).  BBD_XCD_REMAP=0 / 1 forces it.
 int xcd_remap_enabled(int S) {
-  static const int forced = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr ? -1 : (e[0] == '1'); }();
+  static const int forced = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr ? -1 : (e[0] - '0'); }();
   return forced >= 0 ? forced : (S == 1);
 }
-
 int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -2161,6 +2286,32 @@ int bbd_num_tiles_fwd(int H, int W) {      /* tiles of the fused FORWARD launch:
 }
 int bbd_num_tiles_bwd(int H, int W) { return ((H + TH - 1) / TH) * ((W + TW2 - 1) / TW2); }
 
+int bbd_fused_work_items(int B, int S, int H, int W, int backward, const int32_t* sample_order, int32_t* out) {
+  if (B <= 0 || S <= 0 || H < 3 || W < 3 || !out || B > (1 << WORK_B_BITS) || S > (1 << WORK_S_BITS)) return BBD_E_BADARG;
+  const int tw = backward ? TW2 : TW;
+  const int tiles_x = (W + tw - 1) / tw, ntiles = tiles_x * ((H + TH - 1) / TH);
+  if (ntiles >= (1 << (32 - WORK_B_BITS - WORK_S_BITS)) || W > 0xffff || H > 0xffff) return BBD_E_BADARG;
+  const int n = B * S * ntiles, q = ntiles >> 3, r = ntiles & 7, bs = B * S;
+  const int head = bs * r * (q + 1);            // the first r slabs hold q + 1 tiles, the others q
+  for (int i = 0; i < n; ++i) {
+    // hardware block i runs on XCD i & 7 (round-robin dispatch); XCD x walks the contiguous range [x n / 8, (x + 1) n / 8)
+    // of the slab-major virtual order v: slab -> sample (caller's order) -> scale -> tile of the slab
+    const int nq = n >> 3, nr = n & 7, x8 = i & 7;
+    const int v = (x8 < nr ? x8 * (nq + 1) : nr * (nq + 1) + (x8 - nr) * nq) + (i >> 3);
+    const int x = v < head ? v / (bs * (q + 1)) : r + (v - head) / (bs * q);
+    const int t0 = x * q + (x < r ? x : r), cs = q + (x < r ? 1 : 0);
+    int w = v - bs * t0;
+    const int rank = w / (S * cs);
+    w -= rank * S * cs;
+    const int s = w / cs, tile = t0 + (w - s * cs);
+    const int b = sample_order != nullptr ? sample_order[rank] : rank;
+    if (b < 0 || b >= B) return BBD_E_BADARG;
+    out[2 * i] = b | (s << WORK_B_BITS) | (tile << (WORK_B_BITS + WORK_S_BITS));
+    out[2 * i + 1] = ((tile % tiles_x) * tw) | (((tile / tiles_x) * TH) << 16);
+  }
+  return 0;
+}
+
 int bbd_identity_loss_fwd(const void* const* frames, const float* target, const int32_t* items, int NI,
                           float* ident, int H, int W, int no_ssim, void* stream) {
   if (!target || !items || !ident || NI < 0 || H < 3 || W < 3) return BBD_E_BADARG;
@@ -2170,7 +2321,7 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   const int ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(identity_loss_kernel, dim3((unsigned)(NI * ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim,
-                     xcd_remap_enabled(0));
+                     xcd_remap_enabled(1));
   return launch_status();
 }
 
@@ -2198,8 +2349,8 @@ static int fill_disp(const void* const* disp, const int32_t* disp_hw, double min
 static int launch_fused_fwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
                             const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                             const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
-                            float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                            int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
+                            const int32_t* work, float* min_loss, uint8_t* argmin, float* partial, float* warped,
+                            float* depth_out, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!target || (!depth && !disp) || !cand || !ncand || !min_loss || !argmin || !partial) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
   FwdArgs a;
@@ -2215,6 +2366,7 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.warped = warped; a.depth_out = depth_out; a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_fwd(H, W);
   a.remap = xcd_remap_enabled(S);
+  a.work = work;
   // (a paired-candidate / packed-SSIM form of this kernel was built and measured slower - profiles/r03/fwdp_ab.txt; its
   // source is kept under tools/experiments/paired_packed_forward.hip.txt)
   if (depth != nullptr)
@@ -2228,8 +2380,8 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
 
 static int launch_fused_bwd(const void* const* frames, const float* target, const float* depth, const void* const* disp,
                             const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
-                            const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
-                            float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W,
+                            const bbd_cand_t* cand, const int32_t* ncand, const int32_t* work, const uint8_t* argmin,
+                            const float* gscale, float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W,
                             int no_ssim, void* stream) {
   if (!target || (!depth && !disp) || !cand || !ncand || !argmin || !gscale || !grad_depth || !grad_proj) return BBD_E_BADARG;
   if (S <= 0 || B <= 0 || H < 3 || W < 3 || NP < 0) return BBD_E_BADARG;
@@ -2246,6 +2398,7 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.S = S; a.B = B; a.NP = NP; a.dm = bbd_dims(H, W); a.no_ssim = no_ssim;
   a.ntiles = bbd_num_tiles_bwd(H, W);
   a.remap = xcd_remap_enabled(S);
+  a.work = work;
   // (a sparse-item form of this kernel - per-candidate winner lists, scatter instead of the dense phases - was built and
   // measured slower inside the training step: profiles/r03/bwd3_*.txt, tools/experiments/sparse_item_backward.hip.txt)
   if (depth != nullptr)
@@ -2262,8 +2415,8 @@ int bbd_warp_ssim_min_fwd(const void* const* frames, const float* target, const 
                           float* min_loss, uint8_t* argmin, float* partial, float* warped, int S, int B, int NP,
                           int H, int W, int no_ssim, void* stream) {
   if (!depth) return BBD_E_BADARG;
-  return launch_fused_fwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, ident, noise, cand, ncand, min_loss,
-                          argmin, partial, warped, nullptr, S, B, NP, H, W, no_ssim, stream);
+  return launch_fused_fwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, ident, noise, cand, ncand, nullptr,
+                          min_loss, argmin, partial, warped, nullptr, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const float* depth, const float* proj,
@@ -2271,28 +2424,28 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
                           float* grad_depth, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim,
                           void* stream) {
   if (!depth) return BBD_E_BADARG;
-  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, argmin, gscale,
+  return launch_fused_bwd(frames, target, depth, nullptr, nullptr, 0.0, 0.0, proj, cand, ncand, nullptr, argmin, gscale,
                           grad_depth, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                                const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
-                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                               int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
+                               const int32_t* work_items, float* min_loss, uint8_t* argmin, float* partial, float* warped,
+                               float* depth_out, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
   return launch_fused_fwd(frames, target, nullptr, disp, disp_hw, min_depth, max_depth, proj, ident, noise, cand, ncand,
-                          min_loss, argmin, partial, warped, depth_out, S, B, NP, H, W, no_ssim, stream);
+                          work_items, min_loss, argmin, partial, warped, depth_out, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* depth,
                                const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
-                               const uint8_t* argmin, const float* gscale, float* grad_up, float* grad_proj, int S, int B,
-                               int NP, int H, int W, int no_ssim, void* stream) {
+                               const int32_t* work_items, const uint8_t* argmin, const float* gscale, float* grad_up,
+                               float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim, void* stream) {
   if (!disp) return BBD_E_BADARG;
-  return launch_fused_bwd(frames, target, depth, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, argmin, gscale,
-                          grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
+  return launch_fused_bwd(frames, target, depth, disp, disp_hw, min_depth, max_depth, proj, cand, ncand, work_items, argmin,
+                          gscale, grad_up, grad_proj, S, B, NP, H, W, no_ssim, stream);
 }
 
 int bbd_identity_loss_grouped_fwd(const void* const* frames, const float* target, const int32_t* items,
@@ -2304,7 +2457,7 @@ int bbd_identity_loss_grouped_fwd(const void* const* frames, const float* target
   const int ntiles = bbd_num_tiles(H, W);
   hipLaunchKernelGGL(identity_loss_grouped_kernel, dim3((unsigned)(G * ntiles)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), fp, target, items, group_off, ident, H, W, ntiles, no_ssim,
-                     xcd_remap_enabled(0));
+                     xcd_remap_enabled(1));
   return launch_status();
 }
 

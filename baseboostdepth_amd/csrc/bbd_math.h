@@ -178,18 +178,20 @@ BBD_HD float bbd_dot4_hom(const float* a, float x, float y, float z) {   /* a . 
   return fmaf(a[3], 1.0f, fmaf(a[2], z, fmaf(a[1], y, a[0] * x)));
 }
 
-/* proj = 21 floats: P (3x4 row-major), inv_K[:3,:3] (row-major). */
-BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const BbdDims& dm, BbdSample* o) {
-  const float* P = proj;
-  const float* iK = proj + 12;
+/* Camera-space point of pixel (xx, yy) at `depth` (layers.py:163-164  cam = depth * (inv_K[:3,:3] @ [x,y,1])): depends on
+ * the pixel and on inv_K only, not on the candidate's pose. */
+BBD_HD void bbd_backproject(const float* iK, int xx, int yy, float depth, BbdSample* o) {
   const float fx = (float)xx, fy = (float)yy;
-  /* layers.py:163-164  cam = depth * (inv_K[:3,:3] @ [x,y,1]) */
   o->cx = bbd_dot3_hom(iK, fx, fy);
   o->cy = bbd_dot3_hom(iK + 3, fx, fy);
   o->cz = bbd_dot3_hom(iK + 6, fx, fy);
   o->X = depth * o->cx;
   o->Y = depth * o->cy;
   o->Z = depth * o->cz;
+}
+
+/* Projection of the camera-space point already in o->X/Y/Z through P (3x4 row-major) to clamped source coordinates. */
+BBD_HD void bbd_project_point(const float* P, const BbdDims& dm, BbdSample* o) {
   /* layers.py:185  q = P @ [X,Y,Z,1] */
   const float qx = bbd_dot4_hom(P, o->X, o->Y, o->Z);
   const float qy = bbd_dot4_hom(P + 4, o->X, o->Y, o->Z);
@@ -227,6 +229,12 @@ BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const Bb
   iy = iy > 0.0f ? iy : 0.0f;
   o->ix = ix < wm1 ? ix : wm1;
   o->iy = iy < hm1 ? iy : hm1;
+}
+
+/* proj = 21 floats: P (3x4 row-major), inv_K[:3,:3] (row-major). */
+BBD_HD void bbd_project(const float* proj, int xx, int yy, float depth, const BbdDims& dm, BbdSample* o) {
+  bbd_backproject(proj + 12, xx, yy, depth, o);
+  bbd_project_point(proj, dm, o);
 }
 
 /* bbd_project for the backward's warp recompute: the same operation sequence with the unguarded divisions. */

@@ -73,6 +73,21 @@ class HipBackend:
     def smooth_chunks(self):
         return self.lib.smooth_chunks
 
+    def fused_work_items(self, plan, S, H, W, backward, device):
+        """Device table [S*B*ntiles, 2] of bbd_fused_work_items (slab order per XCD, the plan's samples with the most
+        candidates first), built once per (plan, S, H, W, direction) and cached on the plan's device tables."""
+        if os.environ.get("BBD_WORK_TABLE", "1") == "0":      # A/B switch: grid order, decoded in the kernel
+            return None
+        tb = plan.tables(device)
+        key = ("work", S, H, W, int(backward))
+        if key not in tb:
+            n = S * plan.B * (self.num_tiles_bwd(H, W) if backward else self.num_tiles_fwd(H, W))
+            host = torch.empty(n, 2, dtype=torch.int32)
+            order = None if plan.sample_order is None else (ctypes.c_int32 * plan.B)(*plan.sample_order)
+            self.lib.call("bbd_fused_work_items", plan.B, S, H, W, int(backward), order, host.data_ptr())
+            tb[key] = host.to(device)
+        return tb[key]
+
     @staticmethod
     def _check(*tensors):
         for t in tensors:
@@ -432,8 +447,8 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         backend.run("bbd_pose_expand", proj, ptr(proj), ptr(ptab), plan.NP)
         backend.run("bbd_warp_ssim_min_disp_fwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps),
                     float(min_depth), float(max_depth), ptr(ptab), ptr(ident), ptr(noise), ptr(tb["cand"]),
-                    ptr(tb["ncand"]), ptr(min_loss), ptr(argmin), ptr(partial), ptr(warped), ptr(depth), S, B,
-                    plan.NP, H, W, int(no_ssim))
+                    ptr(tb["ncand"]), ptr(backend.fused_work_items(plan, S, H, W, False, dev)), ptr(min_loss), ptr(argmin),
+                    ptr(partial), ptr(warped), ptr(depth), S, B, plan.NP, H, W, int(no_ssim))
         # the depth by-product is handed to the caller (outputs[("depth",0,s)], NOT differentiable: a depth-based
         # regulariser must use disp_to_depth / opt.fused_disp=False) AND read by the backward: saving it
         # through autograd makes an in-place edit by the caller an error instead of a silently corrupted gradient
@@ -462,8 +477,8 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         ntb = backend.num_tiles_bwd(H, W)
         gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
         backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
-                    ptr(depth), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial),
-                    S, B, plan.NP, H, W, no_ssim)
+                    ptr(depth), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(backend.fused_work_items(plan, S, H, W, True, dev)),
+                    ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial), S, B, plan.NP, H, W, no_ssim)
         # a scale at full resolution: grad_up IS its disparity gradient; the reduced ones share one adjoint launch
         grads, small, small_g, small_up = [None] * S, [], [], []
         for i, d in enumerate(disps):

@@ -123,6 +123,11 @@ class ReprojectionPlan:
             ncand[b] = len(entries)
             self.cand_names.append(names)
         self.cand_np, self.ncand_np = cand, ncand
+        # the order in which the fused launches' workgroups take the samples (bbd_fused_work_items' `sample_order`): most
+        # candidates first, so that a batch mixing 8-, 14- and 18-candidate samples ends on its cheap workgroups
+        # (stable: equal counts keep batch order; None = batch order, nothing to upload)
+        order = sorted(range(self.B), key=lambda b: -int(ncand[b]))
+        self.sample_order = None if order == list(range(self.B)) else order
         self._dev = {}
 
     # ------------------------------------------------------------------ row bookkeeping

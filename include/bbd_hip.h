@@ -31,7 +31,7 @@ extern "C" {
  * scratch sizing changed (round 2, was not bumped then); 3 = round 3 (backward tiling / scratch contract); 4 = the
  * depth-wise token weight gradient's scratch contract (one partial row per workgroup) and `add_input` of
  * bbd_dwconv_tokens_fwd became a bit field (round 3, with the bbd_token_ln_* / bbd_colsum additions). */
-#define BBD_ABI_VERSION 4
+#define BBD_ABI_VERSION 5
 
 /* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
  * trainer.py:428).  A "slot" indexes a host array of their base pointers. */
@@ -164,17 +164,26 @@ int bbd_warp_ssim_min_bwd(const void* const* frames, const float* target, const 
  * The backward takes `depth` = the forward's depth_out (or NULL: it then re-evaluates the up-sampling per staged
  * pixel, +5 % instructions) and hands back grad_up [S,B,H,W] = d loss / d (up-sampled disparity); for a scale at full
  * resolution that IS the disparity gradient, the reduced scales go through bbd_disp_upsample_adjoint
- * (ONE launch for all of them; n <= 4 entries: grad_up[i] -> grad_disp[i] [B,h_i,w_i]; deterministic).      */
+ * (ONE launch for all of them; n <= 4 entries: grad_up[i] -> grad_disp[i] [B,h_i,w_i]; deterministic).
+ * work_items (device [S*B*ntiles][2] int32 from bbd_fused_work_items, or NULL = grid order decoded in the kernel): which
+ * (sample, scale, tile) each workgroup takes.  A speed choice: results do not depend on it.                 */
 int bbd_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                                const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
-                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
-                               int S, int B, int NP, int H, int W, int no_ssim, void* stream);
+                               const int32_t* work_items, float* min_loss, uint8_t* argmin, float* partial, float* warped,
+                               float* depth_out, int S, int B, int NP, int H, int W, int no_ssim, void* stream);
 int bbd_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                                const int32_t* disp_hw, double min_depth, double max_depth, const float* depth,
                                const float* proj, const bbd_cand_t* cand, const int32_t* ncand,
-                               const uint8_t* argmin, const float* gscale, float* grad_up, float* grad_proj, int S, int B,
-                               int NP, int H, int W, int no_ssim, void* stream);
+                               const int32_t* work_items, const uint8_t* argmin, const float* gscale, float* grad_up,
+                               float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim, void* stream);
+/* Work order of the fused launches (host function, fills a HOST buffer the caller uploads once per batch signature):
+ * out [S*B*ntiles][2] for the forward (backward = 0, ntiles = bbd_num_tiles_fwd) or the backward (1, bbd_num_tiles_bwd)
+ * launch.  Slab order: every XCD walks one slab of consecutive tiles - for every sample in `sample_order` (host [B], a
+ * permutation of 0..B-1, or NULL = 0..B-1; list the samples with the most candidates first so that a batch mixing 8-,
+ * 14- and 18-candidate samples, mono_dataset.py:87-109, ends on its cheap workgroups), for every scale, the slab's
+ * tiles - so the scales of a sample share one XCD's L2 and every XCD gets the same work.                    */
+int bbd_fused_work_items(int B, int S, int H, int W, int backward, const int32_t* sample_order, int32_t* out);
 int bbd_disp_upsample_adjoint(const void* const* grad_up, const int32_t* disp_hw, void* const* grad_disp, int n, int B,
                               int H, int W, void* stream);
 
