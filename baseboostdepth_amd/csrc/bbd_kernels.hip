@@ -103,6 +103,22 @@ __device__ __forceinline__ float wave_sum63(float v) {
   return a;
 }
 
+// bitwise OR over the wave on the same crossbar steps; result valid in lane 63
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ unsigned dpp0u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ unsigned wave_or63(unsigned v) {
+  unsigned a = v | dpp0u<0x111, 0xf, 0xf>(v);
+  a |= dpp0u<0x112, 0xf, 0xf>(v);
+  a |= dpp0u<0x113, 0xf, 0xf>(v);
+  a |= dpp0u<0x114, 0xf, 0xe>(a);
+  a |= dpp0u<0x118, 0xf, 0xc>(a);
+  a |= dpp0u<0x142, 0xa, 0xf>(a);
+  a |= dpp0u<0x143, 0xc, 0xf>(a);
+  return a;
+}
+
 // Twelve wave totals at once (the 3x4 pose-gradient of a candidate): a reduce-scatter instead of twelve full
 // reductions.  v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even 16-lane rows of TWO registers,
 // so one swap + one add folds a pair of values through a butterfly level and leaves each half (row) holding a
@@ -1143,7 +1159,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   __shared__ uint16_t s_list[CH * CW2];
   __shared__ __attribute__((aligned(16))) float s_dv[6][TH * TW2];
   __shared__ float s_red[NT2 / 64][12];
-  __shared__ unsigned s_present;
+  __shared__ unsigned s_present[NT2 / 64];
   __shared__ int s_count;
   float (*s_xy)[2 * BPLANE2] = reinterpret_cast<float (*)[2 * BPLANE2]>(s_xybuf);      // [ch][2 * cell + {0: x, 1: y}]
   const BbdDims dm = a.dm;
@@ -1222,18 +1238,19 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   float gdepth[PPT2] = {0.0f, 0.0f};
 
   BBD_STAMP(23);
-  if (threadIdx.x == 0) { s_present = 0u; s_count = 0; }
+  if (threadIdx.x == 0) s_count = 0;
   for (int i = threadIdx.x; i < 3 * CPLANE2 / 4; i += NT2)
     reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   BBD_STAMP(24);
-  __syncthreads();
-  BBD_STAMP(25);
   {
+    // which candidates won a pixel in or next to this tile: OR over the wave on the DPP crossbar, one word per wave - no
+    // LDS atomic and no barrier of its own (round 3 zeroed a shared word, synchronised, then OR-ed into it atomically)
     unsigned mine = 0u;
 #pragma unroll
     for (int k = 0; k < NP_CELLS; ++k)
       if (BBD_PARG(k) != 255u) mine |= 1u << BBD_PARG(k);
-    if (mine) atomicOr(&s_present, mine);
+    const unsigned wave_mine = wave_or63(mine);
+    if ((threadIdx.x & 63) == 63) s_present[threadIdx.x >> 6] = wave_mine;
   }
   BBD_STAMP(26);
 #pragma unroll
@@ -1250,7 +1267,9 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(B
   BBD_STAMP(1);
   __syncthreads();
   BBD_STAMP(2);
-  const unsigned present = s_present;
+  unsigned present = 0u;
+#pragma unroll
+  for (int w8 = 0; w8 < NT2 / 64; ++w8) present |= s_present[w8];
 
   int prev = -1;
   CandOrder order;                       // a frame's true-pose and error-induced warps back to back (cache locality)
