@@ -35,24 +35,6 @@
 #ifndef BBD_BWD_WARP_BATCH
 #define BBD_BWD_WARP_BATCH 2
 #endif
-#ifndef BBD_IDENT_PASS2
-#define BBD_IDENT_PASS2 1
-#endif
-#ifndef BBD_FWD_RAYS
-#define BBD_FWD_RAYS 0     // forward: camera-space points of the staged cells kept across the candidate loop
-#endif
-#ifndef BBD_FWD_SINGLE_BUF
-#define BBD_FWD_SINGLE_BUF 0   // experiment: warped tile single-buffered (4 workgroups per CU fit in LDS)
-#endif
-#ifndef BBD_FWD_RESTAT
-#define BBD_FWD_RESTAT 0       // experiment: target-window statistics re-derived per candidate, not held
-#endif
-#ifndef BBD_FWD_VDIMS
-#define BBD_FWD_VDIMS 0    // forward: image-dimension constants of the projection in VGPRs (issue class A instead of B)
-#endif
-#ifndef BBD_FWD_VPOSE
-#define BBD_FWD_VPOSE 0    // forward: the 12 entries of P in VGPRs per candidate
-#endif
 
 namespace {
 
@@ -442,7 +424,7 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
                                               const float (&pj)[21], const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
                                               float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
-                                              Work under_gathers = Work(), float (*ray)[3] = nullptr) {
+                                              Work under_gathers = Work()) {
   // pj = P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table by the caller, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
@@ -468,14 +450,8 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
 #pragma unroll
       for (int kk = 2 * NPAIR; kk < BATCH; ++kk) {
         const int k = k0 + kk < CellsT::N ? k0 + kk : CellsT::N - 1;
-        if (BWD) {
-          bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
-        } else if (ray != nullptr) {      // the cell's camera-space point is candidate-independent: kept by the caller
-          smp[kk].X = ray[k][0]; smp[kk].Y = ray[k][1]; smp[kk].Z = ray[k][2];
-          bbd_project_point(pj, dm, &smp[kk]);
-        } else {
-          bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
-        }
+        if (BWD) bbd_project_bwd(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
+        else bbd_project(pj, cl.xy[k] & 0xffff, cl.xy[k] >> 16, d[k], dm, &smp[kk]);
       }
     }
 #pragma unroll
@@ -585,7 +561,6 @@ __device__ __forceinline__ void strip_ystats(const float (*sy)[FPLANE], int ly, 
 }
 
 // Photometric loss of the strip's 4 pixels given the staged prediction (sx) and target (sy).
-template <bool RESTAT = false>
 __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const float (*sy)[FPLANE],
                                            int ly, int lx0, const float mu_y[3][PPT],
                                            const float sg_y[3][PPT], int no_ssim, float out[PPT]) {
@@ -598,7 +573,7 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
     float nn[PPT], dd[PPT], qq[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      float s = 0.0f, ss = 0.0f, sxy = 0.0f, ty = 0.0f, tyy = 0.0f;
+      float s = 0.0f, ss = 0.0f, sxy = 0.0f;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -607,15 +582,8 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
           s += v;
           ss += v * v;
           sxy += v * y[r][j + c];
-          if (RESTAT) {
-            ty += y[r][j + c];
-            tyy += y[r][j + c] * y[r][j + c];
-          }
         }
-      float my = 0.0f, gy = 0.0f;
-      if (RESTAT) bbd_ystats(ty, tyy, &my, &gy);
-      else { my = mu_y[ch][j]; gy = sg_y[ch][j]; }
-      bbd_ssim_nd(s, ss, sxy, my, gy, &nn[j], &dd[j]);
+      bbd_ssim_nd(s, ss, sxy, mu_y[ch][j], sg_y[ch][j], &nn[j], &dd[j]);
       l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
     }
 #pragma unroll
@@ -837,7 +805,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
   // still read candidate c, so one barrier per warp candidate is enough
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
-  __shared__ __attribute__((aligned(16))) float s_xx[BBD_FWD_SINGLE_BUF ? 1 : 2][3][FPLANE];
+  __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE];
   __shared__ float s_red[4];
   int buf = 0;
   const BbdDims dm = a.dm;
@@ -902,9 +870,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   const int pix = yy * W + xx;
 
   float mu_y[3][PPT], sg_y[3][PPT];
-#if !BBD_FWD_RESTAT
   strip_ystats(s_y, ly, lx0, mu_y, sg_y);
-#endif
 
   float dcell[CellsF::N];
 #pragma unroll
@@ -923,20 +889,6 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   for (int j = 0; j < PPT; ++j) best[j] = INFINITY;
   BBD_STAMP(3);
 
-#if BBD_FWD_RAYS
-  // camera-space point depth * inv_K (x, y, 1) of every staged cell (layers.py:163-164): it depends on the candidate only
-  // through inv_K, which is the same matrix for every candidate of a sample unless the caller's K rows differ (the
-  // reference slices K by count, trainer.py:431-432) - kept across the loop and redone when a candidate's inv_K bits differ
-  float ray[CellsF::N][3];
-  float ray_ik[9];
-  bool have_rays = false;
-#endif
-#if BBD_FWD_VDIMS
-  BbdDims dmv = dm;       // image-dimension constants as vector registers: SGPR operands double an instruction's issue cost
-  asm volatile("" : "+v"(dmv.wm1), "+v"(dmv.hm1), "+v"(dmv.rw), "+v"(dmv.rh));
-#else
-  const BbdDims dmv = dm;
-#endif
   // pass 1: the warp candidates (a frame's two warps back to back); identity candidates are only noted
   CandOrder order;
   order.init(nc);
@@ -946,26 +898,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
     bbd_cand_t cd;
     const int c = order.next(a.cand + b * BBD_MAX_CAND, &cd);
     if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) {
-#if BBD_IDENT_PASS2
       idents |= 1u << c;
-#else
-      float il[PPT] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (row_ok) {
-        load_strip(a.ident + (size_t)cd.row * hw + pix, xx, W, vec_ok, il);
-        if (a.noise != nullptr) {
-          float nz[PPT];
-          load_strip(a.noise + (size_t)b * hw + pix, xx, W, vec_ok, nz);
-#pragma unroll
-          for (int j = 0; j < PPT; ++j) il[j] += nz[j];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        int aj = (int)((argw >> (8 * j)) & 0xffu);
-        min_update_any_order(il[j], c, &best[j], &aj);
-        argw = (argw & ~(0xffu << (8 * j))) | ((unsigned)aj << (8 * j));
-      }
-#endif
       continue;
     }
     const int vs = visit++;
@@ -976,44 +909,14 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
     float pj[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
-#if BBD_FWD_RAYS
-    {
-      bool same = have_rays;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) same = same && (__float_as_uint(pj[12 + i]) == __float_as_uint(ray_ik[i]));
-      if (!same) {
-#pragma unroll
-        for (int k = 0; k < CellsF::N; ++k) {
-          BbdSample t;
-          bbd_backproject(pj + 12, cl.xy[k] & 0xffff, cl.xy[k] >> 16, dcell[k], &t);
-          ray[k][0] = t.X; ray[k][1] = t.Y; ray[k][2] = t.Z;
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) ray_ik[i] = pj[12 + i];
-        have_rays = true;
-      }
-    }
-#endif
-#if BBD_FWD_VPOSE
-#pragma unroll
-    for (int i = 0; i < 12; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(pj[i]) : "s"(pj[i]));
-#endif
     BBD_STAMP(4 + 4 * (vs & 3));
-#if BBD_FWD_RAYS
-    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dmv, hw, cl, s_xx[buf], wout, static_cast<float (*)[TH * TW]>(nullptr), NoWork(), ray);
-#else
-    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dmv, hw, cl, s_xx[buf], wout);
-#endif
+    warp_into_lds<BBD_WARP_BATCH, CellsF, FPLANE>(src, dcell, pj, dm, hw, cl, s_xx[buf], wout);
     BBD_STAMP(5 + 4 * (vs & 3));
     __syncthreads();
     BBD_STAMP(6 + 4 * (vs & 3));
-    strip_loss<BBD_FWD_RESTAT != 0>(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+    strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
     BBD_STAMP(7 + 4 * (vs & 3));
-#if BBD_FWD_SINGLE_BUF
-    __syncthreads();
-#else
     buf ^= 1;
-#endif
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       int aj = (int)((argw >> (8 * j)) & 0xffu);
