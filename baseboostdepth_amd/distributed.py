@@ -8,6 +8,7 @@ flatten/unflatten copies, `zero_grad` is one memset, and the exchange is a singl
 all-reduce over xGMI (107 MB; a ring moves 2*(N-1)/N of that per link, ~1.2 ms at 8 GPUs, which
 is small against the conv backward - see DESIGN.md for why it is not bucketed further).
 """
+import datetime
 import os
 
 import torch
@@ -243,11 +244,15 @@ def init_from_env(backend=None):
         if backend is None:
             # BBD_DIST_BACKEND=gloo lets a single-GPU box exercise the multi-rank code path (tests)
             backend = os.environ.get("BBD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # a bounded rendezvous / collective timeout: a rank that never arrives must end the job with an error, not hang it
+        # (the default is 10 minutes for RCCL and 30 for gloo); BBD_DIST_TIMEOUT_S overrides
+        timeout = datetime.timedelta(seconds=float(os.environ.get("BBD_DIST_TIMEOUT_S", "120")))
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
 
 
@@ -259,37 +264,36 @@ def attach(trainer, group=None):
         return None
     flat = FlatGradients(getattr(trainer, "optimizer_parameters", None) or trainer.parameters_to_train)
     trainer.flat_grads = flat
-    if True:
-        # identical initial weights on every rank
-        for p in flat.params:
-            dist.broadcast(p.data, src=0, group=group)
-        for m in trainer.models.values():
-            for b in m.buffers():
-                if b.is_floating_point():
-                    dist.broadcast(b.data, src=0, group=group)
-        # a step replayed as hipGraphs cannot launch collectives from autograd hooks: the split-graph step packs inside
-        # its forward+backward graph and exchanges the whole buffer between its two graphs
-        # ... unless the collectives themselves are captured (`dp_capture`: RCCL only - gloo cannot be captured): then the
-        # bucketed all-reduces launched from the autograd hooks become nodes of the ONE step graph and overlap backward
-        # inside the replay
-        capture = bool(getattr(trainer, "dp_capture", False)) and dist.get_backend(group) == "nccl"
-        trainer.dp_capture = capture
-        overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1" and (capture or not getattr(trainer, "use_graph", False))
-        bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
-        never = trainer.gradient_free_parameters() if hasattr(trainer, "gradient_free_parameters") else ()
-        trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket, never=never) if overlap
-                             else GradientAverager(flat, group))
-        if capture and overlap:
-            # RCCL sets its channels / connections up lazily, per message size, by talking to its peers: let that happen
-            # here, where every rank is, not inside one rank's graph capture (a cache miss is a per-rank event)
-            for sl in trainer.grad_sync.slices:
-                trainer.grad_sync._reduce(sl)
-            torch.cuda.synchronize()
-            flat.flat.zero_()
-        side = trainer._pose_stream() if hasattr(trainer, "_pose_stream") else None
-        if overlap and side is not None:
-            # the stream process_batch ran on (the default stream in the eager loop, the capturing stream while a step
-            # graph is being captured - a capturing stream must not wait on a stream outside the capture) + the pose stream
-            default = torch.cuda.default_stream(trainer.device)
-            trainer.grad_sync.streams = lambda: [getattr(trainer, "_main_stream", None) or default, side]
+    # identical initial weights on every rank
+    for p in flat.params:
+        dist.broadcast(p.data, src=0, group=group)
+    for m in trainer.models.values():
+        for b in m.buffers():
+            if b.is_floating_point():
+                dist.broadcast(b.data, src=0, group=group)
+    # a step replayed as hipGraphs cannot launch collectives from autograd hooks: the split-graph step packs inside
+    # its forward+backward graph and exchanges the whole buffer between its two graphs
+    # ... unless the collectives themselves are captured (`dp_capture`: RCCL only - gloo cannot be captured): then the
+    # bucketed all-reduces launched from the autograd hooks become nodes of the ONE step graph and overlap backward
+    # inside the replay
+    capture = bool(getattr(trainer, "dp_capture", False)) and dist.get_backend(group) == "nccl"
+    trainer.dp_capture = capture
+    overlap = os.environ.get("BBD_NO_OVERLAP", "0") != "1" and (capture or not getattr(trainer, "use_graph", False))
+    bucket = int(os.environ.get("BBD_BUCKET_BYTES", str(32 << 20)))
+    never = trainer.gradient_free_parameters() if hasattr(trainer, "gradient_free_parameters") else ()
+    trainer.grad_sync = (OverlappedGradientAverager(flat, group, bucket, never=never) if overlap
+                         else GradientAverager(flat, group))
+    if capture and overlap:
+        # RCCL sets its channels / connections up lazily, per message size, by talking to its peers: let that happen
+        # here, where every rank is, not inside one rank's graph capture (a cache miss is a per-rank event)
+        for sl in trainer.grad_sync.slices:
+            trainer.grad_sync._reduce(sl)
+        torch.cuda.synchronize()
+        flat.flat.zero_()
+    side = trainer._pose_stream() if hasattr(trainer, "_pose_stream") else None
+    if overlap and side is not None:
+        # the stream process_batch ran on (the default stream in the eager loop, the capturing stream while a step
+        # graph is being captured - a capturing stream must not wait on a stream outside the capture) + the pose stream
+        default = torch.cuda.default_stream(trainer.device)
+        trainer.grad_sync.streams = lambda: [getattr(trainer, "_main_stream", None) or default, side]
     return flat

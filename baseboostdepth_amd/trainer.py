@@ -82,7 +82,7 @@ class Trainer:
         # every parameter the optimizer steps, in group order (the gradient exchange packs exactly these)
         self.optimizer_parameters = [p for g in self.model_optimizer.param_groups for p in g["params"]]
         self._graphs = {}
-        self.max_graphs = int(os.environ.get("BBD_MAX_GRAPHS", "8"))
+        self.max_graphs = max(1, int(os.environ.get("BBD_MAX_GRAPHS", "8")))      # (0 / negative would empty an empty LRU)
         # data parallel + step graph: capture the bucketed RCCL all-reduces INTO the graph (one graph per step, exchange
         # overlapped with backward inside the replay) instead of two graphs around one exposed all-reduce.  Opt-in:
         # multi-rank RCCL capture cannot be exercised on the one-GPU boxes this was built on
@@ -144,6 +144,7 @@ class Trainer:
     def _graph_key(self, inputs):
         """Batches that replay the same graph: same candidate plan, same tensor shapes, same lr."""
         shapes = tuple(sorted((str(k), tuple(v.shape)) for k, v in inputs.items() if torch.is_tensor(v) and v.is_cuda))
+        # (train_step has made `cutt` a host value: float() of a device tensor here would be a device -> host sync per step)
         return (str(inputs["ordering"]), str(inputs.get("frames")), float(inputs["cutt"]), tuple(self.opt.scales), shapes,
                 tuple(g["lr"] for g in self.model_optimizer.param_groups))
 
@@ -211,6 +212,29 @@ class Trainer:
                     losses["loss"].backward()
                     self.model_optimizer.step()
             elif self.dp_capture:
+                # Captured collectives have only ever run with the ONE rank a single-GPU box allows, so the
+                # first captured signature is checked against the eager data-parallel step on the same batch: one eager
+                # step WITH its exchange gives the reference gradients, the state is restored, and after the first replay
+                # below the flat gradient buffer must agree (every rank takes this path on its first signature: same collectives on
+                # all of them).  BBD_DP_CAPTURE_CHECK=0 skips it.
+                check = (not self._graphs) and os.environ.get("BBD_DP_CAPTURE_CHECK", "1") != "0"
+                if check:
+                    snap2_p = [p.detach().clone() for p in params]
+                    snap2_b = [b.detach().clone() for b in buffers]
+                    snap2_s = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+                               for p, st in self.model_optimizer.state.items()}
+                    self._eager_step(dict(static))
+                    self._capture_reference = self.flat_grads.flat.detach().clone()      # the exchanged (averaged) gradients
+                    with torch.no_grad():
+                        for p, v in zip(params, snap2_p):
+                            p.copy_(v)
+                        for b, v in zip(buffers, snap2_b):
+                            b.copy_(v)
+                        for p, st in self.model_optimizer.state.items():
+                            for k, v in st.items():
+                                if torch.is_tensor(v):
+                                    v.copy_(snap2_s[p][k]) if (p in snap2_s and k in snap2_s[p]) else v.zero_()
+                    self.step = step0
                 # data parallel, collectives captured: ONE graph.  The post-accumulate hooks fire while backward is being
                 # captured, so every bucket's pack + RCCL all-reduce becomes a node on RCCL's stream, forked from and
                 # joined to the capturing stream by the work handles' waits - the replay overlaps the exchange with
@@ -244,6 +268,17 @@ class Trainer:
         if tail is not None:
             self.grad_sync.exchange()
             tail.replay()
+        ref = getattr(self, "_capture_reference", None)
+        if ref is not None:
+            # first replay of the first captured-collective graph vs the eager data-parallel step (see the capture above);
+            # the bar is the run-to-run spread of MIOpen's atomics-based weight gradients, far below a wrong exchange
+            self._capture_reference = None
+            num = float((self.flat_grads.flat - ref).abs().sum())
+            den = float(ref.abs().sum()) + 1e-30
+            if not (num / den < 1e-3):
+                raise RuntimeError("step graph with captured collectives disagrees with the eager data-parallel step on its "
+                                   "first batch (relative L1 difference of the exchanged gradients %.3e): refusing to train "
+                                   "on it; use dp_capture=False (split graphs around one exposed all-reduce)" % (num / den))
         self.step += 1
         return outputs, losses
 
@@ -252,6 +287,11 @@ class Trainer:
         if "frames" in inputs:
             self.opt.frame_ids = sorted(inputs["frames"], key=_frame_sort_key)
         if self.use_graph and self.device.type == "cuda":
+            cutt = inputs.get("cutt")
+            if torch.is_tensor(cutt) and cutt.is_cuda:
+                # the pose-mode threshold is part of the graph key: fetch it ONCE per batch dict (the reference's collate
+                # keeps it on the host, trainer.py:867-886; a caller that moved it pays one sync here, not one per step)
+                inputs["cutt"] = cutt.detach().cpu()
             for key, ipt in inputs.items():
                 if key not in ["frames", "ordering", "cutt"] and torch.is_tensor(ipt):
                     inputs[key] = ipt.to(self.device, non_blocking=True)

@@ -183,14 +183,42 @@ def _free_port():
 
 def self_launch(args, argv):
     """`--gpus N` without a torchrun environment: run the N ranks as a CHILD process group (never exec -
-    this process must not have touched the GPU yet, and does not) and hand its exit status back."""
+    this process must not have touched the GPU yet, and does not) and hand its exit status back.  The child
+    is its own session: if it has not finished after `--launch-timeout` seconds (a hung rendezvous or
+    collective) the whole group is terminated and the status is 124 - a hang cannot outlive the caller."""
+    import signal
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
-    return subprocess.run(cmd, env=env).returncode
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the %d-rank child did not finish within %d s - terminating its process group\n"
+                         % (args.gpus, args.launch_timeout))
+        for sig, grace in ((signal.SIGTERM, 15), (signal.SIGKILL, 15)):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+
+
+def device_identity(local):
+    """A string that is different for every physical GPU of the node: uuid + PCI address where PyTorch exposes them."""
+    pr = torch.cuda.get_device_properties(local)
+    parts = [str(getattr(pr, "uuid", "")), pr.name]
+    if hasattr(pr, "pci_bus_id"):
+        parts.append("%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)))
+    return "|".join(parts)
 
 
 def dry_launch(args):
@@ -236,78 +264,98 @@ def eager_full_step(trainer, inputs, opt, iters=10):
             "what": "same nets + Adam on this GPU, hot path as eager PyTorch-ROCm ops (oracle), batch %d" % plan.B}
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
-    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5", "vit"],
-                    help="md2 = BASELINE configs[1]/[3] (the headline); configs[2] (SURVEY 8d config 3): boosted = "
-                         "worst case m=7 for every sample, boosted15 = the epoch-15 offset distribution (standard "
-                         "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales); "
-                         "vit = configs[4]: MonoViT (mpvit_small) encoder + HR decoder, MD2 frame set")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--channels-last", action="store_true")
-    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
-    ap.add_argument("--no-fused-adam", action="store_true")
-    ap.add_argument("--no-eager-ab", action="store_true",
-                    help="skip timing the hot path / the whole step as eager PyTorch-ROCm ops (oracle) vs the fused kernels")
-    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the whole step (both HIP streams, MIOpen, the C-ABI launches, fused Adam) as one hipGraph: "
-                         "the ~1 200 launches of a step cost ~16 ms of host time, which a slow or busy host CPU turns into "
-                         "the bottleneck (measured: 480 vs 575 images/s on two boxes with identical GPU time).  auto = on for "
-                         "every run, falling back to the eager loop if capture fails; multi-rank runs replay two graphs "
-                         "per step (forward+backward+gradient pack | eager RCCL all-reduce | optimizer)")
-    ap.add_argument("--dp-mode", default="graph", choices=["graph", "overlap", "graph-overlap"],
-                    help="multi-rank loop: graph = two hipGraphs around ONE eager all-reduce of the flat gradient buffer (host "
-                         "out of the loop, exchange exposed); overlap = eager loop, 32 MB buckets all-reduced from autograd "
-                         "hooks while backward still runs; graph-overlap = ONE hipGraph per step with the bucketed RCCL "
-                         "all-reduces captured into it (host out of the loop AND exchange overlapped; opt-in until it has run on "
-                         "a multi-GPU node).  graph / overlap print `exchange_ms` (exposed wait) so one node can compare them")
-    ap.add_argument("--dry-launch", action="store_true",
-                    help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
-    argv = list(sys.argv[1:] if argv is None else argv)
-    args = ap.parse_args(argv)
+ISSUE_NOTE = ("stall (the launch runs at frac_of_issue_bound of its vector-issue bound, kernels.*; HBM traffic is at or below "
+              "the algorithmic bytes - DESIGN.md 3, findings 14 and 26)")
 
-    # ---- multi-rank launch: before ANY GPU call (torch.cuda.* initialises HIP; a process that has done so
-    #      must never be replaced, and the children must find the devices untouched)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(args, argv)
-    if args.dry_launch:
-        return dry_launch(args)
 
+def committed_constants(config):
+    """Counter-derived constants bench.py quotes next to its own measurements: per-kernel HBM traffic of a committed
+    rocprofv3 PMC pass of this workload and the static instruction mix, with the hash of the kernel source they were
+    taken from (tools/pmc_summary.py, tools/isa_mix.py).  `stale` = the shipped source is not that source."""
+    from baseboostdepth_amd.csrc.build import source_sha16
+    now = source_sha16()
+    out = {"traffic": None, "traffic_path": None, "isa_mix": {}, "isa_mix_path": None, "source_sha16": now, "stale": []}
+    for rnd in ("r04", "r03", "r02", "r01"):
+        cand = os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % config)
+        if out["traffic"] is None and os.path.isfile(cand):
+            out["traffic"], out["traffic_path"] = json.load(open(cand)), os.path.relpath(cand, ROOT)
+        cand = os.path.join(ROOT, "profiles", rnd, "isa_mix.json")
+        if not out["isa_mix"] and os.path.isfile(cand):
+            out["isa_mix"], out["isa_mix_path"] = json.load(open(cand)), os.path.relpath(cand, ROOT)
+    for name, blob, path in (("traffic", out["traffic"], out["traffic_path"]), ("isa_mix", out["isa_mix"], out["isa_mix_path"])):
+        if blob and blob.get("kernel_source_sha16") != now:
+            out["stale"].append("%s (%s: taken from source %s, shipped %s)" % (name, path, blob.get("kernel_source_sha16"), now))
+    return out
+
+
+def kernel_table(timer, plan, S, config, batch):
+    """Per hot-path kernel: this run's HIP-event mean, the algorithmic GB/s it implies, and (batch 12 only) the committed
+    counter constants.  Returns (kernels, dominant kernel, roofline)."""
+    nbytes = algorithmic_bytes(plan, S)
+    kernels = {}
+    for name, (count, mean_ms) in timer.summary().items():
+        if name in nbytes and mean_ms > 0:
+            gbps = nbytes[name] / (mean_ms * 1e-3) / 1e9
+            kernels[name] = {"launches": count, "mean_ms": round(mean_ms, 4), "alg_MB_per_launch": round(nbytes[name] / 1e6, 2),
+                             "achieved_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4)}
+    if not kernels:
+        return {}, None, None, None
+    dom = max(kernels, key=lambda k: kernels[k]["mean_ms"])
+    cc = committed_constants(config)
+    traffic = None
+    alias = lambda k: k.replace("_disp_", "_")           # PMC files name the kernels, not the entry points
+    if batch == 12 and cc["traffic"] is not None:
+        tj = cc["traffic"]
+        traffic = tj.get(alias(dom), {}).get("traffic_bytes")
+        for k in kernels:
+            e = tj.get(alias(k))
+            if not e:
+                continue
+            kernels[k]["pmc_traffic_MB_per_launch"] = round(e["traffic_bytes"] / 1e6, 1)
+            mix = cc["isa_mix"].get(alias(k))
+            if "valu_wave_instructions" in e and mix:
+                # vector-issue bound (DESIGN.md 3, finding 14): the launch's counter-measured vector instructions (a
+                # committed PMC pass, not this run) x the kernel's mean cycles per instruction by static issue class at
+                # 2.4 GHz over 1024 SIMDs = the time the launch would take if two waves could always issue on every SIMD.
+                # (No entry for a kernel the instruction-mix file does not list - no default.)
+                bound_ms = e["valu_wave_instructions"] * mix["cycles_per_valu_instruction"] / 1024 / 2.4e9 * 1e3
+                kernels[k]["issue_bound_ms"] = round(bound_ms, 4)
+                kernels[k]["frac_of_issue_bound"] = round(bound_ms / kernels[k]["mean_ms"], 3)
+    fib = kernels[dom].get("frac_of_issue_bound")
+    roofline = {"bound": "hbm", "limiter": ISSUE_NOTE if fib is None else ISSUE_NOTE.replace("frac_of_issue_bound", "%.2f" % fib, 1),
+                "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
+                "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
+                "traffic_source": cc["traffic_path"] if traffic is not None else None}
+    return kernels, dom, roofline, cc
+
+
+def batch_for(config, batch, rank):
+    import random as _random
+    draw = _random.Random(1234 + rank)
+    if config in ("md2", "vit"):
+        return [1] * batch
+    if config == "boosted":
+        return [7] * batch
+    if config == "boosted15":                # SURVEY 8d: P(m = 1..7) at epoch 15
+        return draw.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448], k=batch)
+    return draw.choices(range(0, 3), [.062, .573, .366], k=batch)     # epoch 5: P(m = 0,1,2) = .062 .573 .366
+
+
+def run_workload(args, ctx, config, steps, warmup, want_graph, dp_mode):
+    """Build a fresh Trainer for `config`, warm up, time EXACTLY `steps` steps between barrier + synchronise, then the
+    per-kernel HIP-event pass.  Returns a dict (trainer / opt / inputs included: the caller releases them)."""
     from baseboostdepth_amd import distributed as bdist
-    rank, local, world = bdist.init_from_env()
-    assert world == args.gpus, "world size %d != --gpus %d (launch with torchrun --nproc-per-node == --gpus, " \
-                               "or plain `python bench.py --gpus N`)" % (world, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path in the product)"
-    collective = "none"
-    if world > 1:
-        backend_name = torch.distributed.get_backend()
-        assert backend_name == "nccl" or os.environ.get("BBD_DIST_BACKEND"), \
-            "multi-GPU runs exchange gradients over RCCL (backend 'nccl'), got %r" % backend_name
-        collective = {"nccl": "rccl"}.get(backend_name, backend_name)
-    if os.environ.get("BBD_SHARE_GPU0"):       # test hook: all ranks on GPU 0 (with BBD_DIST_BACKEND=gloo)
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    from baseboostdepth_amd import ops, tuning
-    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd import ops
     from baseboostdepth_amd.synthetic import synthetic_batch
+    from baseboostdepth_amd.trainer import Trainer
+    rank, local, world, dev = ctx["rank"], ctx["local"], ctx["world"], ctx["dev"]
 
-    tuning.use_shipped_db()            # explicit (the Trainer would do it too): before the first convolution
-    gemm_db = tuning.use_shipped_gemm_db()
-    torch.manual_seed(42)
-    if args.miopen_benchmark:
-        torch.backends.cudnn.benchmark = True
     def build_trainer(step_graph):
         torch.manual_seed(42)
-        opt = make_options(args.batch, local, args.config)
+        opt = make_options(args.batch, local, config)
         opt.fused_adam = not args.no_fused_adam
         opt.step_graph = bool(step_graph)
-        opt.dp_capture = bool(step_graph) and args.dp_mode == "graph-overlap"
+        opt.dp_capture = bool(step_graph) and dp_mode == "graph-overlap"
         run_scales = list(opt.scales)
         opt.scales = list(SCALES)      # networks + num_scales are built for 4 scales (trainer.py:44); the epoch>=10
         tr = Trainer(opt)              # curriculum then trains on scale 0 only (run_epoch, trainer.py:209-212)
@@ -319,24 +367,14 @@ def main(argv=None):
         bdist.attach(tr)
         return tr, opt
 
-    want_graph = args.step_graph == "on" or (args.step_graph == "auto" and not args.no_fused_adam)
-    if world > 1 and args.dp_mode == "overlap":
+    if world > 1 and dp_mode == "overlap":
         want_graph = False
     trainer, opt = build_trainer(want_graph)
-    import random as _random
-    draw = _random.Random(1234 + rank)
-    if args.config in ("md2", "vit"):
-        ms = [1] * args.batch
-    elif args.config == "boosted":
-        ms = [7] * args.batch
-    elif args.config == "boosted15":             # P(m = 1..7) at epoch 15
-        ms = draw.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448], k=args.batch)
-    else:                                        # epoch 5: P(m = 0,1,2) = .062 .573 .366
-        ms = draw.choices(range(0, 3), [.062, .573, .366], k=args.batch)
+    ms = batch_for(config, args.batch, rank)
     inputs = synthetic_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
     # the identity-candidate noise is drawn INSIDE every step, as the reference does (trainer.py:518-523)
     inputs.pop("noise")
-    if args.config in ("boosted", "boosted15"):
+    if config in ("boosted", "boosted15"):
         inputs["cutt"] = torch.tensor(1.35)      # epoch >= 10 regime: incremental + partial pose modes
     backend = ops.default_backend()
 
@@ -365,20 +403,20 @@ def main(argv=None):
         if failure:
             graph_note = "capture failed (%s), eager loop used" % failure
             trainer, opt = build_trainer(False)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         trainer.train_step(inputs)
     if trainer.grad_sync is not None:
         trainer.grad_sync.timing = True
     timer = ops.KernelTimer()
     backend.timer = None if trainer.use_graph else timer
     # per-step durations for the median: one event at every step boundary on the main stream (no host sync)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         marks[i].record()
         trainer.train_step(inputs)
-    marks[args.steps].record()
+    marks[steps].record()
     sync_all()
     elapsed = time.perf_counter() - t0
     backend.timer = None
@@ -391,7 +429,7 @@ def main(argv=None):
     if trainer.use_graph:
         # a replayed graph's nodes cannot be bracketed by events: the SAME kernels on the same inputs are timed over
         # eager steps of the same trainer right after the timed region (rocprofv3 stats under profiles/ agree)
-        n_evt = max(5, min(args.steps, 20))
+        n_evt = max(5, min(steps, 20))
         backend.timer = timer
         for _ in range(n_evt):
             trainer._eager_step(dict(inputs))
@@ -399,82 +437,156 @@ def main(argv=None):
         backend.timer = None
         kernel_timing = ("HIP events around each C-ABI launch over %d eager steps run right after the timed region "
                          "(the timed region replays one hipGraph per step)" % n_evt)
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     median_ms = per_step[len(per_step) // 2] if per_step else 0.0
+    rank_ms = [elapsed / steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed, median_ms, exchange_ms], device=dev, dtype=torch.float64)
+        mine = t[:1].clone()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        rank_ms = [float(e.item()) / steps * 1e3 for e in every]
         elapsed, median_ms, exchange_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
+    S = len(opt.scales)
+    kernels, dom, roofline, cc = kernel_table(timer, trainer.plan, S, config, args.batch)
+    dp = "single" if world == 1 else (("graph-overlap" if trainer.dp_capture else "graph") if trainer.use_graph else "overlap")
+    return {"config": config, "trainer": trainer, "opt": opt, "inputs": inputs, "ms": ms, "S": S, "steps": steps, "warmup": warmup,
+            "elapsed": elapsed, "median_ms": median_ms, "rank_ms": rank_ms, "kernels": kernels, "dominant": dom, "roofline": roofline,
+            "constants": cc, "graph_note": graph_note, "kernel_timing": kernel_timing, "exchange_ms": exchange_ms,
+            "reduce_op": reduce_op, "overlapped": overlapped, "dp_mode": dp,
+            "value": args.batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3}
 
+
+def release(res):
+    """Drop a workload's trainer (its captured graphs keep private memory pools) before the next one is built."""
+    import gc
+    for k in ("trainer", "opt", "inputs"):
+        res.pop(k, None)
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def workload_name(config, batch, S, ms):
+    net = "MonoViT (mpvit_small) encoder + HR DepthDecoder" if config == "vit" else "MD2 ResNet-18 encoder+DepthDecoder"
+    if config in ("md2", "vit"):
+        return "%s+PoseNet training step, 640x192, per-GPU batch %d, frames [0,-1,1], %d scales, HIP fused warp+SSIM+min" % (net, batch, S)
+    return ("BaseBoostDepth boosted step (trimin+decomp+incremental+partial, config %s, per-sample max offsets %s), "
+            "ResNet-18, 640x192, per-GPU batch %d, %d scale(s)" % (config, ms, batch, S))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
+    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5", "vit"],
+                    help="md2 = BASELINE configs[1]/[3] (the headline); configs[2] (SURVEY 8d config 3): boosted = "
+                         "worst case m=7 for every sample, boosted15 = the epoch-15 offset distribution (standard "
+                         "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales); "
+                         "vit = configs[4]: MonoViT (mpvit_small) encoder + HR decoder, MD2 frame set")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block: after the headline's measurements a default one-GPU md2 run also times "
+                         "BASELINE configs[2] (boosted, boosted15) and configs[4] (vit) for --secondary-steps steps each, in this "
+                         "process, fresh Trainer each, and reports them under `secondary` of the same JSON line")
+    ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--secondary-budget", type=float, default=150.0, help="seconds; configs not started within it are listed as skipped")
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--no-fused-adam", action="store_true")
+    ap.add_argument("--no-eager-ab", action="store_true",
+                    help="skip timing the hot path / the whole step as eager PyTorch-ROCm ops (oracle) vs the fused kernels")
+    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole step (both HIP streams, MIOpen, the C-ABI launches, fused Adam) as one hipGraph: "
+                         "the ~1 200 launches of a step cost ~16 ms of host time, which a slow or busy host CPU turns into "
+                         "the bottleneck (measured: 480 vs 575 images/s on two boxes with identical GPU time).  auto = on for "
+                         "every run, falling back to the eager loop if capture fails; multi-rank runs replay two graphs "
+                         "per step (forward+backward+gradient pack | eager RCCL all-reduce | optimizer)")
+    ap.add_argument("--dp-mode", default="graph", choices=["graph", "overlap", "graph-overlap", "all"],
+                    help="multi-rank loop: graph = two hipGraphs around ONE eager all-reduce of the flat gradient buffer (host "
+                         "out of the loop, exchange exposed); overlap = eager loop, 32 MB buckets all-reduced from autograd "
+                         "hooks while backward still runs; graph-overlap = ONE hipGraph per step with the bucketed RCCL "
+                         "all-reduces captured into it (host out of the loop AND exchange overlapped; opt-in until it has run on "
+                         "a multi-GPU node).  graph / overlap print `exchange_ms` (exposed wait) so one node can compare them.  "
+                         "all = the headline in graph mode, then overlap and graph-overlap back to back in the same launch, "
+                         "reported under `dp_modes`; graph-overlap runs under a watchdog that prints the line and ends the "
+                         "rank if it hangs, so it cannot take the headline down")
+    ap.add_argument("--dp-extra-timeout", type=float, default=60.0,
+                    help="--dp-mode all: seconds each extra mode may take before the watchdog prints the line without it")
+    ap.add_argument("--launch-timeout", type=int, default=1500,
+                    help="`--gpus N` self-launch: seconds after which the child process group is terminated (status 124)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only prove that --gpus N ranks start and rendezvous (one all-reduce), then exit")
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+
+    # ---- multi-rank launch: before ANY GPU call (torch.cuda.* initialises HIP; a process that has done so
+    #      must never be replaced, and the children must find the devices untouched)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    if args.dry_launch:
+        return dry_launch(args)
+
+    from baseboostdepth_amd import distributed as bdist
+    rank, local, world = bdist.init_from_env()
+    assert world == args.gpus, "world size %d != --gpus %d (launch with torchrun --nproc-per-node == --gpus, " \
+                               "or plain `python bench.py --gpus N`)" % (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path in the product)"
+    collective = "none"
+    if world > 1:
+        backend_name = torch.distributed.get_backend()
+        assert backend_name == "nccl" or os.environ.get("BBD_DIST_BACKEND"), \
+            "multi-GPU runs exchange gradients over RCCL (backend 'nccl'), got %r" % backend_name
+        collective = {"nccl": "rccl"}.get(backend_name, backend_name)
+    if os.environ.get("BBD_SHARE_GPU0"):       # test hook: all ranks on GPU 0 (with BBD_DIST_BACKEND=gloo)
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ctx = {"rank": rank, "local": local, "world": world, "dev": dev}
+    # proof that the ranks sit on DISTINCT physical devices (a mis-set LOCAL_RANK / visible-devices mask would otherwise
+    # print an N-GPU line from N ranks sharing one GPU)
+    identities = [device_identity(local)]
+    if world > 1:
+        identities = [None] * world
+        torch.distributed.all_gather_object(identities, device_identity(local))
+
+    from baseboostdepth_amd import tuning
+
+    tuning.use_shipped_db()            # explicit (the Trainer would do it too): before the first convolution
+    gemm_db = tuning.use_shipped_gemm_db()
+    torch.manual_seed(42)
+    if args.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
+    want_graph = args.step_graph == "on" or (args.step_graph == "auto" and not args.no_fused_adam)
+    head_mode = "graph" if args.dp_mode == "all" else args.dp_mode
+    res = run_workload(args, ctx, args.config, args.steps, args.warmup, want_graph, head_mode)
+    trainer, opt, inputs = res["trainer"], res["opt"], res["inputs"]
+
+    line = None
     if rank == 0:
-        S = len(opt.scales)
-        nbytes = algorithmic_bytes(trainer.plan, S)
-        kernels = {}
-        for name, (count, mean_ms) in timer.summary().items():
-            if name in nbytes:
-                gbps = nbytes[name] / (mean_ms * 1e-3) / 1e9
-                kernels[name] = {"launches": count, "mean_ms": round(mean_ms, 4),
-                                 "alg_MB_per_launch": round(nbytes[name] / 1e6, 2),
-                                 "achieved_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4)}
-        dom = max(kernels, key=lambda k: kernels[k]["mean_ms"])
-        # HBM bytes per launch from rocprofv3 PMC passes of the same workload (committed under profiles/)
-        traffic = None
-        tpath = None
-        for rnd in ("r03", "r02", "r01"):
-            cand = os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % args.config)
-            if os.path.isfile(cand):
-                tpath = cand
-                break
-        isa_mix = {}
-        mix_path = os.path.join(ROOT, "profiles", "r03", "isa_mix.json")
-        if os.path.isfile(mix_path):
-            isa_mix = json.load(open(mix_path))
-        if args.batch == 12 and tpath is not None:
-            tj = json.load(open(tpath))
-            alias = lambda k: k.replace("_disp_", "_")           # PMC files name the kernels, not the entry points
-            traffic = tj.get(alias(dom), {}).get("traffic_bytes")
-            for k in kernels:
-                if alias(k) in tj:
-                    tj[k] = tj[alias(k)]
-                if k in tj:
-                    kernels[k]["pmc_traffic_MB_per_launch"] = round(tj[k]["traffic_bytes"] / 1e6, 1)
-                    if "valu_wave_instructions" in tj[k]:
-                        # vector-issue bound (finding 14): counter-measured vector instructions of the launch
-                        # (a committed PMC pass, not this run) x the kernel's mean cycles per instruction by issue class
-                        # (profiles/r03/isa_mix.json: 2.2 cycles with register / constant operands, 4.1 with an SGPR / vcc
-                        # operand or packed, 8.2 for reciprocals - profiles/r03/valu_rate.txt) at 2.4 GHz over 1024 SIMDs,
-                        # i.e. the time the launch would take if two waves were always ready to issue on every SIMD
-                        cyc = isa_mix.get(alias(k), {}).get("cycles_per_valu_instruction", 3.0)
-                        bound_ms = tj[k]["valu_wave_instructions"] * cyc / 1024 / 2.4e9 * 1e3
-                        kernels[k]["issue_bound_ms"] = round(bound_ms, 4)
-                        kernels[k]["frac_of_issue_bound"] = round(bound_ms / kernels[k]["mean_ms"], 3)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": 8000.0,
-                    "unit": "GB/s", "frac": kernels[dom]["frac"], "traffic": traffic,
-                    "traffic_source": os.path.relpath(tpath, ROOT) if (traffic is not None) else None}
+        S, kernels, roofline, cc = res["S"], res["kernels"], res["roofline"], res["constants"]
         global_batch = args.batch * world
-        net = "MonoViT (mpvit_small) encoder + HR DepthDecoder" if args.config == "vit" else \
-              "MD2 ResNet-18 encoder+DepthDecoder"
         line = {
             "metric": "training images/sec at 640x192, MD2 ResNet18" if args.config != "vit" else
                       "training images/sec at 640x192, MonoViT",
-            "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/sec",
+            "value": round(res["value"], 2), "unit": "images/sec",
             "n_gpus": world, "ranks": world, "collective": collective,
-            "dp_mode": ("single" if world == 1 else
-                        (("graph-overlap" if trainer.dp_capture else "graph") if trainer.use_graph else "overlap")),
+            # distinct physical devices behind the ranks (uuid / PCI address all-gathered from every rank)
+            "devices": len(set(identities)), "device_names": sorted({i.split("|")[1] for i in identities if i and "|" in i}),
+            "dp_mode": res["dp_mode"],
             # (captured collectives cannot be bracketed by events: null there)
-            "exchange_ms": None if (trainer.use_graph and trainer.dp_capture and world > 1) else round(exchange_ms, 4),
-            "reduce_op": reduce_op,
-            "buckets_launched_in_backward": overlapped,
+            "exchange_ms": None if (trainer.use_graph and trainer.dp_capture and world > 1) else round(res["exchange_ms"], 4),
+            "reduce_op": res["reduce_op"],
+            "buckets_launched_in_backward": res["overlapped"],
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
+            "ms_per_step": round(res["ms_per_step"], 3), "ms_per_step_median": round(res["median_ms"], 3),
+            # every rank's own wall time per step over the timed region (value uses the max): load imbalance between ranks
+            "ms_per_step_rank_min": round(min(res["rank_ms"]), 3), "ms_per_step_rank_max": round(max(res["rank_ms"]), 3),
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s+PoseNet training step, 640x192, "
-                                   "per-GPU batch %d, frames [0,-1,1], %d scales, HIP fused warp+SSIM+min"
-                                   % (net, args.batch, S) if args.config in ("md2", "vit") else
-                                   "BaseBoostDepth boosted step (trimin+decomp+incremental+partial, config %s, "
-                                   "per-sample max offsets %s), ResNet-18, 640x192, per-GPU batch %d, %d scale(s)"
-                                   % (args.config, ms, args.batch, S),
+            "config": {"workload": workload_name(args.config, args.batch, S, res["ms"]),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "miopen": {"user_db": ("shipped (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh)"
                                               if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "")).startswith("miopen_db") else
@@ -484,12 +596,16 @@ def main(argv=None):
                                                     if (gemm_db and "gemm_db_" in os.path.basename(gemm_db)) else gemm_db),
                                 "tuning_at_run_time": bool(torch.cuda.tunable.tuning_is_enabled()
                                                            and torch.cuda.tunable.is_enabled())}},
-            "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing,
+            "roofline": roofline, "kernels": kernels, "kernel_timing": res["kernel_timing"],
             # what in `kernels` is measured by THIS run (mean_ms, achieved_GBps, frac) and what is read from committed files
             "kernels_constants": "pmc_traffic_MB_per_launch and the instruction count behind issue_bound_ms come from the "
                                  "committed rocprofv3 PMC pass of this workload (roofline.traffic_source); the cycles per "
-                                 "instruction from profiles/r03/isa_mix.json (issue classes of profiles/r03/valu_rate.txt)",
-            "step_graph": (graph_note if graph_note is not None else
+                                 "instruction from %s (issue classes of profiles/r03/valu_rate.txt)" % (cc["isa_mix_path"] if cc else None),
+            # true when the committed counter / instruction-mix files were taken from other kernel source than the shipped one
+            "kernels_constants_stale": bool(cc and cc["stale"]),
+            "kernels_constants_stale_what": (cc["stale"] if cc else None) or None,
+            "kernel_source_sha16": cc["source_sha16"] if cc else None,
+            "step_graph": (res["graph_note"] if res["graph_note"] is not None else
                            (("one graph per step, bucketed RCCL all-reduces captured inside" if trainer.dp_capture else
                              "split: forward+backward+pack graph | eager all-reduce | optimizer graph")
                             if (trainer.use_graph and world > 1) else bool(trainer.use_graph))),
@@ -501,6 +617,73 @@ def main(argv=None):
                 line["eager_step_images_per_sec"] = line["eager_step"]["images_per_sec"]
             except Exception as e:    # informational, never fail the benchmark on it
                 line["eager_step"] = "n/a (%s: %s)" % (type(e).__name__, e)
+    del trainer, opt, inputs
+    release(res)
+
+    # ---- BASELINE configs[2] and configs[4] in the same command (one GPU, default flags): fresh Trainer each, graphs
+    #      released in between, never a re-exec
+    if world == 1 and args.config == "md2" and not args.no_secondary:
+        secondary, t_sec = [], time.perf_counter()
+        for cfg in ("boosted", "boosted15", "vit"):
+            if time.perf_counter() - t_sec > args.secondary_budget:
+                secondary.append({"config": cfg, "skipped": "secondary budget of %.0f s used up" % args.secondary_budget})
+                continue
+            try:
+                r = run_workload(args, ctx, cfg, max(10, args.secondary_steps), 3, want_graph, "graph")
+                rf = r["roofline"] or {}
+                secondary.append({
+                    "config": cfg, "workload": workload_name(cfg, args.batch, r["S"], r["ms"]),
+                    "value": round(r["value"], 2), "unit": "images/sec", "ms_per_step": round(r["ms_per_step"], 3),
+                    "ms_per_step_median": round(r["median_ms"], 3), "steps": r["steps"], "warmup": r["warmup"],
+                    "step_graph": r["graph_note"] if r["graph_note"] is not None else bool(r["trainer"].use_graph),
+                    "roofline": {k: rf.get(k) for k in ("bound", "limiter", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")},
+                    "kernels": {k: {f: v[f] for f in ("mean_ms", "alg_MB_per_launch", "frac") if f in v} for k, v in r["kernels"].items()},
+                    "kernels_constants_stale": bool(r["constants"] and r["constants"]["stale"])})
+                release(r)
+            except Exception as e:    # a secondary configuration never takes the headline down
+                secondary.append({"config": cfg, "error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+                torch.cuda.synchronize()
+        if line is not None:
+            line["secondary"] = secondary
+            line["secondary_seconds"] = round(time.perf_counter() - t_sec, 1)
+
+    # ---- --dp-mode all: the other two multi-rank loops in the same launch, under a watchdog
+    if world > 1 and args.dp_mode == "all":
+        import threading
+        modes = {"graph": {"value": line["value"], "ms_per_step": line["ms_per_step"], "exchange_ms": line["exchange_ms"]}} if line else {}
+        if line is not None:
+            line["dp_modes"] = modes
+        for mode in ("overlap", "graph-overlap"):
+            fired = threading.Event()
+
+            def bail(mode=mode):
+                # a hung collective cannot be cancelled from Python: print what has been measured and end the rank (every
+                # rank's own watchdog does the same; the launcher sees N clean exits)
+                fired.set()
+                if line is not None:
+                    line["dp_modes"][mode] = "timeout after %.0f s (rank watchdog)" % args.dp_extra_timeout
+                    print(json.dumps(line))
+                    sys.stdout.flush()
+                os._exit(0)
+            dog = threading.Timer(args.dp_extra_timeout, bail)
+            dog.daemon = True
+            dog.start()
+            try:
+                r = run_workload(args, ctx, args.config, args.steps, min(args.warmup, 5), want_graph, mode)
+                entry = {"value": round(r["value"], 2), "ms_per_step": round(r["ms_per_step"], 3), "dp_mode": r["dp_mode"],
+                         "exchange_ms": None if r["dp_mode"] == "graph-overlap" else round(r["exchange_ms"], 4),
+                         "buckets_launched_in_backward": r["overlapped"],
+                         "step_graph": r["graph_note"] if r["graph_note"] is not None else bool(r["trainer"].use_graph)}
+                release(r)
+            except Exception as e:
+                entry = "failed: %s: %s" % (type(e).__name__, str(e)[:160])
+            dog.cancel()
+            if fired.is_set():
+                time.sleep(3600)       # the watchdog is printing / exiting
+            if line is not None:
+                line["dp_modes"][mode] = entry
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -262,6 +262,7 @@ static void hp_depth_planes(const void* const* disp, const int32_t* disp_hw, dou
 int hp_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, const void* const* disp,
                               const int32_t* disp_hw, double min_depth, double max_depth, const float* proj,
                               const float* ident, const float* noise, const bbd_cand_t* cand, const int32_t* ncand,
+                              const int32_t* /*work_items: a launch-order choice of the GPU kernels*/,
                               float* min_loss, uint8_t* argmin, float* partial, float* warped, float* depth_out,
                               int S, int B, int NP, int H, int W, int no_ssim) {
   std::vector<float> tmp;
@@ -275,7 +276,8 @@ int hp_warp_ssim_min_disp_fwd(const void* const* frames, const float* target, co
 int hp_warp_ssim_min_disp_bwd(const void* const* frames, const float* target, const void* const* disp,
                               const int32_t* disp_hw, double min_depth, double max_depth, const float* /*depth planes*/,
                               const float* proj,
-                              const bbd_cand_t* cand, const int32_t* ncand, const uint8_t* argmin, const float* gscale,
+                              const bbd_cand_t* cand, const int32_t* ncand, const int32_t* /*work_items*/,
+                              const uint8_t* argmin, const float* gscale,
                               float* grad_up, float* grad_proj, int S, int B, int NP, int H, int W, int no_ssim) {
   std::vector<float> depth((size_t)S * B * H * W);
   hp_depth_planes(disp, disp_hw, min_depth, max_depth, S, B, H, W, depth.data());
