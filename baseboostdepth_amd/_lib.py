@@ -45,8 +45,10 @@ SIGNATURES = {
     "bbd_disp_upsample_adjoint": [_p, _p, _p, _i, _i, _i, _i, _p],
     "bbd_disp_to_depth_fwd": [_p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
     "bbd_disp_to_depth_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _d, _p],
-    "bbd_pose_matrix_fwd": [_p, _p, _p, _i, _i, _p],
-    "bbd_pose_matrix_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "bbd_pose_matrix_fwd": [_p, _p, _p, _i, _i, _p, _p],
+    "bbd_pose_matrix_bwd": [_p, _p, _p, _p, _p, _i, _i, _p, _p],
+    "bbd_smooth_loss_multi_fwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "bbd_smooth_loss_multi_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "bbd_pose_compose_fwd": [_p, _p, _p, _i, _d, _p],
     "bbd_pose_compose_bwd": [_p, _p, _p, _p, _p, _p, _i, _p],
     "bbd_smooth_chunks": [],

@@ -1912,9 +1912,11 @@ __device__ __forceinline__ Rodrigues rodrigues(const float* v) {
 }
 
 __global__ __launch_bounds__(NT) void pose_matrix_fwd_kernel(const float* __restrict__ aa, const float* __restrict__ tr,
-                                                             float* __restrict__ M, int n, int invert) {
+                                                             float* __restrict__ M, int n, int invert,
+                                                             const int32_t* __restrict__ invert_rows) {
   const int i = blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;
+  if (invert_rows != nullptr) invert = invert_rows[i];      // one launch for the poses of both signs of a step
   const Rodrigues r = rodrigues(aa + i * 3);
   const float* t = tr + i * 3;
   float* m = M + i * 16;
@@ -1941,9 +1943,11 @@ __global__ __launch_bounds__(NT) void pose_matrix_fwd_kernel(const float* __rest
 
 __global__ __launch_bounds__(NT) void pose_matrix_bwd_kernel(const float* __restrict__ aa, const float* __restrict__ tr,
                                                              const float* __restrict__ gM, float* __restrict__ gaa,
-                                                             float* __restrict__ gtr, int n, int invert) {
+                                                             float* __restrict__ gtr, int n, int invert,
+                                                             const int32_t* __restrict__ invert_rows) {
   const int i = blockIdx.x * NT + threadIdx.x;
   if (i >= n) return;
+  if (invert_rows != nullptr) invert = invert_rows[i];
   const float* v = aa + i * 3;
   const float* t = tr + i * 3;
   const float* g = gM + i * 16;
@@ -2014,18 +2018,33 @@ __device__ __forceinline__ float block_sum_all(float v, float* s_red4) {   // ev
   return t;
 }
 
+// Every scale of a step in ONE launch per pass (round 4: MD2's four scales took 16 launches of 3-10 us each, and the eager
+// hot path is launch-bound): grid = (B * SM_CHUNKS, S), blockIdx.y picks the scale's pointers and sizes.  The single-scale
+// entry points run the same kernels with S = 1, so both forms reduce in the same fixed order.
+struct SmoothArgs {
+  const float* disp[MAX_SCALES];
+  const float* img[MAX_SCALES];
+  float* grad[MAX_SCALES];
+  int h[MAX_SCALES], w[MAX_SCALES];
+  float* mean;            // [S][B][SM_CHUNKS] partial sums of disp
+  float* sums;            // [S][B][SM_CHUNKS][2]
+  float* dots;            // [S][B][SM_CHUNKS]
+  const float* gscale;    // [S]
+  int B;
+};
+
 // per-(sample, chunk) partial sums of disp; the mean is finished by sample_mean() in the consumers
-__global__ __launch_bounds__(NT) void smooth_mean_kernel(const float* __restrict__ disp, float* __restrict__ psum,
-                                                         int hw) {
+__global__ __launch_bounds__(NT) void smooth_mean_kernel(SmoothArgs a) {
   __shared__ float s_red4[4];
+  const int s = blockIdx.y, hw = a.h[s] * a.w[s];
   const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
-  const float* d = disp + (size_t)b * hw;
+  const float* d = a.disp[s] + (size_t)b * hw;
   const int per = (hw + SM_CHUNKS - 1) / SM_CHUNKS;
   const int i0 = chunk * per, i1 = min(hw, i0 + per);
   float acc = 0.0f;
   for (int i = i0 + threadIdx.x; i < i1; i += NT) acc += d[i];
   const float tot = block_sum_all(acc, s_red4);
-  if (threadIdx.x == 0) psum[blockIdx.x] = tot;
+  if (threadIdx.x == 0) a.mean[(size_t)s * a.B * SM_CHUNKS + blockIdx.x] = tot;
 }
 
 __device__ __forceinline__ float sample_mean(const float* __restrict__ psum, int b, int hw) {
@@ -2040,15 +2059,14 @@ __device__ __forceinline__ float edge_weight(const float* img, int hw, int i0, i
   return __expf(-g * (1.0f / 3.0f));
 }
 
-__global__ __launch_bounds__(NT) void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img,
-                                                        const float* __restrict__ mean, float* __restrict__ sums,
-                                                        int h, int w) {
+__global__ __launch_bounds__(NT) void smooth_fwd_kernel(SmoothArgs a) {
   __shared__ float s_red4[4];
+  const int s = blockIdx.y, h = a.h[s], w = a.w[s];
   const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
   const int hw = h * w;
-  const float* d = disp + (size_t)b * hw;
-  const float* im = img + (size_t)b * 3 * hw;
-  const float inv = 1.0f / (sample_mean(mean, b, hw) + 1e-7f);
+  const float* d = a.disp[s] + (size_t)b * hw;
+  const float* im = a.img[s] + (size_t)b * 3 * hw;
+  const float inv = 1.0f / (sample_mean(a.mean + (size_t)s * a.B * SM_CHUNKS, b, hw) + 1e-7f);
   const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
   const int y0 = chunk * rows, y1 = min(h, y0 + rows);
   float ax = 0.0f, ay = 0.0f;
@@ -2061,26 +2079,25 @@ __global__ __launch_bounds__(NT) void smooth_fwd_kernel(const float* __restrict_
   const float tx = block_sum_all(ax, s_red4);
   const float ty = block_sum_all(ay, s_red4);
   if (threadIdx.x == 0) {
-    sums[blockIdx.x * 2 + 0] = tx;
-    sums[blockIdx.x * 2 + 1] = ty;
+    float* o = a.sums + ((size_t)s * a.B * SM_CHUNKS + blockIdx.x) * 2;
+    o[0] = tx;
+    o[1] = ty;
   }
 }
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
 // pass 1: gn = d loss / d norm (stored into grad), and per-chunk partial of sum(gn * disp)
-__global__ __launch_bounds__(NT) void smooth_bwd1_kernel(const float* __restrict__ disp, const float* __restrict__ img,
-                                                         const float* __restrict__ mean, const float* __restrict__ gscale,
-                                                         float* __restrict__ grad, float* __restrict__ dots, int B,
-                                                         int h, int w) {
+__global__ __launch_bounds__(NT) void smooth_bwd1_kernel(SmoothArgs a) {
   __shared__ float s_red4[4];
+  const int s = blockIdx.y, h = a.h[s], w = a.w[s], B = a.B;
   const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
   const int hw = h * w;
-  const float* d = disp + (size_t)b * hw;
-  const float* im = img + (size_t)b * 3 * hw;
-  float* gout = grad + (size_t)b * hw;
-  const float inv = 1.0f / (sample_mean(mean, b, hw) + 1e-7f);
-  const float g = gscale[0];
+  const float* d = a.disp[s] + (size_t)b * hw;
+  const float* im = a.img[s] + (size_t)b * 3 * hw;
+  float* gout = a.grad[s] + (size_t)b * hw;
+  const float inv = 1.0f / (sample_mean(a.mean + (size_t)s * B * SM_CHUNKS, b, hw) + 1e-7f);
+  const float g = a.gscale[s];
   const float gxs = g / ((float)B * (float)h * (float)(w - 1));
   const float gys = g / ((float)B * (float)(h - 1) * (float)w);
   const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
@@ -2098,19 +2115,20 @@ __global__ __launch_bounds__(NT) void smooth_bwd1_kernel(const float* __restrict
     dot += gn * d[i];
   }
   const float t = block_sum_all(dot, s_red4);
-  if (threadIdx.x == 0) dots[blockIdx.x] = t;
+  if (threadIdx.x == 0) a.dots[(size_t)s * B * SM_CHUNKS + blockIdx.x] = t;
 }
 
 // pass 2: grad_disp = gn / (m+eps) - sum(gn*disp) / (N (m+eps)^2)
-__global__ __launch_bounds__(NT) void smooth_bwd2_kernel(const float* __restrict__ mean, const float* __restrict__ dots,
-                                                         float* __restrict__ grad, int h, int w) {
+__global__ __launch_bounds__(NT) void smooth_bwd2_kernel(SmoothArgs a) {
+  const int s = blockIdx.y, h = a.h[s], w = a.w[s];
   const int b = blockIdx.x / SM_CHUNKS, chunk = blockIdx.x - b * SM_CHUNKS;
   const int hw = h * w;
+  const float* dots = a.dots + (size_t)s * a.B * SM_CHUNKS;
   float dot = 0.0f;
   for (int k = 0; k < SM_CHUNKS; ++k) dot += dots[b * SM_CHUNKS + k];
-  const float inv = 1.0f / (sample_mean(mean, b, hw) + 1e-7f);
+  const float inv = 1.0f / (sample_mean(a.mean + (size_t)s * a.B * SM_CHUNKS, b, hw) + 1e-7f);
   const float sub = dot * inv * inv / (float)hw;
-  float* gout = grad + (size_t)b * hw;
+  float* gout = a.grad[s] + (size_t)b * hw;
   const int rows = (h + SM_CHUNKS - 1) / SM_CHUNKS;
   const int y0 = chunk * rows, y1 = min(h, y0 + rows);
   for (int i = y0 * w + threadIdx.x; i < y1 * w; i += NT) gout[i] = gout[i] * inv - sub;
@@ -2450,45 +2468,87 @@ int bbd_pose_expand(const float* pose, float* proj, int NP, void* stream) {
   return launch_status();
 }
 
-int bbd_pose_matrix_fwd(const float* axisangle, const float* translation, float* M, int n, int invert, void* stream) {
+int bbd_pose_matrix_fwd(const float* axisangle, const float* translation, float* M, int n, int invert,
+                        const int32_t* invert_rows, void* stream) {
   if (!axisangle || !translation || !M || n < 0) return BBD_E_BADARG;
   if (n == 0) return 0;
   hipLaunchKernelGGL(pose_matrix_fwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
-                     static_cast<hipStream_t>(stream), axisangle, translation, M, n, invert);
+                     static_cast<hipStream_t>(stream), axisangle, translation, M, n, invert, invert_rows);
   return launch_status();
 }
 
 int bbd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* grad_M, float* grad_axisangle,
-                        float* grad_translation, int n, int invert, void* stream) {
+                        float* grad_translation, int n, int invert, const int32_t* invert_rows, void* stream) {
   if (!axisangle || !translation || !grad_M || !grad_axisangle || !grad_translation || n < 0) return BBD_E_BADARG;
   if (n == 0) return 0;
   hipLaunchKernelGGL(pose_matrix_bwd_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
                      static_cast<hipStream_t>(stream), axisangle, translation, grad_M, grad_axisangle,
-                     grad_translation, n, invert);
+                     grad_translation, n, invert, invert_rows);
   return launch_status();
 }
 
 int bbd_smooth_chunks(void) { return SM_CHUNKS; }
 
+static int launch_smooth_fwd(const SmoothArgs& a, int S, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(smooth_mean_kernel, dim3((unsigned)(a.B * SM_CHUNKS), (unsigned)S), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(a.B * SM_CHUNKS), (unsigned)S), dim3(NT), 0, st, a);
+  return launch_status();
+}
+static int launch_smooth_bwd(const SmoothArgs& a, int S, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(smooth_bwd1_kernel, dim3((unsigned)(a.B * SM_CHUNKS), (unsigned)S), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(smooth_bwd2_kernel, dim3((unsigned)(a.B * SM_CHUNKS), (unsigned)S), dim3(NT), 0, st, a);
+  return launch_status();
+}
+
 int bbd_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, float* sums, int B, int h, int w,
                         void* stream) {
   if (!disp || !img || !mean_disp || !sums || B <= 0 || h < 2 || w < 2) return BBD_E_BADARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(smooth_mean_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, mean_disp, h * w);
-  hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, img, mean_disp, sums,
-                     h, w);
-  return launch_status();
+  SmoothArgs a = {};
+  a.disp[0] = disp; a.img[0] = img; a.h[0] = h; a.w[0] = w; a.mean = mean_disp; a.sums = sums; a.B = B;
+  return launch_smooth_fwd(a, 1, stream);
 }
 
 int bbd_smooth_loss_bwd(const float* disp, const float* img, const float* mean_disp, const float* gscale,
                         float* grad_disp, float* dots, int B, int h, int w, void* stream) {
   if (!disp || !img || !mean_disp || !gscale || !grad_disp || !dots || B <= 0 || h < 2 || w < 2) return BBD_E_BADARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(smooth_bwd1_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, disp, img, mean_disp,
-                     gscale, grad_disp, dots, B, h, w);
-  hipLaunchKernelGGL(smooth_bwd2_kernel, dim3((unsigned)(B * SM_CHUNKS)), dim3(NT), 0, st, mean_disp, dots, grad_disp,
-                     h, w);
-  return launch_status();
+  SmoothArgs a = {};
+  a.disp[0] = disp; a.img[0] = img; a.grad[0] = grad_disp; a.h[0] = h; a.w[0] = w;
+  a.mean = const_cast<float*>(mean_disp); a.dots = dots; a.gscale = gscale; a.B = B;
+  return launch_smooth_bwd(a, 1, stream);
+}
+
+static int fill_smooth(const void* const* disp, const void* const* img, const int32_t* hw, int S, int B, SmoothArgs* a) {
+  if (!disp || !img || !hw || S <= 0 || S > MAX_SCALES || B <= 0) return BBD_E_BADARG;
+  for (int i = 0; i < S; ++i) {
+    a->disp[i] = static_cast<const float*>(disp[i]);
+    a->img[i] = static_cast<const float*>(img[i]);
+    a->h[i] = hw[2 * i]; a->w[i] = hw[2 * i + 1];
+    if (!a->disp[i] || !a->img[i] || a->h[i] < 2 || a->w[i] < 2) return BBD_E_BADARG;
+  }
+  a->B = B;
+  return 0;
+}
+
+int bbd_smooth_loss_multi_fwd(const void* const* disp, const void* const* img, const int32_t* hw, float* mean_disp,
+                              float* sums, int S, int B, void* stream) {
+  SmoothArgs a = {};
+  if (!mean_disp || !sums || fill_smooth(disp, img, hw, S, B, &a)) return BBD_E_BADARG;
+  a.mean = mean_disp; a.sums = sums;
+  return launch_smooth_fwd(a, S, stream);
+}
+
+int bbd_smooth_loss_multi_bwd(const void* const* disp, const void* const* img, const int32_t* hw, const float* mean_disp,
+                              const float* gscale, void* const* grad_disp, float* dots, int S, int B, void* stream) {
+  SmoothArgs a = {};
+  if (!mean_disp || !gscale || !grad_disp || !dots || fill_smooth(disp, img, hw, S, B, &a)) return BBD_E_BADARG;
+  for (int i = 0; i < S; ++i) {
+    a.grad[i] = static_cast<float*>(grad_disp[i]);
+    if (!a.grad[i]) return BBD_E_BADARG;
+  }
+  a.mean = const_cast<float*>(mean_disp); a.dots = dots; a.gscale = gscale;
+  return launch_smooth_bwd(a, S, stream);
 }
 
 #ifdef BBD_STAMPS

@@ -191,30 +191,33 @@ def disp_pyramid_to_depth(disps, H, W, min_depth, max_depth, backend=None):
 # ---------------------------------------------------------------------------- pose matrix
 class _PoseMatrix(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, axisangle, translation, invert, backend):
+    def forward(ctx, axisangle, translation, invert, backend, invert_rows):
         aa = axisangle.reshape(-1, 3).contiguous()
         tr = translation.reshape(-1, 3).contiguous()
         backend._check(aa, tr)
         n = aa.shape[0]
+        assert invert_rows is None or (invert_rows.dtype == torch.int32 and invert_rows.numel() == n)
         M = torch.empty(n, 4, 4, device=aa.device, dtype=torch.float32)
-        backend.run("bbd_pose_matrix_fwd", aa, ptr(aa), ptr(tr), ptr(M), n, int(invert))
+        backend.run("bbd_pose_matrix_fwd", aa, ptr(aa), ptr(tr), ptr(M), n, int(invert), ptr(invert_rows))
         ctx.save_for_backward(aa, tr)
-        ctx.meta = (bool(invert), backend, axisangle.shape, translation.shape)
+        ctx.meta = (bool(invert), backend, axisangle.shape, translation.shape, invert_rows)
         return M
 
     @staticmethod
     def backward(ctx, gM):
         aa, tr = ctx.saved_tensors
-        invert, backend, shp_a, shp_t = ctx.meta
+        invert, backend, shp_a, shp_t, invert_rows = ctx.meta
         gM = gM.contiguous()
         ga, gt = torch.empty_like(aa), torch.empty_like(tr)
-        backend.run("bbd_pose_matrix_bwd", aa, ptr(aa), ptr(tr), ptr(gM), ptr(ga), ptr(gt), aa.shape[0], int(invert))
-        return ga.view(shp_a), gt.view(shp_t), None, None
+        backend.run("bbd_pose_matrix_bwd", aa, ptr(aa), ptr(tr), ptr(gM), ptr(ga), ptr(gt), aa.shape[0], int(invert),
+                    ptr(invert_rows))
+        return ga.view(shp_a), gt.view(shp_t), None, None, None
 
 
-def pose_matrix(axisangle, translation, invert=False, backend=None):
-    """layers.transformation_from_parameters as one kernel (forward) + one (backward)."""
-    return _PoseMatrix.apply(axisangle, translation, invert, backend or default_backend())
+def pose_matrix(axisangle, translation, invert=False, backend=None, invert_rows=None):
+    """layers.transformation_from_parameters as one kernel (forward) + one (backward).  `invert_rows` (device int32 [n])
+    replaces the scalar flag row by row: the poses of both signs of a step in one launch each way."""
+    return _PoseMatrix.apply(axisangle, translation, invert, backend or default_backend(), invert_rows)
 
 
 # ---------------------------------------------------------------------------- smoothness
@@ -246,6 +249,51 @@ class _SmoothLoss(torch.autograd.Function):
         backend.run("bbd_smooth_loss_bwd", disp, ptr(disp), ptr(img), ptr(mean), ptr(gscale), ptr(grad), ptr(dots),
                     B, h, w)
         return grad, None, None
+
+
+class _SmoothLossMulti(torch.autograd.Function):
+    """The smoothness terms of ALL scales of a step (trainer.py:560-564 inside the scale loop) as one launch pair each way
+    (bbd_smooth_loss_multi_*): MD2's four scales took 16 launches.  Returns the [S] vector of smooth values."""
+    _den = {}
+
+    @staticmethod
+    def forward(ctx, backend, n, *tensors):
+        disps = [t.contiguous() for t in tensors[:n]]
+        imgs = [t.contiguous() for t in tensors[n:]]
+        backend._check(*disps, *imgs)
+        B, dev = disps[0].shape[0], disps[0].device
+        chunks = backend.smooth_chunks()
+        mean = torch.empty(n, B, chunks, device=dev, dtype=torch.float32)
+        sums = torch.empty(n, B, chunks, 2, device=dev, dtype=torch.float32)
+        backend.run("bbd_smooth_loss_multi_fwd", disps[0], _ptr_array(disps), _ptr_array(imgs), _hw_array(disps), ptr(mean),
+                    ptr(sums), n, B)
+        ctx.save_for_backward(mean, *disps, *imgs)
+        ctx.meta = (backend, chunks, n)
+        key = (str(dev), B) + tuple(tuple(d.shape[-2:]) for d in disps)
+        den = _SmoothLossMulti._den.get(key)
+        if den is None:       # mean over the x-terms' B*h*(w-1) and the y-terms' B*(h-1)*w elements (layers.py:213-216)
+            den = torch.tensor([[B * d.shape[-2] * (d.shape[-1] - 1), B * (d.shape[-2] - 1) * d.shape[-1]] for d in disps],
+                               dtype=torch.float32).to(dev)
+            _SmoothLossMulti._den[key] = den
+        return (sums.sum(dim=(1, 2)) / den).sum(dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        backend, chunks, n = ctx.meta
+        mean = ctx.saved_tensors[0]
+        disps, imgs = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        B = disps[0].shape[0]
+        gscale = g.contiguous().to(torch.float32)
+        grads = [torch.empty_like(d) for d in disps]
+        dots = torch.empty(n, B, chunks, device=mean.device, dtype=torch.float32)
+        backend.run("bbd_smooth_loss_multi_bwd", disps[0], _ptr_array(disps), _ptr_array(imgs), _hw_array(disps), ptr(mean),
+                    ptr(gscale), _ptr_array(grads), ptr(dots), n, B)
+        return (None, None) + tuple(grads) + (None,) * n
+
+
+def normalised_smooth_losses(disps, imgs, backend=None):
+    """[S] tensor: normalised_smooth_loss of every (disp, img) pair, one launch pair each way (at most 4 scales)."""
+    return _SmoothLossMulti.apply(backend or default_backend(), len(disps), *disps, *imgs)
 
 
 def normalised_smooth_loss(disp, img, backend=None):

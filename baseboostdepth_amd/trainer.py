@@ -541,10 +541,15 @@ class Trainer:
             with ops.bn_call_groups(rows):
                 feats = [self.models["pose_encoder"](x)]
             axisangle, translation = self.models["pose"](feats)
-            r0 = 0
-            for n, (_, _, inv) in zip(rows, chunk):
-                out.append(transformation_from_parameters(axisangle[r0:r0 + n, 0], translation[r0:r0 + n, 0], invert=inv))
-                r0 += n
+            # the chunk's pose matrices in ONE launch each way: the `invert` flag (negative frame ids, trainer.py:360,384,402)
+            # goes row by row as a small device table cached per (rows, flags) signature
+            key = (tuple(rows), tuple(bool(inv) for _, _, inv in chunk))
+            cache = self.__dict__.setdefault("_invert_rows", {})
+            if key not in cache:
+                flags = [int(bool(inv)) for n, (_, _, inv) in zip(rows, chunk) for _ in range(n)]
+                cache[key] = torch.tensor(flags, dtype=torch.int32).to(self.device)
+            M = ops.pose_matrix(axisangle[:, 0], translation[:, 0], backend=self._backend(), invert_rows=cache[key])
+            out.extend(torch.split(M, rows, dim=0))
         return out
 
     def _error_pose(self, T):
@@ -803,11 +808,12 @@ class Trainer:
             raise RuntimeError("compute_losses needs the outputs of generate_images_pred (fused launch)")
         losses, total = {}, 0
         n_px = self.plan.B * opt.height * opt.width
+        # the edge-aware smoothness of every scale (:560-563, layers.py:203-216) in one launch pair each way
+        smooths = ops.normalised_smooth_losses([outputs[("disp", s)] for s in opt.scales],
+                                               [inputs[("color", 0, s)] for s in opt.scales], self._backend())
         for i, s in enumerate(opt.scales):
             loss = outputs[("bbd", "loss_sum")][i] / n_px                     # to_optimise.mean(), :557
-            disp, color = outputs[("disp", s)], inputs[("color", 0, s)]
-            smooth = ops.normalised_smooth_loss(disp, color, self._backend())         # :560-563, layers.py:203-216
-            loss = loss + opt.disparity_smoothness * smooth / (2 ** s)
+            loss = loss + opt.disparity_smoothness * smooths[i] / (2 ** s)
             total = total + loss
             losses["loss/{}".format(s)] = loss
         losses["loss"] = total / self.num_scales

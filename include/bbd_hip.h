@@ -200,11 +200,14 @@ int bbd_disp_to_depth_bwd(const float* disp, const float* depth, const float* gr
 
 /* Pose matrix from the pose head's output: layers.transformation_from_parameters
  * (layers.py:25-100: rot_from_axisangle, get_translation_matrix, T@R or R^T@T(-t)).
- *   axisangle, translation [n,3] -> M [n,4,4];  bwd: grad_M [n,4,4] -> grads [n,3] each.      */
+ *   axisangle, translation [n,3] -> M [n,4,4];  bwd: grad_M [n,4,4] -> grads [n,3] each.
+ *   invert_rows (device [n] int32, or NULL): per-row `invert` flag that replaces the scalar one, so that the poses of
+ *   BOTH signs of a step (trainer.py:360,384,402: invert for negative frame ids) are one launch each way.         */
 int bbd_pose_matrix_fwd(const float* axisangle, const float* translation, float* M, int n, int invert,
-                        void* stream);
+                        const int32_t* invert_rows, void* stream);
 int bbd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* grad_M,
-                        float* grad_axisangle, float* grad_translation, int n, int invert, void* stream);
+                        float* grad_axisangle, float* grad_translation, int n, int invert,
+                        const int32_t* invert_rows, void* stream);
 
 /* Edge-aware smoothness of the mean-normalised disparity: layers.get_smooth_loss
  * (layers.py:203-216) applied to disp / (mean_{H,W}(disp) + 1e-7) as in trainer.py:560-563.
@@ -220,6 +223,15 @@ int bbd_smooth_loss_fwd(const float* disp, const float* img, float* mean_disp, f
 int bbd_smooth_loss_bwd(const float* disp, const float* img, const float* mean_disp,
                         const float* gscale, float* grad_disp, float* dots,
                         int B, int h, int w, void* stream);
+/* The same for ALL scales of a step (trainer.py:527-564 loops over opt.scales) in one launch pair each way: disp / img /
+ * grad_disp = host arrays of S (<= 4) device pointers, hw = host {h_0,w_0,h_1,w_1,...}; mean_disp [S,B,chunks],
+ * sums [S,B,chunks,2], dots [S,B,chunks], gscale [S] (device).  Same kernels, same reduction order as the single-scale
+ * form (which is the S = 1 case).                                                                              */
+int bbd_smooth_loss_multi_fwd(const void* const* disp, const void* const* img, const int32_t* hw, float* mean_disp,
+                              float* sums, int S, int B, void* stream);
+int bbd_smooth_loss_multi_bwd(const void* const* disp, const void* const* img, const int32_t* hw,
+                              const float* mean_disp, const float* gscale, void* const* grad_disp, float* dots,
+                              int S, int B, void* stream);
 
 /* Stand-alone kernels behind the reference's layer classes (the training step uses the fused entry
  * points above and never materialises these tensors; callers written against the reference's

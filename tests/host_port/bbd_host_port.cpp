@@ -373,6 +373,27 @@ int hp_smooth_loss_bwd(const float* disp, const float* img, const float* mean_di
   return 0;
 }
 
+// every scale of a step (bbd_smooth_loss_multi_*): the single-scale port per scale
+int hp_smooth_loss_multi_fwd(const void* const* disp, const void* const* img, const int32_t* hw, float* mean_disp, float* sums,
+                             int S, int B) {
+  for (int s = 0; s < S; ++s) {
+    const int rc = hp_smooth_loss_fwd(static_cast<const float*>(disp[s]), static_cast<const float*>(img[s]),
+                                      mean_disp + (size_t)s * B, sums + (size_t)s * B * 2, B, hw[2 * s], hw[2 * s + 1]);
+    if (rc) return rc;
+  }
+  return 0;
+}
+int hp_smooth_loss_multi_bwd(const void* const* disp, const void* const* img, const int32_t* hw, const float* mean_disp,
+                             const float* gscale, void* const* grad_disp, float* dots, int S, int B) {
+  for (int s = 0; s < S; ++s) {
+    const int rc = hp_smooth_loss_bwd(static_cast<const float*>(disp[s]), static_cast<const float*>(img[s]),
+                                      mean_disp + (size_t)s * B, gscale + s, static_cast<float*>(grad_disp[s]),
+                                      dots + (size_t)s * B, B, hw[2 * s], hw[2 * s + 1]);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 // exhaustive-ish check helpers for the constant divisions
 int hp_check_div(uint32_t start, uint32_t count, uint32_t stride) {
   int bad = 0;

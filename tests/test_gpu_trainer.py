@@ -73,6 +73,51 @@ def test_process_batch_end_to_end(boosted, ms, scales, cutt):
         assert sum(got) >= 0.75 * len(got), name     # unused-scale dispconvs get none when scales=[0]
 
 
+def test_boosted_process_batch_at_baseline_size():
+    """the boosted recipe's WHOLE step at BASELINE configs[2] size - B = 12, 192x640, trimin + decomp +
+    incremental + partial pose modes (cutt 1.35: the epoch >= 10 regime, scale 0 only), per-sample offsets = bench.py's
+    epoch-15 draw (mixed 8 / 14 / 18-candidate samples, i.e. the sorted slab work order is on) - against the live oracle on
+    the networks' own disparities and poses: loss 1e-5, min-loss maps 1e-4, arg-min equal where the oracle's margin exceeds
+    2e-4, disparity gradient with the flip-aware protocol of test_full_resolution_against_oracle (trainer.py:286-308,
+    310-419, 444-570, 983-1100)."""
+    import random
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, B = 192, 640, 12
+    ms = random.Random(1234).choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448], k=B)   # bench.py boosted15, rank 0
+    assert len(set(ms)) > 2
+    torch.manual_seed(0)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    tr = Trainer(opt)
+    tr.opt.scales = [0]
+    tr.set_train()
+    inputs = synthetic_batch(ms, H, W, [0], device=DEV, seed=42)
+    inputs["cutt"] = torch.tensor(1.35)
+    tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+    outputs, losses = tr.process_batch(inputs)
+    assert tr.plan.sample_order is not None                     # mixed candidate counts: most-candidates-first order in use
+    assert sorted(len(n) for n in tr.plan.cand_names)[0] < 18 and max(len(n) for n in tr.plan.cand_names) == 18
+    disp_gpu = outputs[("disp", 0)]
+    disp_gpu.retain_grad()
+    losses["loss"].backward()
+    ref, ref_disp = oracle_on_outputs(tr, inputs, outputs, opt, ms)
+    ref["loss"].backward()
+    assert abs(float(losses["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
+    got = outputs[("bbd", "to_optimise")][0].cpu()
+    assert float((got - ref["min/0"]).abs().max()) < 1e-4
+    mism = outputs[("bbd", "argmin")][0].cpu() != ref["argmin/0"]
+    assert int((mism & (ref["margin/0"] > 2e-4)).sum()) == 0
+    flips = int(mism.sum())
+    ge, gg = ref_disp[0].grad, disp_gpu.grad.cpu()
+    rel = (gg - ge).abs() / float(ge.abs().max())
+    n_bad = int((rel > 1e-4).sum())
+    assert n_bad <= 25 * flips, (flips, n_bad, float(rel.max()))
+    assert float((gg - ge).norm() / ge.norm()) < (1e-4 if flips == 0 else 5e-2)
+    for name, model in tr.models.items():
+        got = [p.grad is not None and float(p.grad.abs().sum()) > 0 for n, p in model.named_parameters() if ".fc." not in n]
+        assert sum(got) >= 0.75 * len(got), name
+
+
 def test_train_step_updates_weights_and_is_deterministic():
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
