@@ -301,6 +301,43 @@ def normalised_smooth_loss(disp, img, backend=None):
     return _SmoothLoss.apply(disp, img, backend or default_backend())
 
 
+# ---------------------------------------------------------------------------- per-scale losses -> total (trainer.py:557-568)
+class _CombineLosses(torch.autograd.Function):
+    """per[s] = loss_sum[s] / n_px + w[s] * smooth[s];  total = sum(per) / num_scales  (trainer.py:557, :563-564, :566-568).
+    As scalar torch ops this was ~25 launches forward and ~45 backward per step (divisions, multiplications, additions and
+    their autograd nodes on one-element tensors - the eager hot path is launch-bound, profiles/r04/hot_path_launches.txt);
+    here it is 4 + 3 on [S]-vectors, the backward being two constants times the incoming gradient."""
+    _w = {}
+
+    @staticmethod
+    def forward(ctx, loss_sum, smooths, n_px, smoothness, scales, num_scales):
+        key = (str(loss_sum.device), float(smoothness), tuple(scales))
+        w = _CombineLosses._w.get(key)
+        if w is None:       # disparity_smoothness / 2**s in fp32: scaling by a power of two commutes with the rounding
+            w = (torch.tensor([float(smoothness)] * len(scales), dtype=torch.float32) /
+                 torch.tensor([2.0 ** s for s in scales], dtype=torch.float32)).to(loss_sum.device)
+            _CombineLosses._w[key] = w
+        per = torch.addcmul(loss_sum / n_px, smooths, w)
+        total = per.sum() / num_scales
+        ctx.save_for_backward(w)
+        ctx.meta = (float(n_px), float(num_scales))
+        return total, per
+
+    @staticmethod
+    def backward(ctx, g_total, g_per):
+        (w,) = ctx.saved_tensors
+        n_px, num_scales = ctx.meta
+        g = (g_total / num_scales).expand_as(w)
+        if g_per is not None:
+            g = g + g_per
+        return g / n_px, g * w, None, None, None, None
+
+
+def combine_losses(loss_sum, smooths, n_px, smoothness, scales, num_scales):
+    """(total, per-scale [S]) of the step's loss from the fused launch's per-scale sums and the smoothness terms."""
+    return _CombineLosses.apply(loss_sum, smooths, n_px, smoothness, scales, num_scales)
+
+
 # ---------------------------------------------------------------------------- pose composition (SURVEY 8f-2)
 FUSED_POSE_COMPOSE = os.environ.get("BBD_FUSED_POSE_COMPOSE", "1") != "0"
 

@@ -806,17 +806,18 @@ class Trainer:
         opt = self.opt
         if ("bbd", "loss_sum") not in outputs:
             raise RuntimeError("compute_losses needs the outputs of generate_images_pred (fused launch)")
-        losses, total = {}, 0
+        losses = {}
         n_px = self.plan.B * opt.height * opt.width
         # the edge-aware smoothness of every scale (:560-563, layers.py:203-216) in one launch pair each way
         smooths = ops.normalised_smooth_losses([outputs[("disp", s)] for s in opt.scales],
                                                [inputs[("color", 0, s)] for s in opt.scales], self._backend())
+        # loss/s = to_optimise.mean() + disparity_smoothness * smooth / 2**s (:557, :563-564); loss = sum / num_scales (:568,
+        # the frozen 4) - one small node on [S]-vectors instead of ~70 one-element launches per step
+        loss_sum = outputs[("bbd", "loss_sum")]
+        total, per = ops.combine_losses(loss_sum, smooths, n_px, opt.disparity_smoothness, list(opt.scales), self.num_scales)
         for i, s in enumerate(opt.scales):
-            loss = outputs[("bbd", "loss_sum")][i] / n_px                     # to_optimise.mean(), :557
-            loss = loss + opt.disparity_smoothness * smooths[i] / (2 ** s)
-            total = total + loss
-            losses["loss/{}".format(s)] = loss
-        losses["loss"] = total / self.num_scales
+            losses["loss/{}".format(s)] = per[i]
+        losses["loss"] = total
         return losses
 
     # ------------------------------------------------------------------ validation metrics (trainer.py:572-617)
