@@ -82,6 +82,8 @@ def evaluate(opt, dataloader=None, gt_depths=None, models=None, batch_size=16):
     `dataloader` / `gt_depths` / `models` may be injected (tests, synthetic splits); by default they are
     built from `opt.splits_dir/<eval_split>/{test_files.txt, gt_depths.npz}`, `opt.kt_path` and
     `opt.load_weights_folder`."""
+    from . import tuning
+    tuning.use_shipped_db()      # (no Trainer is built here: the tuned MIOpen database is wired explicitly)
     import os
     from . import datasets, networks
     from .layers import disp_to_depth

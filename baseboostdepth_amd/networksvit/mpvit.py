@@ -342,14 +342,16 @@ class MHCAEncoder(nn.Module):
         self.MHCA_layers = nn.ModuleList([
             MHCABlock(dim, num_heads=num_heads, mlp_ratio=mlp_ratio, drop_path=drop_path_list[i], qk_scale=qk_scale,
                       shared_cpe=self.cpe, shared_crpe=self.crpe) for i in range(num_layers)])
-        self._cpe_grads, self._crpe_grads = ops.SharedGrads(), ops.SharedGrads()
 
     def forward(self, x, size):
         """[B, N, C] tokens -> [B, C, H, W] feature map (channels-last memory, zero-copy)."""
         fused = _hip_tokens(x) and ops.FUSED_TOKEN_GLUE and ops.token_glue_supported(x) and torch.is_grad_enabled()
         n = len(self.MHCA_layers)
+        # gradient sinks of the shared position encodings: one pair per forward pass (they live in the layers' autograd
+        # nodes), so passes never share a buffer
+        cpe_grads, crpe_grads = ops.SharedGrads(), ops.SharedGrads()
         for i, layer in enumerate(self.MHCA_layers):
-            x = layer(x, size, (self._cpe_grads, self._crpe_grads, i, n) if (fused and n > 1) else None)
+            x = layer(x, size, (cpe_grads, crpe_grads, i, n) if (fused and n > 1) else None)
         return _as_image(x, size)
 
 

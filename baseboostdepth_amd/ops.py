@@ -718,17 +718,29 @@ class SharedGrads:
 
     def __init__(self):
         self.buf = {}
+        self.last = {}
 
     def target(self, key, like, index, count):
-        """(buffer to write the gradient into, accumulate flag) for layer `index` of `count`."""
-        if index == count - 1 or key not in self.buf:       # the layer whose backward runs first starts the sum
+        """(buffer to write the gradient into, accumulate flag) for layer `index` of `count`.  One sink belongs to ONE
+        forward pass of the chain (MHCAEncoder.forward makes a fresh pair per call), so two forwards before a backward, or
+        a second backward through a retained graph, cannot meet in one buffer; inside a pass the layers must arrive
+        last to first - anything else (nodes of a partial autograd.grad pass interleaved out of order) is refused rather
+        than summed wrongly."""
+        if key in self.buf and index >= self.last[key]:
+            raise RuntimeError("shared position-encoding gradients: layer %d after layer %d in one backward pass "
+                               "(set BBD_FUSED_TOKEN_GLUE=0 for per-layer gradients)" % (index, self.last[key]))
+        start = key not in self.buf                          # the layer whose backward runs first starts the sum
+        if start:
             self.buf[key] = torch.empty_like(like)
-            return self.buf[key], 0
-        return self.buf[key], 1
+        self.last[key] = index
+        return self.buf[key], 0 if start else 1
 
     def result(self, key, index):
         """What the layer returns to autograd for this parameter: the finished sum from layer 0, nothing from the others."""
-        return self.buf.pop(key) if index == 0 else None
+        if index != 0:
+            return None
+        self.last.pop(key, None)
+        return self.buf.pop(key)
 
 
 def _wgrad_target(share, tag, like):

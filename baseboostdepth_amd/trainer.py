@@ -36,7 +36,10 @@ class Trainer:
         if not getattr(opt, "no_cuda", False):
             from . import tuning
             tuning.use_shipped_db()      # MIOpen reads its database path at the first convolution (explicit, not at import)
-            tuning.use_shipped_gemm_db()  # hipBLASLt / rocBLAS solutions of the token GEMMs (MonoViT); tuning itself stays off
+            if getattr(opt, "ViT", False) or os.environ.get("BBD_GEMM_DB") == "1":
+                # hipBLASLt / rocBLAS solutions of MonoViT's token GEMMs (tuning itself stays off).  Only the MonoViT
+                # configuration turns TunableOp on - it is process-wide, and the ResNet configurations have no GEMMs
+                tuning.use_shipped_gemm_db()
         self.log_path = os.path.join(getattr(opt, "log_dir", "."), getattr(opt, "model_name", "mdp"))
         assert opt.height % 32 == 0, "'height' must be a multiple of 32"
         assert opt.width % 32 == 0, "'width' must be a multiple of 32"

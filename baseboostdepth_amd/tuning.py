@@ -8,8 +8,8 @@ the compiled kernels of the winning solvers (`cache/*.ukdb`, a build product: gi
 database in place MIOpen's immediate mode (torch.backends.cudnn.benchmark = False, the reference's setting,
 train.py:21) picks the measured-fastest solver for a known shape and falls back to its heuristic for any other.
 
-`use_shipped_db()` is an EXPLICIT call (Trainer.__init__, bench.py, train.py make it before the first convolution;
-importing the package changes nothing).  It never writes into the checkout: MIOpen appends to its user database and
+`use_shipped_db()` is an EXPLICIT call (Trainer.__init__, bench.py and evaluation.evaluate make it before the first
+convolution; importing the package changes nothing).  It never writes into the checkout: MIOpen appends to its user database and
 keeps lock files beside it, so the shipped files are copied ONCE into a per-user cache directory (reused by later
 processes and by all ranks of a job; MIOpen's own locking serialises their writes) and MIOpen is pointed there.  A
 caller's own MIOPEN_USER_DB_PATH always wins.
@@ -33,14 +33,22 @@ def _cache_root():
 
 
 def _fingerprint():
+    """Content hash of the shipped database (names + bytes, not mtimes: every clone of one commit maps to the SAME private
+    copy instead of leaving a new one behind)."""
     h = hashlib.sha256()
     for base, _, files in sorted(os.walk(DB_DIR)):
         for f in sorted(files):
             if f.endswith((".lock", ".time")):
                 continue
-            st = os.stat(os.path.join(base, f))
-            h.update(("%s:%d:%d;" % (os.path.relpath(os.path.join(base, f), DB_DIR), st.st_size, int(st.st_mtime))).encode())
+            h.update((os.path.relpath(os.path.join(base, f), DB_DIR) + ";").encode())
+            with open(os.path.join(base, f), "rb") as fh:
+                h.update(fh.read())
     return h.hexdigest()[:12]
+
+
+# what the last use_shipped_db() / use_shipped_gemm_db() did, for callers that report it (bench.py): the private MIOpen
+# copy is one MIOpen appends to, so a run that found it already there also sees earlier runs' find results
+STATUS = {"miopen_db": None, "miopen_db_prewarmed": None, "gemm_db": None, "gemm_db_accepted": None, "gemm_db_why": None}
 
 
 def use_shipped_db():
@@ -53,6 +61,8 @@ def use_shipped_db():
     if "MIOPEN_USER_DB_PATH" in os.environ:
         return os.environ["MIOPEN_USER_DB_PATH"]
     db = os.path.join(_cache_root(), "miopen_db_" + _fingerprint())
+    if STATUS["miopen_db"] != db:
+        STATUS["miopen_db"], STATUS["miopen_db_prewarmed"] = db, os.path.isdir(db)
     if not os.path.isdir(db):
         os.makedirs(os.path.dirname(db), exist_ok=True)
         tmp = tempfile.mkdtemp(prefix="miopen_db_", dir=os.path.dirname(db))
@@ -90,8 +100,8 @@ def use_shipped_gemm_db():
     if not torch.cuda.is_available():
         return None
     import torch.cuda.tunable as tunable
-    st = os.stat(GEMM_DB)
-    tag = hashlib.sha256(("%d:%d" % (st.st_size, int(st.st_mtime))).encode()).hexdigest()[:12]
+    with open(GEMM_DB, "rb") as fh:
+        tag = hashlib.sha256(fh.read()).hexdigest()[:12]
     dst = os.path.join(_cache_root(), "gemm_db_%s.csv" % tag)
     if not os.path.isfile(dst):
         os.makedirs(os.path.dirname(dst), exist_ok=True)
@@ -105,4 +115,31 @@ def use_shipped_gemm_db():
     tunable.set_filename(dst, insert_device_ordinal=False)
     tunable.enable(True)
     tunable.tuning_enable(False)
+    # TunableOp drops a table without a word when the versions in its header are not this process's: say so
+    ok, why = gemm_db_accepted(dst)
+    STATUS.update(gemm_db=dst, gemm_db_accepted=ok, gemm_db_why=why)
+    if not ok:
+        import warnings
+        warnings.warn("the shipped GEMM solution table will be ignored by TunableOp (%s): MonoViT's token GEMMs take "
+                      "the library defaults (about -10 %% step throughput); re-record it with tools/gemm_tune.sh" % why)
     return dst
+
+
+def gemm_db_accepted(path=None):
+    """(True, None) when every `Validator` line of the table equals what this process's TunableOp reports
+    (torch.cuda.tunable.get_validators(): PyTorch / HIP / hipBLASLt / rocBLAS versions, GPU architecture) - the condition
+    under which TunableOp uses the table; otherwise (False, which entries differ)."""
+    import torch.cuda.tunable as tunable
+    path = path or GEMM_DB
+    want = {}
+    with open(path) as fh:
+        for line in fh:
+            parts = line.strip().split(",")
+            if len(parts) >= 3 and parts[0] == "Validator":
+                want[parts[1]] = ",".join(parts[2:])
+    try:
+        have = {str(k): str(v) for k, v in tunable.get_validators()}
+    except Exception as e:                       # never fail a run on the report
+        return False, "validators unavailable (%s)" % type(e).__name__
+    bad = ["%s: table %s, here %s" % (k, v, have.get(k)) for k, v in want.items() if have.get(k) != v]
+    return (not bad), ("; ".join(bad) or None)

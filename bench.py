@@ -555,7 +555,6 @@ def main(argv=None):
     from baseboostdepth_amd import tuning
 
     tuning.use_shipped_db()            # explicit (the Trainer would do it too): before the first convolution
-    gemm_db = tuning.use_shipped_gemm_db()
     torch.manual_seed(42)
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
@@ -591,9 +590,12 @@ def main(argv=None):
                        "miopen": {"user_db": ("shipped (baseboostdepth_amd/miopen_db, tools/miopen_tune.sh)"
                                               if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "")).startswith("miopen_db") else
                                               os.environ.get("MIOPEN_USER_DB_PATH")),
+                                  # MIOpen appends to its private copy: a copy that was already there also holds the find
+                                  # results of earlier runs on this machine (BBD_MIOPEN_CACHE=<fresh dir> for a cold one)
+                                  "user_db_prewarmed": tuning.STATUS["miopen_db_prewarmed"],
                                   "find": bool(torch.backends.cudnn.benchmark)},
-                       "gemm": {"tunableop_table": ("shipped (baseboostdepth_amd/gemm_db, tools/gemm_tune.sh)"
-                                                    if (gemm_db and "gemm_db_" in os.path.basename(gemm_db)) else gemm_db),
+                       # TunableOp is process-wide and only the MonoViT trainer turns it on (secondary.vit below)
+                       "gemm": {"tunableop_enabled": bool(torch.cuda.tunable.is_enabled()),
                                 "tuning_at_run_time": bool(torch.cuda.tunable.tuning_is_enabled()
                                                            and torch.cuda.tunable.is_enabled())}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": res["kernel_timing"],
@@ -638,7 +640,10 @@ def main(argv=None):
                     "step_graph": r["graph_note"] if r["graph_note"] is not None else bool(r["trainer"].use_graph),
                     "roofline": {k: rf.get(k) for k in ("bound", "limiter", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")},
                     "kernels": {k: {f: v[f] for f in ("mean_ms", "alg_MB_per_launch", "frac") if f in v} for k, v in r["kernels"].items()},
-                    "kernels_constants_stale": bool(r["constants"] and r["constants"]["stale"])})
+                    "kernels_constants_stale": bool(r["constants"] and r["constants"]["stale"]),
+                    **({"gemm": {"tunableop_table": "shipped (baseboostdepth_amd/gemm_db, tools/gemm_tune.sh)",
+                                 "accepted_by_tunableop": tuning.STATUS["gemm_db_accepted"],
+                                 "why_not": tuning.STATUS["gemm_db_why"]}} if cfg == "vit" else {})})
                 release(r)
             except Exception as e:    # a secondary configuration never takes the headline down
                 secondary.append({"config": cfg, "error": "%s: %s" % (type(e).__name__, str(e)[:200])})

@@ -44,8 +44,11 @@ extern "C" {
 /* Optional pairing hint of a WARP candidate, bits 16-23 of `kind`: 1 + the index (arg-min id) of another warp
  * candidate of the same sample that samples the SAME source image (the error-induced warp of a frame and its true-pose
  * warp, trainer.py:439-442).  The backward takes two candidates per pass and prefers the hinted partner (their gathers
- * share cache lines); 0 = no hint (the next candidate in id order is taken).  A speed hint only: results do not depend
- * on it. */
+ * share cache lines); 0 = no hint (the next candidate in id order is taken).  A speed hint: min-loss maps, arg-min ids,
+ * depth and warped images are bit-for-bit the same with any hint (the running minimum is order-free); the backward adds
+ * a pixel's per-candidate depth gradients in visiting order, so disparity gradients are deterministic for a given table
+ * and equal across tables up to fp32 summation order (only one candidate wins a pixel, the others add exact zeros -
+ * in practice the same bits). */
 #define BBD_PAIR_SHIFT 16
 
 #define BBD_E_BADARG (-1)

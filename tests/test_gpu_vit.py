@@ -250,6 +250,8 @@ def test_shipped_gemm_table_drives_tunableop_without_tuning():
     torch.cuda.synchronize()
     assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert tunable.get_filename() == path
+    # whether TunableOp will USE the table is reported (it drops a table with other versions in its header silently)
+    assert tuning.STATUS["gemm_db"] == path and tuning.STATUS["gemm_db_accepted"] is True, tuning.STATUS
 
 
 @pytest.mark.parametrize("B,N,cin,cout", [(3, 37, 64, 192), (2, 129, 216, 648), (1, 3, 288, 1152), (12, 480, 216, 216), (2, 50, 64, 62),
