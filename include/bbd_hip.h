@@ -47,8 +47,8 @@ extern "C" {
  * share cache lines); 0 = no hint (the next candidate in id order is taken).  A speed hint: min-loss maps, arg-min ids,
  * depth and warped images are bit-for-bit the same with any hint (the running minimum is order-free); the backward adds
  * a pixel's per-candidate depth gradients in visiting order, so disparity gradients are deterministic for a given table
- * and equal across tables up to fp32 summation order (only one candidate wins a pixel, the others add exact zeros -
- * in practice the same bits). */
+ * and equal across tables up to fp32 summation order (a pixel collects gradient from every candidate that won one of
+ * its 3x3 neighbours). */
 #define BBD_PAIR_SHIFT 16
 
 #define BBD_E_BADARG (-1)
