@@ -15,7 +15,7 @@ while read -r group; do
   i=$((i+1))
   if [ "${PMC_TARGET:-kernel_bench}" = "bench" ]; then
     rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OUT" -o pass$i -- \
-        python3 bench.py --step-graph off --steps 3 --warmup 2 --no-cpu-baseline --no-eager-ab "$@" > "$OUT/pass$i.log" 2>&1
+        python3 bench.py --step-graph off --steps 3 --warmup 2 --no-cpu-baseline --no-eager-ab --no-secondary "$@" > "$OUT/pass$i.log" 2>&1
   else
     rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$OUT" -o pass$i -- \
         python3 tools/kernel_bench.py --iters 3 --warmup 1 "$@" > "$OUT/pass$i.log" 2>&1

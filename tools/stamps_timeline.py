@@ -3,7 +3,7 @@
 Every workgroup records the chip-wide 100 MHz wall clock at its start and end, plus (backward) how many candidates it
 processed.  Prints the launch span, the sum of workgroup lifetimes / resident slots (= the span a perfectly balanced launch
 would need), lifetime statistics by live-candidate count, and how many workgroups are resident over time.
-usage: stamps_timeline.py [md2|boost7]     (SMOOTH_DISP=1: spatially smooth disparities, like the training step's)"""
+usage: stamps_timeline.py [md2|boost7|boost_e15]     (SMOOTH_DISP=1: spatially smooth disparities, like the training step's)"""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +21,11 @@ from baseboostdepth_amd.trainer import Trainer
 dev, H, W, B = "cuda:0", 192, 640, 12
 if cfg == "md2":
     ms, trimin, decomp, scales = [1] * B, False, False, [0, 1, 2, 3]
+elif cfg == "boost_e15":        # the epoch-15 offset distribution (tools/kernel_bench.py's draw): mixed 8- and 18-candidate samples
+    import random
+    rnd = random.Random(15)
+    ms = [rnd.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448])[0] for _ in range(B)]
+    trimin, decomp, scales = True, True, [0]
 else:
     ms, trimin, decomp, scales = [7] * B, True, True, [0]
 inputs = synthetic_batch(ms, H, W, scales, device=dev, seed=42)

@@ -7,7 +7,7 @@ export TMPDIR=/tmp BBD_XCD_REMAP=$mode
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o ${cfg}_m${mode}_$c -- \
-      python3 bench.py --config $cfg --step-graph off --steps 3 --warmup 2 --no-cpu-baseline --no-eager-ab > $out/${cfg}_m${mode}_$c.log 2>&1
+      python3 bench.py --config $cfg --step-graph off --steps 3 --warmup 2 --no-cpu-baseline --no-eager-ab --no-secondary > $out/${cfg}_m${mode}_$c.log 2>&1
 done
 python3 - $out $cfg $mode <<'PY'
 import csv, glob, sys, collections
