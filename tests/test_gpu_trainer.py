@@ -260,7 +260,11 @@ def test_rccl_collectives_captured_into_the_step_graph_one_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BBD_BUCKET_BYTES="4000000", MASTER_PORT=str(29000 + os.getpid() % 300))
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:      # a port that is free NOW (a fixed one can still be
+        sock.bind(("127.0.0.1", 0))                                      # in TIME_WAIT from an earlier test of the run)
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BBD_BUCKET_BYTES="4000000", MASTER_PORT=str(port))
     env.pop("BBD_DIST_BACKEND", None)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_check.py"), "--capture"], env=env,
                          capture_output=True, text=True, timeout=900)
