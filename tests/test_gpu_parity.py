@@ -298,6 +298,43 @@ def test_smoothness_kernel_against_oracle(backend):
         assert err < 1e-4, (s, err)
 
 
+def test_multi_scale_smoothness_launch_equals_the_single_scale_launches(backend):
+    """bbd_smooth_loss_multi_* (all scales of a step in one launch pair each way) vs bbd_smooth_loss_* per scale: same
+    kernels, same reduction order - values and gradients bit for bit."""
+    from baseboostdepth_amd import ops
+    gen = torch.Generator().manual_seed(19)
+    B = 5
+    disps = [(torch.rand(B, 1, 192 >> s, 640 >> s, generator=gen) * 0.8 + 0.01).to(DEV).requires_grad_(True) for s in range(4)]
+    imgs = [(torch.round(torch.rand(B, 3, 192 >> s, 640 >> s, generator=gen) * 255) / 255).to(DEV) for s in range(4)]
+    multi = ops.normalised_smooth_losses(disps, imgs, backend)
+    wts = torch.tensor([1.0, 0.5, 0.25, 0.125], device=DEV)
+    (multi * wts).sum().backward()
+    for i in range(4):
+        d2 = disps[i].detach().clone().requires_grad_(True)
+        one = ops.normalised_smooth_loss(d2, imgs[i], backend)
+        (one * wts[i]).backward()
+        assert abs(float(one) - float(multi[i])) <= 3e-7 * abs(float(one))       # (1-2 ulp: the sum over chunks and the division are ATen ops in another order)
+        assert torch.equal(d2.grad, disps[i].grad), i
+
+
+def test_pose_matrix_rows_launch_equals_the_per_sign_launches(backend):
+    """ops.pose_matrix(invert_rows=...) - the poses of both signs of a step in one launch each way - vs one call per sign."""
+    from baseboostdepth_amd import ops
+    gen = torch.Generator().manual_seed(23)
+    n = 24
+    aa = (0.3 * torch.randn(n, 1, 3, generator=gen)).to(DEV)
+    tr = torch.randn(n, 1, 3, generator=gen).to(DEV)
+    w = torch.randn(n, 4, 4, generator=gen).to(DEV)
+    flags = torch.tensor([1] * 12 + [0] * 12, dtype=torch.int32, device=DEV)
+    a1, t1 = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    M = ops.pose_matrix(a1, t1, backend=backend, invert_rows=flags)
+    (M * w).sum().backward()
+    a2, t2 = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    M2 = torch.cat([ops.pose_matrix(a2[:12], t2[:12], True, backend), ops.pose_matrix(a2[12:], t2[12:], False, backend)], 0)
+    (M2 * w).sum().backward()
+    assert torch.equal(M, M2) and torch.equal(a1.grad, a2.grad) and torch.equal(t1.grad, t2.grad)
+
+
 def test_pose_matrix_kernel(backend):
     """Fused transformation_from_parameters vs the op-for-op torch form (values and gradients)."""
     from baseboostdepth_amd import layers as L
