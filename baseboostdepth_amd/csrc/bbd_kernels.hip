@@ -561,6 +561,10 @@ __device__ __forceinline__ void strip_ystats(const float (*sy)[FPLANE], int ly, 
 }
 
 // Photometric loss of the strip's 4 pixels given the staged prediction (sx) and target (sy).
+// RESTAT: the target window's statistics are re-derived here from the target tile (its window is loaded for the x y sums
+// anyway: 18 more adds and 9 more multiplications per pixel and channel) instead of being held in 24 registers across the
+// candidate loop - the forward's low-register form, see warp_ssim_min_fwd_kernel.
+template <bool RESTAT = false>
 __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const float (*sy)[FPLANE],
                                            int ly, int lx0, const float mu_y[3][PPT],
                                            const float sg_y[3][PPT], int no_ssim, float out[PPT]) {
@@ -573,7 +577,7 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
     float nn[PPT], dd[PPT], qq[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      float s = 0.0f, ss = 0.0f, sxy = 0.0f;
+      float s = 0.0f, ss = 0.0f, sxy = 0.0f, ty = 0.0f, tyy = 0.0f;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -582,8 +586,15 @@ __device__ __forceinline__ void strip_loss(const float (*sx)[FPLANE], const floa
           s += v;
           ss += v * v;
           sxy += v * y[r][j + c];
+          if (RESTAT) {         // (the same row-major sums as strip_ystats: the same bits)
+            ty += y[r][j + c];
+            tyy += y[r][j + c] * y[r][j + c];
+          }
         }
-      bbd_ssim_nd(s, ss, sxy, mu_y[ch][j], sg_y[ch][j], &nn[j], &dd[j]);
+      float my, gy;
+      if (RESTAT) bbd_ystats(ty, tyy, &my, &gy);
+      else { my = mu_y[ch][j]; gy = sg_y[ch][j]; }
+      bbd_ssim_nd(s, ss, sxy, my, gy, &nn[j], &dd[j]);
       l1[j][ch] = fabsf(y[1][j + 1] - x[1][j + 1]);
     }
 #pragma unroll
@@ -797,15 +808,25 @@ struct FwdArgs {
   int S, B, NP, ntiles, no_ssim, remap;
 };
 
-#ifndef BBD_FWD_WAVES
-#define BBD_FWD_WAVES 3   // <= 168 VGPRs (154 used since the pose rows moved to SGPRs); 2 waves/SIMD is 15 % slower
-#endif
-template <bool PLANE>
-__global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(FwdArgs a) {
-  // s_x is double-buffered: candidate c+1 is warped into the other buffer while slower waves
-  // still read candidate c, so one barrier per warp candidate is enough
+// Three forms of the forward, chosen per launch by launch_fused_fwd (round 4; VERDICT r3 item 1c measured INSIDE the training
+// step, profiles/r04/forward_four_waves_instep.txt - round 3 had measured four-wave forms with scattered gathers only and
+// found nothing):
+//   FWD_DOUBLE   three waves per SIMD (<= 168 VGPRs: 146 used), the warped tile double-buffered (44 KB of LDS): candidate
+//                c+1 is warped into the other buffer while slower waves still read candidate c, one barrier per candidate.
+//                Single-scale launches with many candidates (the boosted recipe from epoch 10 on): 1 440 workgroups are
+//                1.9 rounds of 768 slots but only 1.4 of 1 024 - the fourth wave loses to the launch's quantisation there
+//                (epoch-15 draw +3.4 % with four waves, uniform m = 7 -3.4 %: the mixed batches are the real distribution).
+//   FWD_RESTAT   four waves per SIMD, single buffer (29 KB, a second barrier per candidate), the target window's statistics
+//                re-derived per candidate inside strip_loss instead of held in 24 registers: 119 VGPRs, no spill.  Few warp
+//                candidates per sample (MD2, MonoViT): MD2 forward -3.6 %; +3 % at 12 warp candidates.
+//   FWD_HELD     four waves per SIMD, single buffer, statistics held: 17 registers spilled at the 128 line (none in the warp
+//                phase).  Many candidates AND several scales (the early curriculum, trimin5): -7.8 %.
+constexpr int FWD_DOUBLE = 0, FWD_RESTAT = 1, FWD_HELD = 2;
+template <bool PLANE, int FORM>
+__global__ __launch_bounds__(NT, FORM == FWD_DOUBLE ? 3 : 4) void warp_ssim_min_fwd_kernel(FwdArgs a) {
+  constexpr bool RESTAT = FORM == FWD_RESTAT;
   __shared__ __attribute__((aligned(16))) float s_y[3][FPLANE];
-  __shared__ __attribute__((aligned(16))) float s_xx[2][3][FPLANE];
+  __shared__ __attribute__((aligned(16))) float s_xx[FORM == FWD_DOUBLE ? 2 : 1][3][FPLANE];
   __shared__ float s_red[4];
   int buf = 0;
   const BbdDims dm = a.dm;
@@ -870,7 +891,7 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
   const int pix = yy * W + xx;
 
   float mu_y[3][PPT], sg_y[3][PPT];
-  strip_ystats(s_y, ly, lx0, mu_y, sg_y);
+  if (!RESTAT) strip_ystats(s_y, ly, lx0, mu_y, sg_y);
 
   float dcell[CellsF::N];
 #pragma unroll
@@ -914,9 +935,10 @@ __global__ __launch_bounds__(NT, BBD_FWD_WAVES) void warp_ssim_min_fwd_kernel(Fw
     BBD_STAMP(5 + 4 * (vs & 3));
     __syncthreads();
     BBD_STAMP(6 + 4 * (vs & 3));
-    strip_loss(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
+    strip_loss<RESTAT>(s_xx[buf], s_y, ly, lx0, mu_y, sg_y, a.no_ssim, loss);
     BBD_STAMP(7 + 4 * (vs & 3));
-    buf ^= 1;
+    if (FORM == FWD_DOUBLE) buf ^= 1;
+    else __syncthreads();     // (single buffer: the next candidate's warp phase overwrites the tile)
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       int aj = (int)((argw >> (8 * j)) & 0xffu);
@@ -2208,6 +2230,13 @@ int xcd_remap_enabled(int S) {
   static const int forced = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr ? -1 : (e[0] - '0'); }();
   return forced >= 0 ? forced : (S == 1);
 }
+int fused_fwd_form(int S, int B, int NP, int ntiles) {
+  static const int forced = [] { const char* e = getenv("BBD_FWD_FORM"); return e == nullptr ? -1 : (e[0] - '0'); }();
+  if (forced >= 0 && forced <= 2) return forced;
+  if (NP <= 4 * B) return FWD_RESTAT;
+  return (long)S * B * ntiles >= 4 * 1024 ? FWD_HELD : FWD_DOUBLE;
+}
+
 int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -2309,12 +2338,22 @@ static int launch_fused_fwd(const void* const* frames, const float* target, cons
   a.work = work;
   // (a paired-candidate / packed-SSIM form of this kernel was built and measured slower - profiles/r03/fwdp_ab.txt; its
   // source is kept under tools/experiments/paired_packed_forward.hip.txt)
-  if (depth != nullptr)
-    hipLaunchKernelGGL(warp_ssim_min_fwd_kernel<true>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
-                       static_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL(warp_ssim_min_fwd_kernel<false>, dim3((unsigned)(S * B * a.ntiles)), dim3(NT), 0,
-                       static_cast<hipStream_t>(stream), a);
+  // which form (see warp_ssim_min_fwd_kernel): few warp candidates per sample (pose-table rows per sample <= 4: MD2's 2) ->
+  // RESTAT; many candidates over several scales (>= 4 rounds of the 1 024 four-wave slots) -> HELD; else the three-wave form
+  const int form = fused_fwd_form(S, B, NP, a.ntiles);
+  const dim3 grid((unsigned)(S * B * a.ntiles));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define BBD_LAUNCH_FWD(P, F) hipLaunchKernelGGL((warp_ssim_min_fwd_kernel<P, F>), grid, dim3(NT), 0, st, a)
+  if (depth != nullptr) {
+    if (form == FWD_RESTAT) BBD_LAUNCH_FWD(true, FWD_RESTAT);
+    else if (form == FWD_HELD) BBD_LAUNCH_FWD(true, FWD_HELD);
+    else BBD_LAUNCH_FWD(true, FWD_DOUBLE);
+  } else {
+    if (form == FWD_RESTAT) BBD_LAUNCH_FWD(false, FWD_RESTAT);
+    else if (form == FWD_HELD) BBD_LAUNCH_FWD(false, FWD_HELD);
+    else BBD_LAUNCH_FWD(false, FWD_DOUBLE);
+  }
+#undef BBD_LAUNCH_FWD
   return launch_status();
 }
 

@@ -312,7 +312,12 @@ def kernel_table(timer, plan, S, config, batch):
             if not e:
                 continue
             kernels[k]["pmc_traffic_MB_per_launch"] = round(e["traffic_bytes"] / 1e6, 1)
-            mix = cc["isa_mix"].get(alias(k))
+            # (the forward has two instantiations by candidate count, chosen like launch_fused_fwd does)
+            # (the forward has three forms by launch shape, chosen like fused_fwd_form() of the library does)
+            suffix = ""
+            if alias(k).endswith("_fwd") and plan.NP > 4 * plan.B:
+                suffix = "_held" if S * plan.B * ((H + 15) // 16) * ((W + 63) // 64) >= 4096 else "_many"
+            mix = cc["isa_mix"].get(alias(k) + suffix)
             if "valu_wave_instructions" in e and mix:
                 # vector-issue bound (finding 14): the launch's counter-measured vector instructions (a
                 # committed PMC pass, not this run) x the kernel's mean cycles per instruction by static issue class at

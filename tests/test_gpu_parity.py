@@ -298,6 +298,22 @@ def test_smoothness_kernel_against_oracle(backend):
         assert err < 1e-4, (s, err)
 
 
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_every_forward_form_is_bit_exact(form):
+    """The fused forward has three forms chosen per launch shape (three waves / double buffer; four waves with the target
+    statistics re-derived per candidate; four waves with them held).  Each is valid for every input: the golden cases must
+    come out bit for bit under each (BBD_FWD_FORM forces one; it is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBD_FWD_FORM=str(form))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
+                          "-k", "fused_path_matches_reference_bit_for_bit or disparity_mode_equals_depth_plane_mode"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and " passed" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 def test_multi_scale_smoothness_launch_equals_the_single_scale_launches(backend):
     """bbd_smooth_loss_multi_* (all scales of a step in one launch pair each way) vs bbd_smooth_loss_* per scale: same
     kernels, same reduction order - values and gradients bit for bit."""

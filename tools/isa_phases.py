@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of the fused kernels PER PHASE (no GPU): compiles bbd_kernels.hip with -DBBD_MARKS, which turns
 every BBD_STAMP site into an assembly comment, and sums the vector instructions by issue class (tools/isa_mix.py) between
-consecutive marks in layout order.  usage: tools/isa_phases.py [fwd|bwd] [extra hipcc flags...]"""
+consecutive marks in layout order.  usage: tools/isa_phases.py [fwd|fwd_many|bwd] [extra hipcc flags...]"""
 import collections
 import os
 import re
@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from isa_mix import issue_class, CYCLES, DORMANT  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-kern = {"fwd": "warp_ssim_min_fwd_kernelILb0", "bwd": "warp_ssim_min_bwd2_kernelILb1"}[which]
+kern = {"fwd": "warp_ssim_min_fwd_kernelILb0ELi1", "fwd_many": "warp_ssim_min_fwd_kernelILb0ELi0", "fwd_held": "warp_ssim_min_fwd_kernelILb0ELi2",
+        "bwd": "warp_ssim_min_bwd2_kernelILb1"}[which]
 src = os.environ.get("BBD_VARIANT_SRC", os.path.join(ROOT, "baseboostdepth_amd", "csrc", "bbd_kernels.hip"))
 asm = "/tmp/bbd_isa_phases.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math",

@@ -24,10 +24,10 @@ for spec in "$@"; do
 import re, sys
 t = open("build_variants/k_%s.log" % sys.argv[1]).read()
 out = []
-for kern in ("warp_ssim_min_fwd_kernelILb0", "warp_ssim_min_bwd2_kernelILb1", "warp_ssim_min_fwd_kernel", "warp_ssim_min_bwd2_kernel"):
+for kern in ("warp_ssim_min_fwd_kernelILb0ELi1", "warp_ssim_min_fwd_kernelILb0ELi0", "warp_ssim_min_fwd_kernelILb0ELi2", "warp_ssim_min_bwd2_kernelILb1"):
     m = re.search(r"Function Name: \S*%s\S*.*?VGPRs: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+).*?LDS Size \[bytes/block\]: (\d+)" % kern, t, re.S)
-    if m and kern.split("_kernel")[0] not in [o[0] for o in out]:
-        out.append((kern.split("_kernel")[0], "%s: %s VGPR, spills s%s v%s, LDS %s" % (kern.replace("warp_ssim_min_", ""), *m.groups())))
+    if m:
+        out.append((kern, "%s: %s VGPR, spills s%s v%s, LDS %s" % (kern.replace("warp_ssim_min_", ""), *m.groups())))
 print("; ".join(o[1] for o in out))
 PY
 done
