@@ -297,6 +297,19 @@ def test_bench_two_ranks_sharing_this_gpu_print_one_split_graph_line():
     line = json.loads(lines[0])
     assert line["dp_mode"] == "overlap" and line["step_graph"] is False and line["exchange_ms"] > 0
     assert line["buckets_launched_in_backward"] is not None
+    # round 4: both ranks report their device (here the SAME GPU, which is exactly what `devices` must expose), the ranks'
+    # own step times, and `--dp-mode all` measures the three loops in one launch (gloo cannot be captured: graph-overlap
+    # falls back to the split-graph loop and says so)
+    assert line["devices"] == 1 and line["ms_per_step_rank_min"] <= line["ms_per_step_rank_max"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "2", "--steps", "3",
+                          "--warmup", "1", "--no-cpu-baseline", "--dp-mode", "all", "--dp-extra-timeout", "300"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["dp_mode"] == "graph" and set(line["dp_modes"]) == {"graph", "overlap", "graph-overlap"}
+    assert line["dp_modes"]["overlap"]["dp_mode"] == "overlap" and line["dp_modes"]["overlap"]["value"] > 0
+    assert line["dp_modes"]["graph-overlap"]["value"] > 0
 
 
 def test_step_graph_replay_matches_eager(monkeypatch):
