@@ -87,7 +87,7 @@ dll.bbd_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 run(False)
 torch.cuda.synchronize()
 dll.bbd_debug_set_stamps(ctypes.c_void_p(0))
-report("forward", nf, 256 * 3, False)
+report("forward", nf, 256 * (4 if cfg == "md2" else 3), False)      # (the forward's form per launch shape: fused_fwd_form)
 ls = run(True)
 torch.cuda.synchronize()
 stamps.zero_()
