@@ -84,8 +84,13 @@ class HipBackend:
             n = S * plan.B * (self.num_tiles_bwd(H, W) if backward else self.num_tiles_fwd(H, W))
             host = torch.empty(n, 2, dtype=torch.int32)
             order = None if plan.sample_order is None else (ctypes.c_int32 * plan.B)(*plan.sample_order)
-            self.lib.call("bbd_fused_work_items", plan.B, S, H, W, int(backward), order, host.data_ptr())
-            tb[key] = host.to(device)
+            try:
+                self.lib.call("bbd_fused_work_items", plan.B, S, H, W, int(backward), order, host.data_ptr())
+                tb[key] = host.to(device)
+            except _lib.BbdError:
+                # outside the table's packing limits (more than 4 096 samples, 8 scales or 2^17 tiles): the launches take
+                # the grid order and decode it themselves - a speed choice only
+                tb[key] = None
         return tb[key]
 
     @staticmethod
