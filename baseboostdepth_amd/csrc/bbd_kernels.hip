@@ -228,11 +228,6 @@ struct Cells {
   }
   __device__ __forceinline__ int pix(int k, int W) const { return (xy[k] >> 16) * W + (xy[k] & 0xffff); }
   __device__ __forceinline__ bool own(int k) const { return (ownbits >> k) & 1; }
-  // index of an owned cell inside the tile's (ROWS-2*HALO) x (COLS-2*HALO) pixel block
-  __device__ __forceinline__ int own_index(int k) const {
-    const int r = lds[k] / STRIDE, c = lds[k] - r * STRIDE;
-    return (r - HALO) * (COLS - 2 * HALO) + (c - HALO);
-  }
 };
 
 // Block-uniform table reads (candidate descriptors, pose-table rows, per-scale scalars): read-only for the whole
@@ -419,15 +414,15 @@ struct NoWork {
 // XS = element stride of the staged planes (2: the backward interleaves (x, y) pairs, see its kernel).
 // `under_gathers`: work of the caller that does not depend on the warp, run once after the first batch's gathers have been
 // issued and before their values are consumed (the wave would otherwise only wait there).
-// OWNREG > 0 (the backward's nine-plane form): the first OWNREG cells of a thread are its own pixels and their
-// d warped / d (ix, iy) stay in its registers (dvr[cell][0..2] = d/d ix per channel, [3..5] = d/d iy), no LDS planes.
-template <int BATCH, typename CellsT, int PLANE, int DVPLANE = TH * TW, bool BWD = false, int XS = 1, typename Work = NoWork,
-          int OWNREG = 0>
+// OWNREG > 0 (the backward): the first OWNREG cells of a thread are its own pixels and their d warped / d (ix, iy) stay in its
+// registers (dvr[cell][0..2] = d/d ix per channel, [3..5] = d/d iy; zero where the border clamp is active), so the
+// sample-gradient phase needs neither gathers nor LDS planes.
+template <int BATCH, typename CellsT, int PLANE, bool BWD = false, int XS = 1, typename Work = NoWork, int OWNREG = 0>
 __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, const float (&d)[CellsT::N],
                                               const float (&pj)[21], const BbdDims dm, int hw,
                                               const CellsT& cl, float (*s)[PLANE],
-                                              float* __restrict__ warped_out, float (*dv)[DVPLANE] = nullptr,
-                                              Work under_gathers = Work(), float (*dvr)[6] = nullptr) {
+                                              float* __restrict__ warped_out, Work under_gathers = Work(),
+                                              float (*dvr)[6] = nullptr) {
   // pj = P (3x4) | inv_K[:3,:3] of this candidate: block-uniform loads from the projection table by the caller, so the
   // 21 values live in SGPRs (bbd_pose_expand formed P once, with the reference's rounding order)
   // Cells are processed in batches: project + tap geometry for the whole batch first, then all of
@@ -508,21 +503,6 @@ __device__ __forceinline__ void warp_into_lds(const float* __restrict__ src, con
           for (int ch = 0; ch < 3; ++ch) {
             dvr[k < OWNREG ? k : 0][ch] = (clip[kk] & 1) ? 0.0f : dvx[ch];
             dvr[k < OWNREG ? k : 0][3 + ch] = (clip[kk] & 2) ? 0.0f : dvy[ch];
-          }
-        }
-      } else if (dv != nullptr && cl.own(k)) {
-        // backward: d warped / d (ix, iy) of the tile's own pixels from the taps already in registers
-        // (zero where the border clamp is active), so the sample-gradient phase needs no gathers
-        const int ci = cl.own_index(k);
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          if (BWD) {
-            dv[ch][ci] = (clip[kk] & 1) ? 0.0f : dvx[ch];
-            dv[3 + ch][ci] = (clip[kk] & 2) ? 0.0f : dvy[ch];
-          } else {
-            const float* vv = v[kk][ch];
-            dv[ch][ci] = (clip[kk] & 1) ? 0.0f : (vv[1] - vv[0]) * t[kk].s + (vv[3] - vv[2]) * t[kk].n;
-            dv[3 + ch][ci] = (clip[kk] & 2) ? 0.0f : (vv[2] - vv[0]) * t[kk].e + (vv[3] - vv[1]) * t[kk].w;
           }
         }
       }
@@ -1032,15 +1012,11 @@ struct BwdArgs {
 };
 
 // ------------------------------------------------------------------------------------------
-// Fused backward, narrow-tile form (the shipped one): the same LDS images and phases as above on a
-// 32x16-pixel tile, 256 threads = 4 waves, a 2-pixel strip per thread.  Per-thread state halves (3 staged
-// cells instead of 6, 2-pixel windows) -> 128 VGPRs, and the LDS images halve -> 38.5 KB per workgroup, so
-// FOUR independent workgroups = 16 waves per CU = 4 waves per SIMD are resident instead of two: the warp and
-// sample-gradient phases wait on gather latency, which only other resident waves can hide, and a barrier of
-// one workgroup (4 waves) no longer idles half the CU.  Measured (profiles/r02/bwd_variants.txt): 64-wide
-// tile / 4 waves / 2 per SIMD 0.378 ms; 64-wide / 8 waves / 4 per SIMD 0.401 ms (8-wave barriers eat the
-// occupancy gain); this form - see the table there.  The halo'd warp region grows from 1.33x to 1.41x of the
-// tile.  2-pixel windows are 8-byte aligned ds_read_b64.
+// Fused backward: the same LDS images and phases as the round-1 wide form on a 32x16-pixel tile, 256 threads = 4 waves, a
+// 2-pixel strip per thread (round 2: 128 VGPRs and 38-41 KB of LDS, so FOUR independent workgroups = 16 waves per CU are
+// resident: the warp and sample-gradient phases wait on gather latency, which only other resident waves can hide, and a
+// barrier of one workgroup no longer idles half the CU; profiles/r02/bwd_variants.txt).  The halo'd warp region is 1.41x
+// the tile.  2-pixel windows are 8-byte aligned ds_read_b64.
 // ------------------------------------------------------------------------------------------
 constexpr int TW2 = 32;              // backward tile width (pixels); height stays TH
 constexpr int NT2 = 256;
@@ -1049,9 +1025,7 @@ constexpr int SPR2 = TW2 / PPT2;     // 16 strips per tile row
 constexpr int BS2 = TW2 + 4;         // 36: row stride of the x / y regions (TH+4) x (TW2+4)
 constexpr int BW2 = TW2 + 4;
 constexpr int BPLANE2 = BH * BS2;
-constexpr int CS2 = TW2 + 4;         // 36: row stride of the coefficient region (TH+2) x (TW2+2)
-constexpr int CW2 = TW2 + 2;
-constexpr int CPLANE2 = CH * CS2;
+constexpr int CW2 = TW2 + 2;         // the coefficient region is (TH+2) x (TW2+2) loss pixels: the tile and a one-pixel ring
 
 __device__ __forceinline__ TileCoord decode_tile2(int t, int W) {
   const int tiles_x = (W + TW2 - 1) / TW2;
@@ -1085,366 +1059,16 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 #ifndef BBD_BWD2_WARP_BATCH
 #define BBD_BWD2_WARP_BATCH 3
 #endif
-template <bool PLANE>
-__global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd2_kernel(BwdArgs a) {
-  // warped (x) and target (y) texels of a staged cell sit side by side - planes of (x, y) pairs: every window read of
-  // the coefficient phase is one 8-byte load that lands in a register pair, and its five running sums become three
-  // packed operations per tap ((sx, sy) += (x, y); (sxx, syy) += (x, y)^2) plus the scalar sxy
-  __shared__ __attribute__((aligned(16))) float s_xybuf[3 * 2 * BPLANE2 + 16];
-  __shared__ __attribute__((aligned(16))) float s_cf[3][CPLANE2];
-  __shared__ uint16_t s_list[CH * CW2];
-  __shared__ __attribute__((aligned(16))) float s_dv[6][TH * TW2];
-  __shared__ float s_red[NT2 / 64][12];
-  __shared__ unsigned s_present[NT2 / 64];
-  __shared__ int s_count;
-  float (*s_xy)[2 * BPLANE2] = reinterpret_cast<float (*)[2 * BPLANE2]>(s_xybuf);      // [ch][2 * cell + {0: x, 1: y}]
-  const BbdDims dm = a.dm;
-  const int H = dm.H, W = dm.W, hw = H * W;
-  int b, s;
-  TileCoord tc;
-  if (a.work != nullptr) {
-    const WorkItem it = load_work_item(a.work);
-    b = it.b; s = it.s;
-    tc.tile = it.tile; tc.tx0 = it.tx0; tc.ty0 = it.ty0;
-  } else {
-    int bid = a.remap ? xcd_work_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    b = bid / (a.S * a.ntiles);
-    bid -= b * a.S * a.ntiles;
-    s = bid / a.ntiles;
-    tc = decode_tile2(bid - s * a.ntiles, W);
-  }
-  const size_t img = (size_t)3 * hw;
-  const size_t sb = (size_t)s * a.B + b;
-  const DepthSrc dsrc = depth_source(a.depth, a.ds, s, b, sb, H, W);
-  const uint8_t* am = a.argmin + sb * hw;
-  const float g = uniform_load(a.gscale + s);
-  const float w_ssim = a.no_ssim ? 0.0f : g * 0.85f / 3.0f;
-  const float w_l1 = a.no_ssim ? g / 3.0f : g * 0.15f / 3.0f;
 
-  BBD_STAMP_RT(30);
-  BBD_STAMP(0);
-  // setup: issue every global load first, then the LDS work that does not depend on them
-  const int nc = uniform_load(a.ncand + b);
-  constexpr int NP_CELLS = (CH * CW2 + NT2 - 1) / NT2;
-  static_assert(NP_CELLS <= 4, "arg-min ids of the loss pixels are packed four to a word");
-  int pcell[NP_CELLS];
-  unsigned pargw = 0u;                 // byte k = arg-min id of loss pixel k (255 = outside the image)
-#pragma unroll
-  for (int k = 0; k < NP_CELLS; ++k) {
-    const int i = k * NT2 + (int)threadIdx.x;
-    const int r = i / CW2, c = i - r * CW2;
-    const int py = tc.ty0 + r - 1, px = tc.tx0 + c - 1;
-    const bool in = i < CH * CW2 && py >= 0 && py < H && px >= 0 && px < W;
-    pcell[k] = r * CS2 + c;
-    pargw |= (in ? (unsigned)am[py * W + px] : 255u) << (8 * k);
-  }
-#define BBD_PARG(k) ((pargw >> (8 * (k))) & 0xffu)
-  BBD_STAMP(21);
-  typedef Cells<BH, BW2, BS2, 2, NT2> CellsB;
-  CellsB cl;
-  cl.init(H, W, tc.tx0, tc.ty0);
-  float tcell[CellsB::N][3];
-  {
-    const float* tg = a.target + (size_t)b * img;
-#pragma unroll
-    for (int k = 0; k < CellsB::N; ++k) {
-      const int px = cl.pix(k, W);
-      tcell[k][0] = tg[px];
-      tcell[k][1] = tg[px + hw];
-      tcell[k][2] = tg[px + 2 * hw];
-    }
-  }
-  const int ly = (int)threadIdx.x / SPR2, lx0 = ((int)threadIdx.x % SPR2) * PPT2;
-  const int qy = tc.ty0 + ly, qx0 = tc.tx0 + lx0;
-  const bool q_row_ok = qy < H;
-  const bool q_vec_ok = (qx0 + PPT2 <= W) && ((W & 1) == 0);
-  // depth of the halo'd cells (only needed to project them) and of the strip's own pixels: one batch of loads (pixels
-  // beyond the image read a clamped address, their value is never used)
-  DepthFetch<CellsB::N + PPT2, PLANE> dfetch;
-#pragma unroll
-  for (int k = 0; k < CellsB::N; ++k) dfetch.issue(dsrc, k, cl.xy[k] >> 16, cl.xy[k] & 0xffff, H, W);
-#pragma unroll
-  for (int j = 0; j < PPT2; ++j) dfetch.issue(dsrc, CellsB::N + j, min(qy, H - 1), min(qx0 + j, W - 1), H, W);
-
-  BBD_STAMP(22);
-  unsigned qargw = 0u;                 // byte j = arg-min id of own pixel j
-#pragma unroll
-  for (int j = 0; j < PPT2; ++j) qargw |= ((q_row_ok && qx0 + j < W) ? (unsigned)am[qy * W + qx0 + j] : 255u) << (8 * j);
-  const bool interior = tc.tx0 >= 2 && tc.tx0 + TW2 + 2 <= W && tc.ty0 >= 2 && tc.ty0 + TH + 2 <= H;
-  float gdepth[PPT2] = {0.0f, 0.0f};
-
-  BBD_STAMP(23);
-  if (threadIdx.x == 0) s_count = 0;
-  for (int i = threadIdx.x; i < 3 * CPLANE2 / 4; i += NT2)
-    reinterpret_cast<float4*>(&s_cf[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  BBD_STAMP(24);
-  {
-    // which candidates won a pixel in or next to this tile: OR over the wave on the DPP crossbar, one word per wave - no
-    // LDS atomic and no barrier of its own (round 3 zeroed a shared word, synchronised, then OR-ed into it atomically)
-    unsigned mine = 0u;
-#pragma unroll
-    for (int k = 0; k < NP_CELLS; ++k)
-      if (BBD_PARG(k) != 255u) mine |= 1u << BBD_PARG(k);
-    const unsigned wave_mine = wave_or63(mine);
-    if ((threadIdx.x & 63) == 63) s_present[threadIdx.x >> 6] = wave_mine;
-  }
-  BBD_STAMP(26);
-#pragma unroll
-  for (int k = 0; k < CellsB::N; ++k) {
-    s_xy[0][2 * cl.lds[k] + 1] = tcell[k][0];
-    s_xy[1][2 * cl.lds[k] + 1] = tcell[k][1];
-    s_xy[2][2 * cl.lds[k] + 1] = tcell[k][2];
-  }
-  float dcell[CellsB::N], qdepth[PPT2];
-#pragma unroll
-  for (int k = 0; k < CellsB::N; ++k) dcell[k] = dfetch.finish(dsrc, k, H, W);
-#pragma unroll
-  for (int j = 0; j < PPT2; ++j) qdepth[j] = (q_row_ok && qx0 + j < W) ? dfetch.finish(dsrc, CellsB::N + j, H, W) : 1.0f;
-  BBD_STAMP(1);
-  __syncthreads();
-  BBD_STAMP(2);
-  unsigned present = 0u;
-#pragma unroll
-  for (int w8 = 0; w8 < NT2 / 64; ++w8) present |= s_present[w8];
-
-  int prev = -1;
-  CandOrder order;                       // a frame's true-pose and error-induced warps back to back (cache locality)
-  order.init(nc);
-  while (order.more()) {
-    bbd_cand_t cd;
-    const int c = order.next(a.cand + b * BBD_MAX_CAND, &cd);
-    if ((cd.kind & KIND_MASK) != BBD_KIND_WARP) continue;
-    float* gp_out = a.grad_proj + (((size_t)s * a.NP + cd.pose) * a.ntiles + tc.tile) * 12;
-    if (!((present >> c) & 1u)) {
-      if (threadIdx.x < 12) gp_out[threadIdx.x] = 0.0f;
-      continue;
-    }
-    const float* src = a.frames.base[cd.slot] + (size_t)cd.row * img;
-    float pj[21];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
-
-    // ---- phase W; the winners' list of this candidate and the clearing of the previous one's coefficient entries are
-    // LDS work that does not depend on the warp: done while the first batch of gathers is in flight
-    const int prev_c = prev;
-    auto lists = [&]() {
-      if (!a.no_ssim) {
-#pragma unroll
-        for (int k = 0; k < NP_CELLS; ++k) {
-          if ((int)BBD_PARG(k) == prev_c) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) s_cf[pl][pcell[k]] = 0.0f;
-          }
-          if (BBD_PARG(k) == (unsigned)c) s_list[atomicAdd(&s_count, 1)] = (uint16_t)pcell[k];
-        }
-      }
-    };
-    prev = c;
-    BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, TH * TW2, true, 2>(src, dcell, pj, dm, hw, cl, s_xy, nullptr,
-                                                                               s_dv, lists);
-    BBD_STAMP(5 + 8 * (c & 1));
-    __syncthreads();
-    BBD_STAMP(6 + 8 * (c & 1));
-
-    // ---- phases C/G, one colour channel at a time
-    const int nwin = a.no_ssim ? 0 : s_count;
-    float gx[3][PPT2];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      for (int idx = threadIdx.x; idx < nwin; idx += NT2) {
-        const int cell = s_list[idx];
-        const int pr = cell / CS2, pc = cell - pr * CS2;
-        v2f s1 = pk1(0.0f), s2 = pk1(0.0f);       // (sum x, sum y), (sum x^2, sum y^2)
-        float sxy = 0.0f;
-        const v2f* xyp = reinterpret_cast<const v2f*>(&s_xy[ch][0]);
-#pragma unroll
-        for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-          for (int dc = 0; dc < 3; ++dc) {
-            const v2f xy = xyp[(pr + dr) * BS2 + pc + dc];
-            s1 = s1 + xy;
-            s2 = s2 + xy * xy;
-            sxy += xy.x * xy.y;
-          }
-        float mu_y, sg_y, A, Bc, Cc;
-        bbd_ystats(s1.y, s2.y, &mu_y, &sg_y);
-        bbd_ssim_grad(s1.x, s2.x, sxy, mu_y, sg_y, &A, &Bc, &Cc);
-        s_cf[0][cell] = A * w_ssim;
-        s_cf[1][cell] = Bc * w_ssim;
-        s_cf[2][cell] = Cc * w_ssim;
-      }
-      if (ch == 0) BBD_STAMP(7 + 8 * (c & 1));
-      __syncthreads();
-      if (ch == 0) BBD_STAMP(8 + 8 * (c & 1));
-      if (ch == 0 && threadIdx.x == 0) s_count = 0;
-
-      // G: adjoint of reflect-pad + 3x3 mean at this thread's 2 texels
-      const float4 xy2 = *reinterpret_cast<const float4*>(&s_xy[ch][2 * ((ly + 2) * BS2 + lx0 + 2)]);   // (x0, y0, x1, y1)
-      const float xqv[PPT2] = {xy2.x, xy2.z}, yqv[PPT2] = {xy2.y, xy2.w};
-      float S3[3][PPT2];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int j = 0; j < PPT2; ++j) S3[pl][j] = 0.0f;
-      if (!a.no_ssim) {
-        if (interior) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            // the 3x4 window arrives as register pairs (two 8-byte reads per row): column sums on pairs
-            const v2f* p2 = reinterpret_cast<const v2f*>(s_cf[pl]) + (ly * (CS2 / 2) + (lx0 >> 1));
-            const v2f colA = (p2[0] + p2[CS2 / 2]) + p2[CS2];                  // columns 0, 1
-            const v2f colB = (p2[1] + p2[CS2 / 2 + 1]) + p2[CS2 + 1];          // columns 2, 3
-            const float mid = colA.y + colB.x;
-            S3[pl][0] = colA.x + mid;
-            S3[pl][1] = mid + colB.y;
-          }
-        } else {
-          float wy[3], wx[PPT2][3];
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int py = qy + d - 1;
-            wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
-#pragma unroll
-            for (int j = 0; j < PPT2; ++j) {
-              const int px = qx0 + j + d - 1;
-              wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
-            }
-          }
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
-            float cw[3][4];
-            load_window4<CS2>(s_cf[pl], ly, lx0, cw);
-#pragma unroll
-            for (int j = 0; j < PPT2; ++j)
-#pragma unroll
-              for (int dr = 0; dr < 3; ++dr) {
-                float r = 0.0f;
-#pragma unroll
-                for (int dc = 0; dc < 3; ++dc) r = fmaf(wx[j][dc], cw[dr][j + dc], r);
-                S3[pl][j] = fmaf(wy[dr], r, S3[pl][j]);
-              }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < PPT2; ++j) {
-        const float xq = xqv[j], yq = yqv[j];
-        float acc = (S3[0][j] + xq * S3[1][j] + yq * S3[2][j]) * (1.0f / 9.0f);
-        if (((qargw >> (8 * j)) & 0xffu) == (unsigned)c) {
-          const float df = xq - yq;
-          acc += w_l1 * (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f));
-        }
-        gx[ch][j] = (q_row_ok && qx0 + j < W) ? acc : 0.0f;
-      }
-      if (ch < 2 && !a.no_ssim) __syncthreads();
-    }
-
-    BBD_STAMP(9 + 8 * (c & 1));
-    // texel gradient -> sampling coordinates -> depth and P; the strip's two pixels as the two halves of packed
-    // registers (bbd_sample_smooth + bbd_project_grad, operation for operation: same arithmetic, half the instructions)
-    float gP[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
-    if (q_row_ok) {
-      // (a fresh scalar load instead of 21 SGPRs held across the C / G phases)
-#pragma unroll
-      for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);
-      v2f dxy[6];
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) {
-        const float2 q = *reinterpret_cast<const float2*>(&s_dv[pl][ly * TW2 + lx0]);
-        dxy[pl] = pk2(q.x, q.y);
-      }
-      const v2f g0 = pk2(gx[0][0], gx[0][1]), g1 = pk2(gx[1][0], gx[1][1]), g2 = pk2(gx[2][0], gx[2][1]);   // (0 beyond W)
-      const v2f gix = g0 * dxy[0] + g1 * dxy[1] + g2 * dxy[2];
-      const v2f giy = g0 * dxy[3] + g1 * dxy[4] + g2 * dxy[5];
-      const float* iK = pj + 12;
-      const v2f fx = pk2((float)qx0, (float)(qx0 + 1)), fy = pk1((float)qy), dep = pk2(qdepth[0], qdepth[1]);
-      const v2f cx = pk_fma(pk1(iK[1]), fy, pk1(iK[0]) * fx) + pk1(iK[2]);
-      const v2f cy = pk_fma(pk1(iK[4]), fy, pk1(iK[3]) * fx) + pk1(iK[5]);
-      const v2f cz = pk_fma(pk1(iK[7]), fy, pk1(iK[6]) * fx) + pk1(iK[8]);
-      const v2f X = dep * cx, Y = dep * cy, Z = dep * cz;
-      const v2f qx_ = pk_fma(pk1(pj[2]), Z, pk_fma(pk1(pj[1]), Y, pk1(pj[0]) * X)) + pk1(pj[3]);
-      const v2f qy_ = pk_fma(pk1(pj[6]), Z, pk_fma(pk1(pj[5]), Y, pk1(pj[4]) * X)) + pk1(pj[7]);
-      const v2f zi = pk_fma(pk1(pj[10]), Z, pk_fma(pk1(pj[9]), Y, pk1(pj[8]) * X)) + pk1(pj[11] + BBD_EPS);
-      v2f r0;
-      r0.x = __builtin_amdgcn_rcpf(zi.x);
-      r0.y = __builtin_amdgcn_rcpf(zi.y);
-      const v2f rz = pk_fma(pk_fma(-zi, r0, pk1(1.0f)), r0, r0);
-      const v2f u = qx_ * rz, v = qy_ * rz;
-      const v2f gq0 = gix * rz, gq1 = giy * rz;
-      const v2f gq2 = -(gix * u + giy * v) * rz;
-      const v2f gX = gq0 * pk1(pj[0]) + gq1 * pk1(pj[4]) + gq2 * pk1(pj[8]);
-      const v2f gY = gq0 * pk1(pj[1]) + gq1 * pk1(pj[5]) + gq2 * pk1(pj[9]);
-      const v2f gZ = gq0 * pk1(pj[2]) + gq1 * pk1(pj[6]) + gq2 * pk1(pj[10]);
-      const v2f gd = gX * cx + gY * cy + gZ * cz;
-      gdepth[0] += gd.x;
-      gdepth[1] += gd.y;
-      const v2f gq[3] = {gq0, gq1, gq2};
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const v2f a = gq[r] * X, b2 = gq[r] * Y, c2 = gq[r] * Z;
-        gP[4 * r + 0] = a.x + a.y;
-        gP[4 * r + 1] = b2.x + b2.y;
-        gP[4 * r + 2] = c2.x + c2.y;
-        gP[4 * r + 3] = gq[r].x + gq[r].y;
-      }
-    }
-    if (cd.kind & FLAG_NO_POSE_GRAD) {
-      if (threadIdx.x < 12) gp_out[threadIdx.x] = 0.0f;
-    } else {
-      float tot[3];
-      wave_sum12(gP, tot);
-      if ((threadIdx.x & 15) == 15) {
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_red[threadIdx.x >> 6][wave_sum12_index(k, lane)] = tot[k];
-      }
-    }
-    BBD_STAMP(10 + 8 * (c & 1));
-    __syncthreads();
-    BBD_STAMP(11 + 8 * (c & 1));
-    if (!(cd.kind & FLAG_NO_POSE_GRAD) && threadIdx.x < 12) {
-      float t = s_red[0][threadIdx.x];
-#pragma unroll
-      for (int w8 = 1; w8 < NT2 / 64; ++w8) t += s_red[w8][threadIdx.x];
-      gp_out[threadIdx.x] = t;
-    }
-  }
-
-  if (a.ds.grad_wrt_disp) {
-    // disparity mode: hand back d loss / d (up-sampled disparity) = d loss / d depth * (-span * depth^2); the
-    // bilinear adjoint onto the low-resolution map is bbd_disp_upsample_adjoint (one launch for all scales)
-#pragma unroll
-    for (int j = 0; j < PPT2; ++j) gdepth[j] *= -dsrc.span * qdepth[j] * qdepth[j];
-  }
-  if (q_row_ok) {
-    float* o = a.grad_depth + sb * hw + qy * W + qx0;
-    if (q_vec_ok) {
-      *reinterpret_cast<float2*>(o) = make_float2(gdepth[0], gdepth[1]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPT2; ++j)
-        if (qx0 + j < W) o[j] = gdepth[j];
-    }
-  }
-  BBD_STAMP(20);
-  BBD_STAMP_RT(31);
-  BBD_STAMP_VAL(29, __builtin_popcount(present));
-#undef BBD_PARG
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused backward, nine-plane form (round 4; launches with MANY candidates per sample - the boosted recipe).  Same phases and
-// arithmetic as warp_ssim_min_bwd2_kernel above, three differences: (1) the coefficient planes of all three colour channels sit
-// in LDS at once, so a candidate needs 3 barriers instead of 7; (2) the winners' SSIM partials are ONE walk over (winner,
-// channel) items: a candidate of the boosted recipe wins a twelfth of a tile, and a walk per channel kept a fifth of the
-// lanes busy for three rounds; (3) to keep four workgroups per CU in LDS (40 816 B) the six d warped / d (ix, iy) planes
-// left LDS: a thread's first two staged cells are its own strip (CellsBwd) and their tap differences stay in its registers.
-// For few candidates (MD2: two warps that win a third of the pixels each) it is 1 % slower than the per-channel form
-// (profiles/r04/setup_variants.txt), so launch_fused_bwd picks by candidate count.
-// ------------------------------------------------------------------------------------------
+// Round 4, the nine-plane form (the only one since the end of that round; the per-channel form of rounds 2-4 is kept as
+// tools/experiments/per_channel_backward.hip.txt): (1) the coefficient planes of all three colour channels sit in LDS at
+// once, so a candidate needs 3 barriers instead of 7; (2) the winners' SSIM partials are ONE walk over (winner, channel)
+// items - a candidate of the boosted recipe wins a twelfth of a tile, and a walk per channel kept a fifth of the lanes busy
+// for three rounds; (3) to keep four workgroups per CU in LDS (40 816 B) the six d warped / d (ix, iy) planes left LDS: a
+// thread's first two staged cells are its own strip (CellsBwd) and their tap differences stay in its registers.  In the
+// training step: MD2 backward -3.5 %, boosted m = 7 -12 %, epoch-15 draw -11 % (profiles/r04/setup_variants.txt).  125
+// VGPRs, no spill - the first build of this form held the border tiles' reflection multiplicities across the channel loop
+// and spilled 10 registers, which hid its gain for MD2.
 constexpr int CS9 = TW2 + 2;         // 34: row stride of the coefficient region - exactly its width
 constexpr int CPLANE9 = CH * CS9;
 
@@ -1475,7 +1099,6 @@ struct CellsBwd {
   }
   __device__ __forceinline__ int pix(int k, int W) const { return (xy[k] >> 16) * W + (xy[k] & 0xffff); }
   __device__ __forceinline__ bool own(int) const { return false; }          // (forward-only uses of the shared warp code)
-  __device__ __forceinline__ int own_index(int) const { return 0; }
 };
 
 template <bool PLANE>
@@ -1634,8 +1257,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
     prev = c;
     float dvr[PPT2][6];
     BBD_STAMP(4 + 8 * (c & 1));
-    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, TH * TW2, true, 2, decltype(lists), PPT2>(
-        src, dcell, pj, dm, hw, cl, s_xy, nullptr, static_cast<float (*)[TH * TW2]>(nullptr), lists, dvr);
+    warp_into_lds<BBD_BWD2_WARP_BATCH, CellsB, 2 * BPLANE2, true, 2, decltype(lists), PPT2>(src, dcell, pj, dm, hw, cl, s_xy,
+                                                                                            nullptr, lists, dvr);
     BBD_STAMP(5 + 8 * (c & 1));
     __syncthreads();
     BBD_STAMP(6 + 8 * (c & 1));
@@ -1674,19 +1297,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
 
     // ---- phase G: adjoint of reflect-pad + 3x3 mean at this thread's 2 texels, channel by channel (no barrier between)
     float gx[3][PPT2];
-    float wy[3], wx[PPT2][3];
-    if (!interior) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const int py = qy + d - 1;
-        wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
-#pragma unroll
-        for (int j = 0; j < PPT2; ++j) {
-          const int px = qx0 + j + d - 1;
-          wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
-        }
-      }
-    }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float4 xy2 = *reinterpret_cast<const float4*>(&s_xy[ch][2 * ((ly + 2) * BS2 + lx0 + 2)]);   // (x0, y0, x1, y1)
@@ -1709,6 +1319,17 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
             S3[pl][1] = mid + colB.y;
           }
         } else {
+          float wy[3], wx[PPT2][3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int py = qy + d - 1;
+            wy[d] = (py >= 0 && py < H) ? (float)bbd_reflect_mult(qy, py, H) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < PPT2; ++j) {
+              const int px = qx0 + j + d - 1;
+              wx[j][d] = (px >= 0 && px < W) ? (float)bbd_reflect_mult(qx0 + j, px, W) : 0.0f;
+            }
+          }
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
             float cw[3][4];
@@ -2785,18 +2406,10 @@ static int launch_fused_bwd(const void* const* frames, const float* target, cons
   a.work = work;
   // (a sparse-item form of this kernel - per-candidate winner lists, scatter instead of the dense phases - was built and
   // measured slower inside the training step: profiles/r03/bwd3_*.txt, tools/experiments/sparse_item_backward.hip.txt)
-  // many candidates per sample (more than 4 pose rows each: the boosted recipe) -> the nine-plane form; BBD_BWD_FORM=0 / 1 forces
-  static const int forced = [] { const char* e = getenv("BBD_BWD_FORM"); return e == nullptr ? -1 : (e[0] - '0'); }();
-  const bool nine = forced >= 0 ? forced == 1 : NP > 4 * B;
   const dim3 grid((unsigned)(S * B * a.ntiles));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (nine) {
-    if (depth != nullptr) hipLaunchKernelGGL(warp_ssim_min_bwd9_kernel<true>, grid, dim3(NT2), 0, st, a);
-    else hipLaunchKernelGGL(warp_ssim_min_bwd9_kernel<false>, grid, dim3(NT2), 0, st, a);
-  } else {
-    if (depth != nullptr) hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<true>, grid, dim3(NT2), 0, st, a);
-    else hipLaunchKernelGGL(warp_ssim_min_bwd2_kernel<false>, grid, dim3(NT2), 0, st, a);
-  }
+  if (depth != nullptr) hipLaunchKernelGGL(warp_ssim_min_bwd9_kernel<true>, grid, dim3(NT2), 0, st, a);
+  else hipLaunchKernelGGL(warp_ssim_min_bwd9_kernel<false>, grid, dim3(NT2), 0, st, a);
   return launch_status();
 }
 

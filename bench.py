@@ -317,8 +317,6 @@ def kernel_table(timer, plan, S, config, batch):
             suffix = ""
             if alias(k).endswith("_fwd") and plan.NP > 4 * plan.B:
                 suffix = "_held" if S * plan.B * ((H + 15) // 16) * ((W + 63) // 64) >= 4096 else "_many"
-            elif alias(k).endswith("_bwd") and plan.NP > 4 * plan.B:
-                suffix = "_many"          # the nine-plane form (launch_fused_bwd)
             mix = cc["isa_mix"].get(alias(k) + suffix)
             if "valu_wave_instructions" in e and mix:
                 # vector-issue bound (finding 14): the launch's counter-measured vector instructions (a

@@ -314,22 +314,6 @@ def test_every_forward_form_is_bit_exact(form):
     assert out.returncode == 0 and " passed" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
-@pytest.mark.parametrize("form", [0, 1])
-def test_every_backward_form_meets_the_gradient_bars(form):
-    """The fused backward has two forms chosen by candidate count (per-channel coefficient planes; nine planes with one walk
-    over (winner, channel) items).  Each is valid for every input: the golden cases' gradients (1e-4 of the maximum, no texel
-    above it) and the full-size live-oracle runs must hold under each (BBD_BWD_FORM forces one; read once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BBD_BWD_FORM=str(form))
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
-                          "-k", "fused_path_matches_reference_bit_for_bit or full_resolution_against_oracle or full_size_properties"],
-                         env=env, cwd=root, capture_output=True, text=True, timeout=1500)
-    assert out.returncode == 0 and " passed" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
-
-
 def test_multi_scale_smoothness_launch_equals_the_single_scale_launches(backend):
     """bbd_smooth_loss_multi_* (all scales of a step in one launch pair each way) vs bbd_smooth_loss_* per scale: same
     kernels, same reduction order - values and gradients bit for bit."""

@@ -14,10 +14,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "baseboostdepth_amd", "csrc", "bbd_kernels.hip")
 # (the training path's instantiations: forward fed with disparities = PLANE false, backward with the forward's depth = true)
-#  forward: three forms by launch shape (fused_fwd_form); backward: two by candidate count ("_many" = the nine-plane form)
+#  forward: three forms by launch shape (fused_fwd_form)
 KERNELS = {"bbd_warp_ssim_min_fwd": "warp_ssim_min_fwd_kernelILb0ELi1", "bbd_warp_ssim_min_fwd_many": "warp_ssim_min_fwd_kernelILb0ELi0",
            "bbd_warp_ssim_min_fwd_held": "warp_ssim_min_fwd_kernelILb0ELi2",
-           "bbd_warp_ssim_min_bwd": "warp_ssim_min_bwd2_kernelILb1", "bbd_warp_ssim_min_bwd_many": "warp_ssim_min_bwd9_kernelILb1",
+           "bbd_warp_ssim_min_bwd": "warp_ssim_min_bwd9_kernelILb1",
            "bbd_identity_loss_fwd": "identity_loss_grouped_kernel"}
 # Issue cost classes measured by tools/microbench/valu_rate.hip (profiles/r03/valu_rate.txt), cycles a wave64 instruction
 # occupies a SIMD when at least two waves share it:

@@ -14,7 +14,7 @@ from isa_mix import issue_class, CYCLES, DORMANT  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 kern = {"fwd": "warp_ssim_min_fwd_kernelILb0ELi1", "fwd_many": "warp_ssim_min_fwd_kernelILb0ELi0", "fwd_held": "warp_ssim_min_fwd_kernelILb0ELi2",
-        "bwd": "warp_ssim_min_bwd2_kernelILb1", "bwd_many": "warp_ssim_min_bwd9_kernelILb1"}[which]
+        "bwd": "warp_ssim_min_bwd9_kernelILb1"}[which]
 src = os.environ.get("BBD_VARIANT_SRC", os.path.join(ROOT, "baseboostdepth_amd", "csrc", "bbd_kernels.hip"))
 asm = "/tmp/bbd_isa_phases.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math",

@@ -24,7 +24,7 @@ for spec in "$@"; do
 import re, sys
 t = open("build_variants/k_%s.log" % sys.argv[1]).read()
 out = []
-for kern in ("warp_ssim_min_fwd_kernelILb0ELi1", "warp_ssim_min_fwd_kernelILb0ELi0", "warp_ssim_min_fwd_kernelILb0ELi2", "warp_ssim_min_bwd2_kernelILb1", "warp_ssim_min_bwd9_kernelILb1"):
+for kern in ("warp_ssim_min_fwd_kernelILb0ELi1", "warp_ssim_min_fwd_kernelILb0ELi0", "warp_ssim_min_fwd_kernelILb0ELi2", "warp_ssim_min_bwd9_kernelILb1"):
     m = re.search(r"Function Name: \S*%s\S*.*?VGPRs: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+).*?LDS Size \[bytes/block\]: (\d+)" % kern, t, re.S)
     if m:
         out.append((kern, "%s: %s VGPR, spills s%s v%s, LDS %s" % (kern.replace("warp_ssim_min_", ""), *m.groups())))
