@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 3): patches the round-3 source of the fused kernels (`git show 6e78be1:baseboostdepth_amd/csrc/bbd_kernels.hip`);
+# the patterns it replaces no longer exist in the shipped source (round 4: nine-plane backward, forward forms).
 # Forward kernel at 4 waves per SIMD (experiment on a patched copy): the warped tile single-buffered (29 KB of LDS per
 # workgroup instead of 44, a second barrier per candidate) and the 128-VGPR budget.
 #   usage: tools/experiments/forward_four_waves_ab.sh      (repo root, GPU box)

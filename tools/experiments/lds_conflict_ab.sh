@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 3): patches the round-3 source of the fused kernels (`git show 6e78be1:baseboostdepth_amd/csrc/bbd_kernels.hip`);
+# the patterns it replaces no longer exist in the shipped source (round 4: nine-plane backward, forward forms).
 # Which LDS instruction of the fused backward owns its bank-conflict cycles?  
 # The shipped source carries no ablation switches: this script patches COPIES of bbd_kernels.hip (one phase's LDS
 # traffic removed or re-shaped per variant; results are numerically meaningless, only the counters matter), builds

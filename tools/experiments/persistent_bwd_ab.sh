@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 3): patches the round-3 source of the fused kernels (`git show 6e78be1:baseboostdepth_amd/csrc/bbd_kernels.hip`);
+# the patterns it replaces no longer exist in the shipped source (round 4: nine-plane backward, forward forms).
 # Persistent workgroups for the fused backward, as an experiment on a patched COPY of the source:
 # the launch has 4 workgroups per CU (1 024) and every workgroup walks work items blockIdx.x, + gridDim.x, ... instead of
 # one workgroup per (sample, scale, tile).  No prefetch of the next item's set-up (that needs ~15 more VGPRs than the
