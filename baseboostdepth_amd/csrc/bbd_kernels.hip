@@ -2252,12 +2252,20 @@ int fill_frames(const void* const* frames, FramePtrs* out) {
 // (always: in-step fabric traffic 124 -> 65 MB and -6 % time for MD2, profiles/r04/work_order_ab.txt) and the fused launches
 // when the caller passes no work-item table and there is one scale (round 3: profiles/r03/xcd_remap_ab.txt; with several
 // scales a range split hands whole scales of different cost to different XCDs).  BBD_XCD_REMAP=0 / 1 forces it.
+// (Both knobs are read only under BBD_EXPERIMENT=1 - the A/B scripts under tools/ and the test that forces every forward
+// form set it: a stray variable in a user's environment cannot put the library into a configuration no test covers.)
+int experiment_knob(const char* name) {
+  const char* on = getenv("BBD_EXPERIMENT");
+  if (on == nullptr || on[0] != '1') return -1;
+  const char* e = getenv(name);
+  return e == nullptr ? -1 : (e[0] - '0');
+}
 int xcd_remap_enabled(int S) {
-  static const int forced = [] { const char* e = getenv("BBD_XCD_REMAP"); return e == nullptr ? -1 : (e[0] - '0'); }();
+  static const int forced = experiment_knob("BBD_XCD_REMAP");
   return forced >= 0 ? forced : (S == 1);
 }
 int fused_fwd_form(int S, int B, int NP, int ntiles) {
-  static const int forced = [] { const char* e = getenv("BBD_FWD_FORM"); return e == nullptr ? -1 : (e[0] - '0'); }();
+  static const int forced = experiment_knob("BBD_FWD_FORM");
   if (forced >= 0 && forced <= 2) return forced;
   if (NP <= 4 * B) return FWD_RESTAT;
   return (long)S * B * ntiles >= 4 * 1024 ? FWD_HELD : FWD_DOUBLE;
@@ -2288,6 +2296,16 @@ int bbd_fused_work_items(int B, int S, int H, int W, int backward, const int32_t
   if (ntiles >= (1 << (32 - WORK_B_BITS - WORK_S_BITS)) || W > 0xffff || H > 0xffff) return BBD_E_BADARG;
   const int n = B * S * ntiles, q = ntiles >> 3, r = ntiles & 7, bs = B * S;
   const int head = bs * r * (q + 1);            // the first r slabs hold q + 1 tiles, the others q
+  if (sample_order != nullptr) {
+    // a permutation of 0..B-1, nothing less: a repeated entry would run one sample's tiles twice and leave another's
+    // outputs (allocated uninitialised by the caller) untouched
+    uint64_t seen[(1 << WORK_B_BITS) / 64] = {0};
+    for (int k = 0; k < B; ++k) {
+      const int b = sample_order[k];
+      if (b < 0 || b >= B || ((seen[b >> 6] >> (b & 63)) & 1)) return BBD_E_BADARG;
+      seen[b >> 6] |= uint64_t(1) << (b & 63);
+    }
+  }
   for (int i = 0; i < n; ++i) {
     // hardware block i runs on XCD i & 7 (round-robin dispatch); XCD x walks the contiguous range [x n / 8, (x + 1) n / 8)
     // of the slab-major virtual order v: slab -> sample (caller's order) -> scale -> tile of the slab

@@ -21,6 +21,7 @@ import torch
 from PIL import Image, ImageFile
 
 from . import imageops
+from .plan import canonical_permutation
 
 ImageFile.LOAD_TRUNCATED_IMAGES = True          # mono_dataset.py:3
 STEREO = "s"
@@ -180,8 +181,11 @@ class DeviceCollate:
     `("color", 0, s)`.  Rows follow the reference's stacking order: the items that have the key, in batch
     order."""
 
-    def __init__(self, height, width, scales, device, backend=None, ring=3, pack_threads=8):
+    def __init__(self, height, width, scales, device, backend=None, ring=3, pack_threads=8, canonical=True):
         self.height, self.width, self.scales = height, width, list(scales)
+        # training batches are stacked in `plan.canonical_permutation` order (largest frame offset first): the loader's
+        # order is a random shuffle anyway, and the trainer then meets far fewer distinct batch signatures
+        self.canonical = bool(canonical)
         self.device = torch.device(device)
         self.pipe = imageops.ImagePipeline(self.device, backend)
         self._ring, self._next = [None] * ring, 0
@@ -208,6 +212,9 @@ class DeviceCollate:
         train = "K" in batch[0]
         # ---- host: which keys exist, and which row each (item, frame) owns (trainer.py:867-886)
         max_frames = [int(torch.max(item["frames"]).item()) for item in batch]
+        if train and self.canonical:
+            order = canonical_permutation(max_frames)
+            batch, max_frames = [batch[i] for i in order], [max_frames[i] for i in order]
         out = {}
         if train:
             out["ordering"] = [[0, STEREO] if m == 0 else [0, m, -m] for m in max_frames]
@@ -223,7 +230,7 @@ class DeviceCollate:
         # ---- one upload of all decoded frames (packed into a recycled pinned buffer by the pack pool)
         entries = [(b, f) for b, item in enumerate(batch) for f in item["images"] if f in frame_ids]
         entries.sort(key=lambda e: e[1] != 0)           # target frames first: the pyramid reads rows [0, B)
-        ring = batch[0].get("_ring")
+        ring = next((item["_ring"] for item in batch if "_ring" in item), None)
         if ring is not None:
             # frames already sit in a shared, host-registered ring slot (written there by the worker process):
             # one DMA straight from it, no staging copy

@@ -17,6 +17,14 @@ from .plan import frame_slot
 
 
 # BBD_FUSED_NN=0 sends the encoder / decoder glue (pad, max-pool) back to the stock ATen kernels (A/B runs)
+def _experiment(name, default):
+    """Experiment knobs of the A/B tooling (tools/*.sh) are read only under BBD_EXPERIMENT=1: a stray variable in a
+    user's environment cannot put the shipped library into a configuration no test covers."""
+    if os.environ.get("BBD_EXPERIMENT") != "1":
+        return default
+    return os.environ.get(name, default)
+
+
 FUSED_NN = os.environ.get("BBD_FUSED_NN", "1") != "0"
 FUSED_TOKEN_GLUE = os.environ.get("BBD_FUSED_TOKEN_GLUE", "1") != "0"   # MonoViT: residual + DropPath + LayerNorm passes
 
@@ -60,6 +68,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.get_lib()
         self.timer = None
+        self._shared_work = {}
 
     def num_tiles(self, H, W):
         return self.lib.num_tiles(H, W)
@@ -75,18 +84,26 @@ class HipBackend:
 
     def fused_work_items(self, plan, S, H, W, backward, device):
         """Device table [S*B*ntiles, 2] of bbd_fused_work_items (slab order per XCD, the plan's samples with the most
-        candidates first), built once per (plan, S, H, W, direction) and cached on the plan's device tables."""
-        if os.environ.get("BBD_WORK_TABLE", "1") == "0":      # A/B switch: grid order, decoded in the kernel
+        candidates first).  Batch order - every batch whose samples arrive sorted by candidate count, `Trainer`'s
+        canonical order - is ONE table per launch shape, uploaded once and shared by all plans; any other order is part
+        of the step's table upload (`steptables.StepTables`) or, for callers without one, a single asynchronous upload."""
+        if _experiment("BBD_WORK_TABLE", "1") == "0":      # A/B switch: grid order, decoded in the kernel
             return None
-        tb = plan.tables(device)
-        key = ("work", S, H, W, int(backward))
+        if plan.sample_order is None:
+            tb = self._shared_work
+            key = (str(device), plan.B, S, H, W, int(backward))
+        else:
+            tb = plan.tables(device)
+            key = ("work", S, H, W, int(backward))
         if key not in tb:
+            from . import steptables
             n = S * plan.B * (self.num_tiles_bwd(H, W) if backward else self.num_tiles_fwd(H, W))
-            host = torch.empty(n, 2, dtype=torch.int32)
+            host = torch.empty(n, 2, dtype=torch.int32, pin_memory=torch.device(device).type == "cuda")
             order = None if plan.sample_order is None else (ctypes.c_int32 * plan.B)(*plan.sample_order)
             try:
                 self.lib.call("bbd_fused_work_items", plan.B, S, H, W, int(backward), order, host.data_ptr())
-                tb[key] = host.to(device)
+                tb[key] = host.to(device, non_blocking=True)
+                steptables.STATS["single_uploads"] += 1
             except _lib.BbdError:
                 # outside the table's packing limits (more than 4 096 samples, 8 scales or 2^17 tiles): the launches take
                 # the grid order and decode it themselves - a speed choice only

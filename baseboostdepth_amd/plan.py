@@ -13,6 +13,7 @@ so no gathered image copies and no concatenated loss stacks are ever materialise
 import numpy as np
 import torch
 
+from .steptables import LRU
 from ._lib import MAX_CAND, MAX_FRAME_SLOTS, KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD, PAIR_SHIFT
 
 STEREO = "s"
@@ -30,6 +31,23 @@ def frame_slot(f):
 def sample_max_offsets(ordering):
     """ordering (trainer.py:870): [0,'s'] -> 0 ; [0, m, -m] -> m."""
     return [0 if o[1] == STEREO else int(o[1]) for o in ordering]
+
+
+def owners_of(ms, f):
+    """Samples (batch positions) that own a row of inputs[("color", f, 0)] (custom_collate, trainer.py:882): the
+    stereo frame is stacked for samples with m < 3, temporal frame f for samples whose own frame set reaches |f|."""
+    if f == STEREO:
+        return [b for b, m in enumerate(ms) if m < 3]
+    return [b for b, m in enumerate(ms) if m >= abs(f)]
+
+
+def canonical_permutation(ms):
+    """Order in which `Trainer.train_step` takes the samples of a batch: largest frame offset first (stable).  The
+    loss is a mean over all pixels of all samples and BatchNorm statistics are sums over the batch, so the step does not
+    depend on the order mathematically - and the loader's order is a random shuffle anyway - but the number of distinct
+    batch SIGNATURES does: 3^12 orderings of the early curriculum's m in {0,1,2} are 91 multisets, so step graphs and
+    table uploads are reused; and samples with the most candidates come first, which is the fused launches' work order."""
+    return sorted(range(len(ms)), key=lambda b: -ms[b])
 
 
 def reprojection_frames(m, trimin):
@@ -51,6 +69,7 @@ class ReprojectionPlan:
     def __init__(self, ordering, trimin, decomp):
         self.ms = sample_max_offsets(ordering)
         self.B = len(self.ms)
+        self._own = {}
         self.trimin = bool(trimin)
         self.decomp = bool(trimin and decomp)   # error-induced warps exist only on the tri-min path
         per_sample = [reprojection_frames(m, self.trimin) for m in self.ms]
@@ -133,9 +152,10 @@ class ReprojectionPlan:
     # ------------------------------------------------------------------ row bookkeeping
     def owners(self, f):
         """Samples that own a tensor row in inputs[("color", f, 0)] (custom_collate, trainer.py:882)."""
-        if f == STEREO:
-            return [b for b, m in enumerate(self.ms) if m < 3]
-        return [b for b, m in enumerate(self.ms) if m >= abs(f)]
+        own = self._own.get(f)
+        if own is None:
+            own = self._own[f] = owners_of(self.ms, f)
+        return own
 
     def source_row(self, f, b):
         return self.owners(f).index(b)
@@ -151,24 +171,24 @@ class ReprojectionPlan:
 
     # ------------------------------------------------------------------ device tables
     def tables(self, device):
+        """cand / ncand / items / ident_off / k_rows on `device` (int32 views of ONE allocation, one asynchronous
+        upload).  Inside a training step `steptables.StepTables` has already put them there together with the rest of
+        the step's tables; this is the stand-alone path (ops called without a Trainer)."""
         key = str(device)
         if key not in self._dev:
-            self._dev[key] = dict(
-                cand=torch.from_numpy(self.cand_np).to(device).contiguous(),
-                ncand=torch.from_numpy(self.ncand_np).to(device).contiguous(),
-                items=torch.tensor(self.ident_items, dtype=torch.int32).reshape(-1, 4).to(device).contiguous(),
-                ident_off=torch.tensor(self.ident_off, dtype=torch.int32).to(device).contiguous(),
-                k_rows=torch.from_numpy(self.k_rows).to(device))
+            from .steptables import upload_plan
+            self._dev[key] = upload_plan(self, device)
         return self._dev[key]
 
 
-_PLAN_CACHE = {}
+# plans by (per-sample offsets, flags).  Boosted `--rand` batches draw a new multiset of offsets almost every step
+# (18 564 of them for batch 12 from epoch 10 on): least recently used goes first, nothing is ever cleared wholesale
+_PLAN_CACHE = LRU(512)
 
 
 def get_plan(ordering, trimin, decomp):
     key = (tuple(sample_max_offsets(ordering)), bool(trimin), bool(decomp))
-    if key not in _PLAN_CACHE:
-        if len(_PLAN_CACHE) > 4096:
-            _PLAN_CACHE.clear()
-        _PLAN_CACHE[key] = ReprojectionPlan(ordering, trimin, decomp)
-    return _PLAN_CACHE[key]
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        plan = _PLAN_CACHE.put(key, ReprojectionPlan(ordering, trimin, decomp))
+    return plan

@@ -89,19 +89,52 @@ def synthetic_poses(plan, device="cpu", seed=2, pose_error=5.5):
     return out
 
 
+def draw_offsets(rnd, batch_size, epoch, trimin):
+    """Per-sample largest usable frame offsets of one batch, drawn like the reference loader does for `epoch`
+    (mono_dataset.py:87-109 over the KITTI baselines): before epoch 10 m = 1 (with tri-minimisation
+    m in {0,1,2} with the epoch-5 probabilities), from epoch 10 the epoch-15 distribution over 1..7."""
+    if epoch < 10:
+        return [rnd.choices(range(0, 3), [.062, .573, .366])[0] if trimin else 1 for _ in range(batch_size)]
+    return [rnd.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448])[0] for _ in range(batch_size)]
+
+
 def synthetic_loader(batch_size, steps, H=192, W=640, scales=(0, 1, 2, 3), device="cpu", seed=42, trimin=False,
-                     epoch=0):
+                     epoch=0, canonical=True):
     """Generator of `steps` synthetic batches shaped like the reference loader's output for `epoch`:
     before epoch 10 the largest offset is 1 (2 with tri-minimisation, stereo for small baselines), from
     epoch 10 it follows the epoch-15 offset distribution of SURVEY.md 8d (m in 1..7)."""
     import random
     rnd = random.Random(seed + 1000 * epoch)
     for it in range(steps):
-        if epoch < 10:
-            ms = [rnd.choice([0, 1, 2]) if trimin else 1 for _ in range(batch_size)]
-        else:
-            ms = [rnd.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448])[0] for _ in range(batch_size)]
+        ms = draw_offsets(rnd, batch_size, epoch, trimin)
+        if canonical:           # stacked like the device loader's collate: largest offset first (plan.canonical_permutation)
+            ms = sorted(ms, reverse=True)
         batch = synthetic_batch(ms, H, W, scales, device=device, seed=seed + it)
         batch["cutt"] = torch.tensor(0.1 + 0.04 * epoch if epoch < 10 else 0.15 * epoch - 0.9)
         batch.pop("noise")        # let the trainer draw its own identity noise, like the reference
         yield batch
+
+
+def synthetic_kitti_tree(root, drives=(("2011_09_26/2011_09_26_drive_0001_sync", 375, 1242),
+                                       ("2011_09_30/2011_09_30_drive_0020_sync", 370, 1226)), frames=24, seed=0):
+    """A small KITTI-raw-shaped directory of synthetic JPEGs (both cameras, KITTI's image sizes) and the split lines
+    with baselines that go with it (`splits/eigen_zhou/train_files_baselines.txt` rows: folder, frame, side, 'kt',
+    baseline) - what `datasets.KITTIRAWDataset` reads.  There is no dataset on the benchmark machines: the loader-fed
+    bench line and the loader tests decode these."""
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    lines = []
+    for folder, h, w in drives:
+        base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 40, 3), dtype=np.uint8)
+        big = np.array(Image.fromarray(base).resize((w + 300, h), Image.BICUBIC))
+        for cam, dx in (("image_02", 0), ("image_03", 9)):
+            d = os.path.join(root, folder, cam, "data")
+            os.makedirs(d, exist_ok=True)
+            for t in range(frames):
+                img = big[:, 5 * t + dx: 5 * t + dx + w]
+                Image.fromarray(img).save(os.path.join(d, "%010d.jpg" % t), quality=92)
+        for t in range(8, frames - 8):
+            for side in "lr":
+                lines.append("%s %d %s kt %.6f" % (folder, t, side, float(rng.uniform(0.02, 0.6))))
+    return lines

@@ -15,9 +15,9 @@ import os
 import torch
 import torch.optim as optim
 
-from . import networks, ops
+from . import networks, ops, steptables
 from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
-from .plan import STEREO, get_plan
+from .plan import STEREO, canonical_permutation, get_plan, owners_of, sample_max_offsets
 
 
 def _frame_sort_key(item):
@@ -85,7 +85,19 @@ class Trainer:
         # every parameter the optimizer steps, in group order (the gradient exchange packs exactly these)
         self.optimizer_parameters = [p for g in self.model_optimizer.param_groups for p in g["params"]]
         self._graphs = {}
-        self.max_graphs = max(1, int(os.environ.get("BBD_MAX_GRAPHS", "8")))      # (0 / negative would empty an empty LRU)
+        # step graphs share ONE memory pool (a step's graph is never replayed concurrently with another's and takes fresh
+        # static inputs), so a cached signature costs its static input copies, not a private pool: 128 of them by default
+        self.max_graphs = max(1, int(os.environ.get("BBD_MAX_GRAPHS", "128")))      # (0 / negative would empty an empty LRU)
+        self._graph_pool = None
+        # a batch signature is captured when it comes back for the (capture_after + 1)-th time; until then its steps run
+        # eagerly.  Fixed-frame-set training (MD2) has one signature: 0.  The boosted recipe (--rand) redraws every
+        # sample's frame set per item (mono_dataset.py:87-109): from epoch 10 on a batch of 12 has 18 564 possible
+        # signatures, hardly any comes back and capturing each (a warm-up step + the capture) would cost more than it
+        # saves; the early curriculum's 91 signatures all come back within a few hundred steps
+        self.capture_after = int(getattr(opt, "graph_capture_after", 2 if getattr(opt, "rand", False) else 0))
+        self._sightings = steptables.LRU(8192)
+        self._capture_checked = False
+        self.graph_stats = {"replays": 0, "captures": 0, "eager": 0}
         # data parallel + step graph: capture the bucketed RCCL all-reduces INTO the graph (one graph per step, exchange
         # overlapped with backward inside the replay) instead of two graphs around one exposed all-reduce.  Opt-in:
         # multi-rank RCCL capture cannot be exercised on the one-GPU boxes this was built on
@@ -160,11 +172,27 @@ class Trainer:
         entry = self._graphs.get(key)
         if entry is not None:
             self._graphs[key] = self._graphs.pop(key)       # most recently used last
+        # data parallel with captured collectives: the first capture is checked against the eager exchange, which takes one
+        # extra exchange - so it happens on every rank's FIRST call (the same global step), never on a later, per-rank miss
+        first_checked_capture = bool(self.grad_sync is not None and self.dp_capture and not self._capture_checked)
+        if entry is None and not first_checked_capture:
+            seen = self._sightings.get(key) or 0
+            if seen < self.capture_after:
+                # not captured (yet): an eager step issues exactly the collectives of a replaying rank (one exchange of
+                # the flat buffer in the split-graph loop, the same buckets in the same order with captured collectives)
+                self._sightings.put(key, seen + 1)
+                self.graph_stats["eager"] += 1
+                return self._eager_step(inputs)
         if entry is None:
-            # every captured signature keeps its own graph memory pool: bound the cache (boosted --rand batches
-            # draw new frame sets all the time; the least recently replayed signature goes first)
+            # bound the cache: the least recently replayed signature goes first
             while len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            pool = self._graph_pool
+            self.graph_stats["captures"] += 1
+            # a signature that has already run eagerly has warmed MIOpen / the allocator for its shapes: one warm-up step
+            warm_steps = 1 if (self._sightings.get(key) or 0) > 0 else 3
             static = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inputs.items()}
             # eager warm-up (allocator, MIOpen solutions, Adam state tensors) must not TRAIN: parameters,
             # BatchNorm buffers, the optimizer state and the step counter are restored afterwards, so the
@@ -187,7 +215,7 @@ class Trainer:
                 if hasattr(self.grad_sync, "paused"):
                     self.grad_sync.paused = True
                 try:
-                    for _ in range(3):
+                    for _ in range(warm_steps):
                         self._eager_step(dict(static))
                 finally:
                     self._local_only = False
@@ -210,7 +238,7 @@ class Trainer:
             graph, tail = torch.cuda.CUDAGraph(), None
             if self.grad_sync is None:
                 self.model_optimizer.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, pool=pool):
                     outputs, losses = self.process_batch(dict(static))
                     losses["loss"].backward()
                     self.model_optimizer.step()
@@ -220,7 +248,10 @@ class Trainer:
                 # step WITH its exchange gives the reference gradients, the state is restored, and after the first replay
                 # below the flat gradient buffer must agree (every rank takes this path on its first signature: same collectives on
                 # all of them).  BBD_DP_CAPTURE_CHECK=0 skips it.
-                check = (not self._graphs) and os.environ.get("BBD_DP_CAPTURE_CHECK", "1") != "0"
+                # (a one-shot flag, not "the cache is empty": LRU eviction empties the cache on a per-rank event, and a
+                # rank that re-ran the check alone would issue an exchange its peers do not - ADVICE r4)
+                check = first_checked_capture and os.environ.get("BBD_DP_CAPTURE_CHECK", "1") != "0"
+                self._capture_checked = True
                 if check:
                     snap2_p = [p.detach().clone() for p in params]
                     snap2_b = [b.detach().clone() for b in buffers]
@@ -243,7 +274,7 @@ class Trainer:
                 # joined to the capturing stream by the work handles' waits - the replay overlaps the exchange with
                 # the rest of backward like the eager overlapped loop does, with no host in between
                 self.flat_grads.zero()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                     outputs, losses = self.process_batch(dict(static))
                     losses["loss"].backward()
                     self.grad_sync()
@@ -255,15 +286,16 @@ class Trainer:
                 # leaving the host (an eager multi-rank loop is host-bound on a busy node).  thread_local capture
                 # mode: the process group's watchdog thread may query events while this thread captures.
                 self.flat_grads.zero()
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                     outputs, losses = self.process_batch(dict(static))
                     losses["loss"].backward()
                     self.flat_grads.pack()
                 tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(tail, capture_error_mode="thread_local"):
+                with torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
                     self.model_optimizer.step()
             entry = self._graphs[key] = (graph, tail, static, outputs, losses)
         graph, tail, static, outputs, losses = entry
+        self.graph_stats["replays"] += 1
         for k, v in inputs.items():
             if torch.is_tensor(v) and v.is_cuda:
                 static[k].copy_(v, non_blocking=True)
@@ -278,18 +310,28 @@ class Trainer:
             self._capture_reference = None
             num = float((self.flat_grads.flat - ref).abs().sum())
             den = float(ref.abs().sum()) + 1e-30
-            if not (num / den < 1e-3):
+            ok = num / den < 1e-3
+            world_ok = ok
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # the verdict is collective: a rank that raised alone would leave its peers waiting in their next all-reduce
+                flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                world_ok = bool(float(flag) > 0.5)
+            if not world_ok:
                 raise RuntimeError("step graph with captured collectives disagrees with the eager data-parallel step on its "
-                                   "first batch (relative L1 difference of the exchanged gradients %.3e): refusing to train "
-                                   "on it; use dp_capture=False (split graphs around one exposed all-reduce)" % (num / den))
+                                   "first batch (relative L1 difference of the exchanged gradients on this rank %.3e%s): "
+                                   "refusing to train on it; use dp_capture=False (split graphs around one exposed all-reduce)"
+                                   % (num / den, "" if not ok else "; another rank failed the check"))
         self.step += 1
         return outputs, losses
 
     def train_step(self, inputs):
-        """One optimisation step on a collated batch, as the body of `run_epoch` does it."""
+        """One optimisation step on a collated batch, as the body of `run_epoch` does it.  The samples are taken in
+        canonical order (`canonicalize`; `opt.canonical_order = False` keeps the caller's)."""
         if "frames" in inputs:
             self.opt.frame_ids = sorted(inputs["frames"], key=_frame_sort_key)
-        if self.use_graph and self.device.type == "cuda":
+        if self.device.type == "cuda":
             cutt = inputs.get("cutt")
             if torch.is_tensor(cutt) and cutt.is_cuda:
                 # the pose-mode threshold is part of the graph key: fetch it ONCE per batch dict (the reference's collate
@@ -298,8 +340,57 @@ class Trainer:
             for key, ipt in inputs.items():
                 if key not in ["frames", "ordering", "cutt"] and torch.is_tensor(ipt):
                     inputs[key] = ipt.to(self.device, non_blocking=True)
+        if getattr(self.opt, "canonical_order", True):
+            self.canonicalize(inputs)
+        if self.use_graph and self.device.type == "cuda":
             return self._graph_step(inputs)
         return self._eager_step(inputs)
+
+    def canonicalize(self, inputs):
+        """Reorders the samples of a collated batch IN PLACE to `plan.canonical_permutation` (largest frame offset first)
+        and returns the permutation (None: already canonical; `inputs["batch_order"][b]` = the caller's position of sample
+        b).  Every tensor is gathered by its own rows: B-row tensors by the permutation, a frame's stack
+        `("color" | "color_aug", f, s)` by where its owners (custom_collate, trainer.py:882) went.  The device loader and
+        `synthetic_loader` collate in this order already, so this costs nothing there."""
+        ordering = inputs["ordering"]
+        ms = sample_max_offsets(ordering)
+        perm = canonical_permutation(ms)
+        B = len(ms)
+        if perm == list(range(B)):
+            return None
+        new_ms = [ms[p] for p in perm]
+        lists, todo = {}, []
+        for key, t in inputs.items():
+            if not torch.is_tensor(t) or t.dim() == 0 or key in ("cutt", "to_use"):
+                continue
+            if isinstance(key, tuple) and len(key) >= 2 and key[0] in ("color", "color_aug") and key[1] != 0:
+                old_own, new_own = owners_of(ms, key[1]), owners_of(new_ms, key[1])
+                if t.shape[0] != len(old_own):
+                    continue
+                rows = tuple(old_own.index(perm[b]) for b in new_own)
+            elif t.shape[0] == B:
+                rows = tuple(perm)
+            else:
+                continue
+            if list(rows) != list(range(len(rows))):
+                lists.setdefault((rows, str(t.device)), None)
+                todo.append((key, rows))
+        # the row lists of one device travel as one pinned, asynchronous upload
+        by_dev = {}
+        for rows, dev in lists:
+            by_dev.setdefault(dev, []).append(rows)
+        for dev, rows_list in by_dev.items():
+            pk = steptables.Packer()
+            for rows in rows_list:
+                pk.add(rows, list(rows), (len(rows),))
+            views = pk.upload(dev)
+            for rows in rows_list:
+                lists[(rows, dev)] = views[rows]
+        for key, rows in todo:
+            inputs[key] = inputs[key].index_select(0, lists[(rows, str(inputs[key].device))])
+        inputs["ordering"] = [ordering[p] for p in perm]
+        inputs["batch_order"] = [p if "batch_order" not in inputs else inputs["batch_order"][p] for p in perm]
+        return perm
 
     def _eager_step(self, inputs):
         outputs, losses = self.process_batch(inputs)
@@ -434,6 +525,7 @@ class Trainer:
         if is_train:
             self.valid_frames = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
             self.valid_frames_trimin(inputs)
+            self._step_tables(inputs)          # the step's ONE table upload goes out before its first launch
             side = self._pose_stream()
             if side is None:
                 outputs = self.predict_poses(inputs)
@@ -494,23 +586,47 @@ class Trainer:
         trainer.py:888-981) and extends `valid_frames` like :961-981."""
         self.plan = get_plan(inputs["ordering"], self.opt.trimin, self.opt.decomp)
         self.valid_frames = list(self.plan.valid_frames)
+        self.tables = None
         return self.plan
 
+    def _step_tables(self, inputs):
+        """Every integer table this step needs (plan, work order, pose schedule + its row lists, composition table,
+        invert flags) resident on the device after ONE asynchronous upload per batch signature (`steptables`).  The pose
+        mode follows the reference's threshold on the batch's `cutt` (trainer.py:312), which the collate keeps on the host."""
+        opt = self.opt
+        cutt = inputs["cutt"]
+        if torch.is_tensor(cutt) and cutt.is_cuda:      # a caller that moved it pays one sync here, once per batch dict
+            cutt = inputs["cutt"] = cutt.detach().cpu()
+        self.maxing_valid_frames = float(cutt) > 0.5
+        incremental = bool(opt.incremental_skip and self.maxing_valid_frames)
+        partial = bool(opt.partial_skip and self.maxing_valid_frames)
+        lib = None
+        if self.device.type == "cuda":
+            lib = getattr(self._backend(), "lib", None)
+        self.tables = steptables.get_step_tables(self.plan, opt.frame_ids, incremental, partial, bool(opt.decomp),
+                                                 len(opt.scales), opt.height, opt.width, self.device, lib, ops.BN_MAX_GROUPS)
+        return self.tables
+
     def _rows(self, tensor, rows):
-        if len(rows) == tensor.shape[0] and list(rows) == list(range(tensor.shape[0])):
+        if rows is None or (len(rows) == tensor.shape[0] and list(rows) == list(range(tensor.shape[0]))):
             return tensor
         return tensor.index_select(0, self._index(rows, tensor.device))
 
-    def _index(self, rows, device, dtype=torch.long):
-        """Row-index tensors are cached per (rows, device): the boosted pose modes select sub-batches
-        ~60 times per step and each fresh `torch.as_tensor(list)` is a synchronous host-to-device copy."""
+    def _index(self, rows, device, dtype=torch.int32):
+        """Row-index tensor of a sub-batch selection.  Inside a step these are views of the step's ONE table upload
+        (`steptables.StepTables.index`); a list the step did not announce (callers outside process_batch, the CPU
+        loops) takes a single pinned, asynchronous upload kept in a bounded LRU."""
+        tables = getattr(self, "tables", None)
+        if tables is not None and dtype == torch.int32 and tables.device == torch.device(device):
+            hit = tables.index(rows)
+            if hit is not None:
+                return hit
         key = (tuple(rows), str(device), dtype)
-        cache = self.__dict__.setdefault("_index_cache", {})
-        if key not in cache:
-            if len(cache) > 8192:
-                cache.clear()
-            cache[key] = torch.as_tensor(list(rows), dtype=dtype, device=device)
-        return cache[key]
+        cache = self.__dict__.setdefault("_index_cache", steptables.LRU(1024))
+        hit = cache.get(key)
+        if hit is None:
+            hit = cache.put(key, steptables.upload_single(list(rows), device, dtype))
+        return hit
 
     # ------------------------------------------------------------------ poses (trainer.py:310-419)
     def _pose_pair(self, first, second, invert):
@@ -537,7 +653,8 @@ class Trainer:
         if len(requests) <= 1 or not self._batched_pose_pairs():
             return [self._pose_pair(a, b, inv) for a, b, inv in requests]
         out = []
-        for lo in range(0, len(requests), ops.BN_MAX_GROUPS):
+        tables = getattr(self, "tables", None)
+        for c, lo in enumerate(range(0, len(requests), ops.BN_MAX_GROUPS)):
             chunk = requests[lo:lo + ops.BN_MAX_GROUPS]
             rows = [a.shape[0] for a, _, _ in chunk]
             x = torch.cat([torch.cat([a, b], 1) for a, b, _ in chunk], 0)
@@ -545,13 +662,13 @@ class Trainer:
                 feats = [self.models["pose_encoder"](x)]
             axisangle, translation = self.models["pose"](feats)
             # the chunk's pose matrices in ONE launch each way: the `invert` flag (negative frame ids, trainer.py:360,384,402)
-            # goes row by row as a small device table cached per (rows, flags) signature
-            key = (tuple(rows), tuple(bool(inv) for _, _, inv in chunk))
-            cache = self.__dict__.setdefault("_invert_rows", {})
-            if key not in cache:
-                flags = [int(bool(inv)) for n, (_, _, inv) in zip(rows, chunk) for _ in range(n)]
-                cache[key] = torch.tensor(flags, dtype=torch.int32).to(self.device)
-            M = ops.pose_matrix(axisangle[:, 0], translation[:, 0], backend=self._backend(), invert_rows=cache[key])
+            # goes row by row as a small device table - part of the step's one table upload
+            flags = [int(bool(inv)) for n, (_, _, inv) in zip(rows, chunk) for _ in range(n)]
+            if tables is not None and c < len(tables.invert) and tables.schedule.chunks[c][3] == flags:
+                invert_rows = tables.invert[c]
+            else:
+                invert_rows = self._index(flags, self.device)
+            M = ops.pose_matrix(axisangle[:, 0], translation[:, 0], backend=self._backend(), invert_rows=invert_rows)
             out.extend(torch.split(M, rows, dim=0))
         return out
 
@@ -565,53 +682,21 @@ class Trainer:
     def predict_poses(self, inputs):
         plan, opt = self.plan, self.opt
         outputs = {}
-        self.maxing_valid_frames = inputs["cutt"].item() > 0.5
-        self.valid_frames_pose = [f for f in plan.frames if f != STEREO]
-        temporal = [f for f in opt.frame_ids[1:] if f != STEREO]
-        incremental = bool(opt.incremental_skip and self.maxing_valid_frames)
-
-        # every pose-network call of the step, in the reference's call order; none depends on another's result, so
-        # they are collected first and run as one batched pass (`_pose_pairs`)
-        requests, slot = [], {}
-
-        def want(key, first, second, invert):
-            slot[key] = len(requests)
-            requests.append((first, second, invert))
-
-        if incremental:
-            # one pose-net call per ADJACENT pair, chained back to frame 0 (trainer.py:348-388)
-            for f in temporal:
-                cur = inputs["color_aug", f, 0]
-                if abs(f) == 1:
-                    ref = inputs["color_aug", 0, 0]
-                    want(("step", f), *((cur, ref, True) if f < 0 else (ref, cur, False)))
-                else:
-                    nb = f + 1 if f < 0 else f - 1
-                    own_f, own_nb = plan.owners(f), plan.owners(nb)
-                    near = self._rows(inputs["color_aug", nb, 0], [own_nb.index(b) for b in own_f])
-                    want(("step", f), *((cur, near, True) if f < 0 else (near, cur, False)))
-        else:
-            # one call per warp job on the already selected sub-batch (trainer.py:390-405)
-            for f in self.valid_frames:
-                if f == STEREO:
-                    continue
-                mid = self._rows(inputs["color_aug", 0, 0], plan.jobs[f])
-                other = self._rows(inputs["color_aug", f, 0], plan.job_rows_in_source(f))
-                want(("job", f), *((other, mid, True) if f < 0 else (mid, other, False)))
-        partial = bool(opt.partial_skip and self.maxing_valid_frames)
-        if partial:
-            # direct 0->f pose supplies the translation column except where |f| == m-2 (trainer.py:407-418)
-            assert incremental, "--partial_skip needs --incremental_skip (the reference's shapes only fit then)"
-            for f in self.valid_frames:
-                if f == STEREO or abs(f) <= 1:
-                    continue
-                mid = self._rows(inputs["color_aug", 0, 0], plan.owners(f))
-                cur = inputs["color_aug", f, 0]
-                want(("direct", f), *((cur, mid, True) if f < 0 else (mid, cur, False)))
+        tables = self._step_tables(inputs)
+        sched = tables.schedule
+        self.valid_frames_pose = list(sched.valid_frames_pose)
+        temporal, incremental, partial = sched.temporal, sched.incremental, sched.partial
+        # every pose-network call of the step, in the reference's call order (trainer.py:348-418: one call per adjacent
+        # pair in incremental mode, one per warp job otherwise, plus the direct 0->f calls of --partial_skip); none
+        # depends on another's result, so the host-side schedule lists them first (`steptables.PoseSchedule`) and they
+        # run as one batched pass (`_pose_pairs`)
+        slot = sched.slot
+        requests = [(self._rows(inputs["color_aug", a[0], 0], a[1]), self._rows(inputs["color_aug", b[0], 0], b[1]), inv)
+                    for _, a, b, inv, _ in sched.requests]
         Ts = self._pose_pairs(requests)
 
-        if ops.FUSED_POSE_COMPOSE and Ts and Ts[0].is_cuda and (incremental or opt.decomp):
-            return self._compose_poses(Ts, slot, temporal, incremental, partial)
+        if ops.FUSED_POSE_COMPOSE and Ts and Ts[0].is_cuda and tables.compose_table is not None:
+            return self._compose_poses(Ts, tables)
 
         if incremental:
             for f in temporal:
@@ -658,85 +743,18 @@ class Trainer:
                 outputs[("cam_T_cam", 0, f)] = torch.where(keep, chained, replaced)
         return outputs
 
-    def _compose_poses(self, Ts, slot, temporal, incremental, partial):
+    def _compose_poses(self, Ts, tables):
         """GPU form of the loops above: the incremental chain, the error-induced poses and the partial
         swap of the whole step as ONE launch each way (`ops.pose_compose`).  The integer table is a function of the
-        batch signature only and is cached; the composed matrices are views of one [NO,4,4] buffer."""
-        plan, opt = self.plan, self.opt
-        rows_of = [t.shape[0] for t in Ts]
-        base, acc = [], 0
-        for n in rows_of:
-            base.append(acc)
-            acc += n
-        key = (tuple(plan.ms), plan.trimin, plan.decomp, bool(opt.decomp), incremental, partial, tuple(temporal),
-               tuple(self.valid_frames), tuple(self.valid_frames_pose), tuple(rows_of),
-               tuple(sorted((str(k), v) for k, v in slot.items())))
-        cache = self.__dict__.setdefault("_compose_cache", {})
-        if key not in cache:
-            if len(cache) > 256:
-                cache.clear()
-            rows, views, passthrough = [], [], []       # views: (output key, first row, count)
-
-            def emit(okey, per_row):
-                # constant rows (empty chain, nothing swapped in; T_error) carry no gradient, like the reference's
-                const = all((flags & ops.COMPOSE_ERROR) or (not chain and not (flags & ops.COMPOSE_REPLACE))
-                            for chain, _, flags in per_row)
-                views.append((okey, len(rows), len(per_row), const))
-                rows.extend(per_row)
-
-            ERR, REP = ops.COMPOSE_ERROR, ops.COMPOSE_REPLACE
-            if incremental:
-                step_rows = {}                          # (k-1, k) -> (request slot, owners of k)
-                chains = {}
-                for f in temporal:
-                    i = slot[("step", f)]
-                    if abs(f) == 1:
-                        passthrough.append((("cam_T_cam", 0, f), i))
-                        passthrough.append((("cam_T_cam_step", 0, f), i))
-                        step_rows[(0, f)] = i
-                        chains[f] = [[base[i] + j] for j in range(rows_of[i])]
-                    else:
-                        nb = f + 1 if f < 0 else f - 1
-                        passthrough.append((("cam_T_cam_step", nb, f), i))
-                        step_rows[(nb, f)] = i
-                        if f not in self.valid_frames_pose:
-                            continue
-                        own_f = plan.owners(f)
-                        per = []
-                        for b in own_f:
-                            # the reference chains with range(f, 0, -1): EMPTY for negative f (identity pose, kept)
-                            per.append([base[step_rows[(k - 1, k)]] + plan.owners(k).index(b) for k in range(f, 0, -1)])
-                        chains[f] = per
-                    if opt.decomp:
-                        emit(("cam_T_cam_error", 0, f), [(c, -1, ERR) for c in chains[f]])
-                nonstereo = [m for m in plan.ms if m != 0]
-                for f in temporal:
-                    if abs(f) == 1 or f not in chains:
-                        continue
-                    swap = partial and f in self.valid_frames and f != STEREO
-                    per = []
-                    for j, c in enumerate(chains[f]):
-                        if swap and not (abs(f) == nonstereo[j] - 2):      # reference quirk: indexed by ROW number
-                            per.append((c, base[slot[("direct", f)]] + j, REP))
-                        else:
-                            per.append((c, -1, 0))
-                    emit(("cam_T_cam", 0, f), per)
-            else:
-                for f in self.valid_frames:
-                    if f == STEREO:
-                        continue
-                    i = slot[("job", f)]
-                    passthrough.append((("cam_T_cam", 0, f), i))
-                    if opt.decomp:
-                        emit(("cam_T_cam_error", 0, f), [([base[i] + j], -1, ERR) for j in range(rows_of[i])])
-            cache[key] = (ops.ComposeTable(rows, acc), views, passthrough)
-        table, views, passthrough = cache[key]
+        batch signature only (`steptables.PoseSchedule._compose_rows`) and reached the device with the step's one table
+        upload; the composed matrices are views of one [NO,4,4] buffer."""
+        table = tables.compose_table
         outputs = {}
-        for okey, i in passthrough:
+        for okey, i in tables.passthrough:
             outputs[okey] = Ts[i]
         if table.NO:
-            out = ops.pose_compose(torch.cat(list(Ts), 0), table, float(opt.pose_error), self._backend())
-            for okey, o0, n, const in views:
+            out = ops.pose_compose(torch.cat(list(Ts), 0), table, float(self.opt.pose_error), self._backend())
+            for okey, o0, n, const in tables.compose_views:
                 view = out[o0:o0 + n]
                 # the reference's T_error is a detached clone (trainer.py:376): the kernel's backward skips those rows
                 outputs[okey] = view.detach() if const else view

@@ -40,6 +40,7 @@ SCALES = [0, 1, 2, 3]
 
 def make_options(batch, device_index, config):
     import types
+    config = config.replace("_fresh", "")
     boosted = config not in ("md2", "vit")
     one_scale = config in ("boosted", "boosted15")
     return types.SimpleNamespace(
@@ -463,6 +464,181 @@ def run_workload(args, ctx, config, steps, warmup, want_graph, dp_mode):
             "value": args.batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3}
 
 
+def fresh_offsets(config, batch, n, seed=2025):
+    """`n` draws of a batch's per-sample frame offsets, as the reference loader redraws them per item
+    (mono_dataset.py:87-109; synthetic.draw_offsets) - stacked in canonical order like the device collate does."""
+    import random as _random
+    from baseboostdepth_amd.synthetic import draw_offsets
+    rnd = _random.Random(seed)
+    epoch = 15 if config.startswith("boosted15") else 5
+    return [sorted(draw_offsets(rnd, batch, epoch, True), reverse=True) for _ in range(n)]
+
+
+def run_fresh(args, ctx, config, want_graph, n_batches=30):
+    """The regime a real `--rand` epoch runs in: EVERY step brings a new batch signature (the loader redraws each
+    sample's frame set, trainer.py:250, 867-886).  `n_batches` pre-resident batches with different orderings, every
+    per-signature cache cold at the first step, device synchronise on both sides of each pass:
+      pass 1  cold: all first sightings (eager steps; every step builds + uploads its tables)
+      pass 2  the same batches again (second sighting: where the signature space is small - the early curriculum's 91
+              multisets - `Trainer` captures a step graph now; otherwise still eager, tables cached)
+      pass 3  third sighting (replays where pass 2 captured)
+    Reported per pass: ms/step, table uploads per step (steptables.STATS) and the synchronising calls per step that
+    torch itself flags (torch.cuda.set_sync_debug_mode("warn"): a pageable host-to-device copy is one)."""
+    import warnings
+    from baseboostdepth_amd import ops, plan as plan_mod, steptables
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    from baseboostdepth_amd.trainer import Trainer
+    base = config.replace("_fresh", "")
+    local, dev = ctx["local"], ctx["dev"]
+    torch.manual_seed(42)
+    opt = make_options(args.batch, local, base)
+    opt.fused_adam = not args.no_fused_adam
+    opt.step_graph = bool(want_graph)
+    opt.rand = True
+    small_space = base == "trimin5"          # 91 signatures: they come back; 18 564 (epoch >= 10): they do not
+    opt.graph_capture_after = 1 if small_space else 1 << 30
+    run_scales = list(opt.scales)
+    opt.scales = list(SCALES)
+    tr = Trainer(opt)
+    tr.opt.scales = run_scales
+    tr.set_train()
+    draws = fresh_offsets(base, args.batch, n_batches)
+    batches = []
+    for i, ms in enumerate(draws):
+        b = synthetic_batch(ms, H, W, run_scales, device=dev, seed=1000 + i)
+        b.pop("noise")
+        b["cutt"] = torch.tensor(1.35 if base.startswith("boosted") else 0.3)
+        batches.append(b)
+    signatures = len({tuple(ms) for ms in draws})
+    # warm everything that is NOT per-signature (MIOpen solutions, allocator, Adam state) on a signature outside the draw,
+    # then drop every per-signature cache: the first timed step of every signature is cold
+    warm = synthetic_batch([7] * args.batch if base.startswith("boosted") else [2] * args.batch, H, W, run_scales, device=dev, seed=7)
+    warm.pop("noise")
+    warm["cutt"] = batches[0]["cutt"].clone()
+    keep = tr.capture_after
+    tr.capture_after = 1 << 30
+    for _ in range(3):
+        tr.train_step(dict(warm))
+    tr.capture_after = keep
+    torch.cuda.synchronize()
+    steptables._STEP_CACHE.clear()
+    plan_mod._PLAN_CACHE.clear()
+    tr.__dict__.pop("_index_cache", None)
+    tr._sightings.clear()
+    passes = []
+    for p in range(3):
+        steptables.reset_stats()
+        g0 = dict(tr.graph_stats)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            torch.cuda.set_sync_debug_mode("warn")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in batches:
+                tr.train_step(dict(b))
+            torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        syncs = sum(1 for w in caught if "synchroniz" in str(w.message).lower())
+        st = dict(steptables.STATS)
+        g1 = tr.graph_stats
+        passes.append({"pass": p + 1, "ms_per_step": round(dt / n_batches * 1e3, 3),
+                       "images_per_sec": round(args.batch * n_batches / dt, 2),
+                       "table_uploads_per_step": round((st["packed_uploads"] + st["single_uploads"]) / n_batches, 3),
+                       "table_bytes_per_step": int(st["packed_words"] * 4 / n_batches),
+                       "table_build_ms_per_step": round(st.get("build_ms", 0.0) / n_batches, 3),
+                       "synchronising_calls_per_step": round(syncs / n_batches, 3),
+                       "eager_steps": g1["eager"] - g0["eager"], "captures": g1["captures"] - g0["captures"],
+                       "replays": g1["replays"] - g0["replays"]})
+    out = {"config": config, "workload": "%s with a NEW ordering every step: %d pre-resident batches, %d distinct signatures, "
+                                          "offsets drawn per sample like mono_dataset.py:87-109, stacked largest offset first"
+                                          % (workload_name(base, args.batch, len(run_scales), "redrawn per step"), n_batches, signatures),
+           "value": passes[0]["images_per_sec"], "unit": "images/sec", "ms_per_step": passes[0]["ms_per_step"],
+           "steps": n_batches, "passes": passes, "step_graph": bool(tr.use_graph),
+           "graph_capture_after": None if opt.graph_capture_after >= 1 << 30 else opt.graph_capture_after,
+           "what": "value = pass 1 (every cache cold, every signature new); pass 3 = every signature seen before"}
+    del tr, batches
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_loader_fed(args, ctx, want_graph, steps=60, warmup=20, workers=None):
+    """SURVEY 8f-3's purpose - real-data images/sec: the MD2 step fed by the loader instead of a pre-resident batch.
+    A synthetic KITTI-raw tree of JPEGs (KITTI's sizes; synthetic.synthetic_kitti_tree) -> `datasets.KITTIRAWDataset`
+    (frame-set selection + JPEG decode in worker processes, mono_dataset.py:76-146) -> shared pinned ring -> `DeviceCollate`
+    (resize / pyramid / colour jitter / ToTensor / stacking as HIP kernels) -> `Trainer.train_step`
+    (trainer.py:214-220, 232-264).  Also times the loader alone (no training) = the host decode ceiling."""
+    import shutil
+    import tempfile
+    from baseboostdepth_amd import datasets
+    from baseboostdepth_amd.synthetic import synthetic_kitti_tree
+    from baseboostdepth_amd.trainer import Trainer
+    local, dev = ctx["local"], ctx["dev"]
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    workers = workers or max(4, min(24, avail - 2))
+    tmp = tempfile.mkdtemp(prefix="bbd_kitti_")
+    try:
+        lines = synthetic_kitti_tree(tmp, frames=40) * 40          # 3 840 split lines over 160 JPEG files
+        torch.manual_seed(42)
+        opt = make_options(args.batch, local, "md2")
+        opt.fused_adam = not args.no_fused_adam
+        opt.step_graph = bool(want_graph)
+        tr = Trainer(opt)
+        tr.set_train()
+
+        def make_loader():
+            ds = datasets.KITTIRAWDataset(lines, 0, H, W, kt_path=tmp, rand=False, is_train=True, scales=opt.scales, kt=True,
+                                          naive_mix=True, trimin=False, seed=1)
+            return datasets.DeviceLoader(ds, args.batch, datasets.DeviceCollate(H, W, opt.scales, dev), num_workers=workers,
+                                         prefetch=3, seed=0, workers="process")
+        # (a) the loader alone: decode + collate, nothing consuming the GPU besides the collate kernels
+        n, t0 = 0, None
+        for i, batch in enumerate(make_loader()):
+            if i == 10:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            if i >= 10:
+                n += args.batch
+            if i == 10 + steps - 1:
+                break
+        torch.cuda.synchronize()
+        loader_alone = n / (time.perf_counter() - t0)
+        frames_per_sample = sum(1 for k in batch if isinstance(k, tuple) and k[0] == "color" and k[2] == 0)
+        # (b) the loader feeding the step
+        n, t0, last = 0, None, None
+        for i, batch in enumerate(make_loader()):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            _, losses = tr.train_step(batch)
+            last = losses["loss"]
+            if i >= warmup:
+                n += args.batch
+            if i == warmup + steps - 1:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        finite = bool(torch.isfinite(last.detach()).item())
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"config": "md2_loader", "workload": "MD2 step fed by datasets.KITTIRAWDataset + DeviceCollate on a synthetic KITTI-raw JPEG "
+                                                "tree (1242x375 -> 640x192, %d JPEG frames per sample: 0, -1, +1, stereo), batch %d"
+                                                % (frames_per_sample, args.batch),
+           "value": round(n / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / (n / args.batch) * 1e3, 3), "steps": n // args.batch,
+           "warmup": warmup, "step_graph": bool(tr.use_graph), "loss_finite": finite,
+           "loader_alone_images_per_sec": round(loader_alone, 1),
+           "host_decode_frames_per_sec": round(loader_alone * frames_per_sample, 1),
+           "decode_workers": workers, "schedulable_cpus": avail, "data": "synthetic JPEG tree (decoded, resized, jittered for real)"}
+    del tr
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+
 def release(res):
     """Drop a workload's trainer (its captured graphs keep private memory pools) before the next one is built."""
     import gc
@@ -486,7 +662,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
-    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5", "vit"],
+    ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5", "vit", "boosted15_fresh",
+                                                        "trimin5_fresh", "md2_loader"],
                     help="md2 = BASELINE configs[1]/[3] (the headline); configs[2] (SURVEY 8d config 3): boosted = "
                          "worst case m=7 for every sample, boosted15 = the epoch-15 offset distribution (standard "
                          "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales); "
@@ -497,7 +674,7 @@ def main(argv=None):
                          "BASELINE configs[2] (boosted, boosted15) and configs[4] (vit) for --secondary-steps steps each, in this "
                          "process, fresh Trainer each, and reports them under `secondary` of the same JSON line")
     ap.add_argument("--secondary-steps", type=int, default=10)
-    ap.add_argument("--secondary-budget", type=float, default=150.0, help="seconds; configs not started within it are listed as skipped")
+    ap.add_argument("--secondary-budget", type=float, default=240.0, help="seconds; configs not started within it are listed as skipped")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--no-fused-adam", action="store_true")
@@ -565,6 +742,12 @@ def main(argv=None):
         torch.backends.cudnn.benchmark = True
     want_graph = args.step_graph == "on" or (args.step_graph == "auto" and not args.no_fused_adam)
     head_mode = "graph" if args.dp_mode == "all" else args.dp_mode
+    if args.config.endswith("_fresh") or args.config == "md2_loader":
+        # stand-alone form of a secondary line (profiling runs): one JSON line, no headline
+        assert world == 1, "the fresh-ordering / loader-fed lines are one-GPU measurements"
+        r = run_fresh(args, ctx, args.config, want_graph) if args.config.endswith("_fresh") else run_loader_fed(args, ctx, want_graph)
+        print(json.dumps(r))
+        return 0
     res = run_workload(args, ctx, args.config, args.steps, args.warmup, want_graph, head_mode)
     trainer, opt, inputs = res["trainer"], res["opt"], res["inputs"]
 
@@ -631,12 +814,25 @@ def main(argv=None):
     #      released in between, never a re-exec
     if world == 1 and args.config == "md2" and not args.no_secondary:
         secondary, t_sec = [], time.perf_counter()
-        for cfg in ("boosted", "boosted15", "vit"):
+        frozen = {"md2": res["value"]}
+        for cfg in ("boosted", "boosted15", "trimin5", "vit", "boosted15_fresh", "trimin5_fresh", "md2_loader"):
             if time.perf_counter() - t_sec > args.secondary_budget:
                 secondary.append({"config": cfg, "skipped": "secondary budget of %.0f s used up" % args.secondary_budget})
                 continue
             try:
+                if cfg.endswith("_fresh") or cfg == "md2_loader":
+                    # the regimes a real run is in: a new ordering every step / the loader in the loop
+                    r = run_fresh(args, ctx, cfg, want_graph) if cfg.endswith("_fresh") else run_loader_fed(args, ctx, want_graph)
+                    ref = frozen.get(cfg.replace("_fresh", "").replace("_loader", ""))
+                    if ref:
+                        r["frozen_batch_images_per_sec"] = round(ref, 2)
+                        r["vs_frozen_batch"] = round(r["value"] / ref, 4)
+                        if "passes" in r:
+                            r["vs_frozen_batch_seen_signatures"] = round(r["passes"][-1]["images_per_sec"] / ref, 4)
+                    secondary.append(r)
+                    continue
                 r = run_workload(args, ctx, cfg, max(10, args.secondary_steps), 3, want_graph, "graph")
+                frozen[cfg] = r["value"]
                 rf = r["roofline"] or {}
                 secondary.append({
                     "config": cfg, "workload": workload_name(cfg, args.batch, r["S"], r["ms"]),
@@ -652,6 +848,7 @@ def main(argv=None):
                 release(r)
             except Exception as e:    # a secondary configuration never takes the headline down
                 secondary.append({"config": cfg, "error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+                torch.cuda.set_sync_debug_mode("default")
                 torch.cuda.synchronize()
         if line is not None:
             line["secondary"] = secondary

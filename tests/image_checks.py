@@ -62,26 +62,10 @@ def check_color_jitter(pipe, H=48, W=160, seed=11):
 
 
 # ---------------------------------------------------------------------------- loader end to end
-def make_kitti_tree(root, drives=(("2011_09_26/2011_09_26_drive_0001_sync", 375, 1242),
-                                  ("2011_09_30/2011_09_30_drive_0020_sync", 370, 1226)), frames=24, seed=0):
+def make_kitti_tree(root, **kw):
     """A small KITTI-raw-shaped directory of synthetic JPEGs (both cameras) + split lines with baselines."""
-    import os
-    from PIL import Image
-    rng = np.random.default_rng(seed)
-    lines = []
-    for folder, h, w in drives:
-        base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 40, 3), dtype=np.uint8)
-        big = np.array(Image.fromarray(base).resize((w + 300, h), Image.BICUBIC))
-        for cam, dx in (("image_02", 0), ("image_03", 9)):
-            d = os.path.join(root, folder, cam, "data")
-            os.makedirs(d, exist_ok=True)
-            for t in range(frames):
-                img = big[:, 5 * t + dx: 5 * t + dx + w]
-                Image.fromarray(img).save(os.path.join(d, "%010d.jpg" % t), quality=92)
-        for t in range(8, frames - 8):
-            for side in "lr":
-                lines.append("%s %d %s kt %.6f" % (folder, t, side, float(rng.uniform(0.02, 0.6))))
-    return lines
+    from baseboostdepth_amd.synthetic import synthetic_kitti_tree
+    return synthetic_kitti_tree(root, **kw)
 
 
 def check_loader_batches(tmpdir, device, backend, epoch, trimin, scales, batch_size=4, n_batches=2, H=96, W=320):
@@ -100,7 +84,12 @@ def check_loader_batches(tmpdir, device, backend, epoch, trimin, scales, batch_s
     chunks = list(loader._batches())
     for chunk, got in zip(chunks, loader):
         recipes = [ds[i] for i in chunk]                       # per-item RNG streams: same draws again
-        want = ref_tr.custom_collate([loader_ref.preprocess_item(r, scales, H, W) for r in recipes])
+        items = [loader_ref.preprocess_item(r, scales, H, W) for r in recipes]
+        # the device collate stacks the samples in canonical order (largest frame offset first, stable): the reference's
+        # collate of the SAME items in that order
+        from baseboostdepth_amd.plan import canonical_permutation
+        order = canonical_permutation([int(torch.max(it["frames"]).item()) for it in items])
+        want = ref_tr.custom_collate([items[i] for i in order])
         assert set(got) == set(want), (sorted(map(str, got)), sorted(map(str, want)))
         for k, v in want.items():
             if torch.is_tensor(v) and v.dim() > 0:

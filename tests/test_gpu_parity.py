@@ -307,7 +307,7 @@ def test_every_forward_form_is_bit_exact(form):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BBD_FWD_FORM=str(form))
+    env = dict(os.environ, BBD_EXPERIMENT="1", BBD_FWD_FORM=str(form))
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
                           "-k", "fused_path_matches_reference_bit_for_bit or disparity_mode_equals_depth_plane_mode"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=900)

@@ -48,6 +48,10 @@ def test_fused_work_items_rejects_a_bad_order():
     host = torch.empty(2 * 1 * lib.num_tiles_fwd(32, 64), 2, dtype=torch.int32)
     with pytest.raises(_lib.BbdError):
         lib.call("bbd_fused_work_items", 2, 1, 32, 64, 0, (ctypes.c_int32 * 2)(0, 5), host.data_ptr())
+    # in range but not a permutation: sample 1 would be skipped, sample 0 run twice
+    host3 = torch.empty(3 * 1 * lib.num_tiles_fwd(32, 64), 2, dtype=torch.int32)
+    with pytest.raises(_lib.BbdError):
+        lib.call("bbd_fused_work_items", 3, 1, 32, 64, 0, (ctypes.c_int32 * 3)(0, 2, 0), host3.data_ptr())
 
 
 def test_plan_orders_samples_by_candidate_count():

@@ -3,7 +3,7 @@
 # bench.py's eager loop (tools/pmc_passes.sh does the full set).   usage: tools/traffic_ab.sh <config> <mode> <outdir>
 set -u
 cfg=$1; mode=$2; out=$3
-export TMPDIR=/tmp BBD_XCD_REMAP=$mode
+export TMPDIR=/tmp BBD_EXPERIMENT=1 BBD_XCD_REMAP=$mode
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o ${cfg}_m${mode}_$c -- \
