@@ -52,6 +52,7 @@ struct BnArgs {
   // call groups: samples [rows[g], rows[g+1]) are normalised with their own statistics, as if each group had been
   // a separate call of the layer (one batched pass of a network that the reference calls G times); blockIdx.z = g
   int G;
+  int untracked;         // the last `untracked` groups are normalised like the others but leave the running statistics alone
   int rows[BBD_BN_MAX_GROUPS + 1];
 };
 
@@ -134,7 +135,7 @@ template <typename Totals>
 __device__ __forceinline__ void update_running(const BnArgs& a, int c, Totals totals) {
   if (a.run_mean) {
     float rm = a.run_mean[c], rv = a.run_var[c];
-    for (int q = 0; q < a.G; ++q) {
+    for (int q = 0; q < a.G - a.untracked; ++q) {
       double qs, qss, qmean, qvar;
       totals(q, &qs, &qss);
       group_moments(a, q, qs, qss, &qmean, &qvar);
@@ -146,7 +147,7 @@ __device__ __forceinline__ void update_running(const BnArgs& a, int c, Totals to
     a.run_mean[c] = rm;
     a.run_var[c] = rv;
   }
-  if (a.batches && c == 0) *a.batches += a.G;
+  if (a.batches && c == 0) *a.batches += a.G - a.untracked;
 }
 
 // forward apply of slice k
@@ -898,10 +899,11 @@ int fill_groups(const int32_t* group_rows, int G, int N, BnArgs* a) {
 
 int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                           long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G, int N, int C,
-                           int HW, double eps, double momentum, int relu, void* stream) {
+                           long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G,
+                           int untracked_groups, int N, int C, int HW, double eps, double momentum, int relu, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch || N <= 0 || C <= 0 || HW <= 0)
     return BBD_E_BADARG;
+  if (untracked_groups < 0 || untracked_groups >= G) return BBD_E_BADARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return BBD_E_BADARG;
   BnArgs a = {};
   const int biggest = fill_groups(group_rows, G, N, &a);
@@ -909,6 +911,7 @@ int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* g
   a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.y = y; a.part = scratch; a.mean = save_mean;
   a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.batches = num_batches_tracked; a.N = N; a.C = C; a.HW = HW;
   a.split = pick_split(biggest, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
+  a.untracked = untracked_groups;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((long long)biggest * HW <= BN_SMALL_ELEMS) {       // one launch (+ a C-thread one for the cross-group results)
     hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(1, (unsigned)C, (unsigned)G), dim3(NT), 0, st, a);
@@ -953,7 +956,7 @@ int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, co
                    int relu, void* stream) {
   const int32_t rows[2] = {0, N};
   return bbd_bn_act_grouped_fwd(x, residual, gamma, beta, y, save_mean, save_invstd, running_mean, running_var,
-                                num_batches_tracked, scratch, rows, 1, N, C, HW, eps, momentum, relu, stream);
+                                num_batches_tracked, scratch, rows, 1, 0, N, C, HW, eps, momentum, relu, stream);
 }
 
 int bbd_bn_act_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,

@@ -1123,6 +1123,7 @@ def residual_add(x, branch, mask, backend=None):
 # ---------------------------------------------------------------------------- BatchNorm (+add) (+ReLU)
 BN_MAX_GROUPS = 32          # BBD_BN_MAX_GROUPS of include/bbd_hip.h
 _bn_groups = None           # row counts of the call groups of the batched pass being run (None = one group)
+_bn_untracked = 0           # trailing groups of it that are padding (no running-statistics update)
 
 
 class bn_call_groups:
@@ -1130,18 +1131,23 @@ class bn_call_groups:
     call groups of n_g samples with their own batch statistics: one batched pass of a network computes what the
     reference's separate calls on the sub-batches compute (the pose network: trainer.py:348-418)."""
 
-    def __init__(self, rows):
+    def __init__(self, rows, padding_groups=0):
+        """`padding_groups`: the last that many groups are padding rows - normalised, but the running statistics and
+        num_batches_tracked see only the real calls (bbd_bn_act_grouped_fwd, `untracked_groups`)."""
         self.rows = [int(r) for r in rows] if rows is not None and len(rows) > 1 else None
+        self.untracked = int(padding_groups) if self.rows is not None else 0
         assert self.rows is None or (len(self.rows) <= BN_MAX_GROUPS and min(self.rows) > 0)
+        assert 0 <= self.untracked < max(len(self.rows or [0]), 1)
 
     def __enter__(self):
-        global _bn_groups
-        self.prev, _bn_groups = _bn_groups, self.rows
+        global _bn_groups, _bn_untracked
+        self.prev, _bn_groups = (_bn_groups, _bn_untracked), self.rows
+        _bn_untracked = self.untracked
         return self
 
     def __exit__(self, *exc):
-        global _bn_groups
-        _bn_groups = self.prev
+        global _bn_groups, _bn_untracked
+        _bn_groups, _bn_untracked = self.prev
 
 
 def _group_table(rows):
@@ -1173,7 +1179,7 @@ class _BatchNormAct(torch.autograd.Function):
                               dtype=torch.float64)
         backend.run("bbd_bn_act_grouped_fwd", x, ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean),
                     ptr(invstd), ptr(running_mean), ptr(running_var), ptr(batches), ptr(scratch), _group_table(rows), G,
-                    N, C, H * W, float(eps), float(momentum), int(relu))
+                    _bn_untracked if _bn_groups is not None else 0, N, C, H * W, float(eps), float(momentum), int(relu))
         # without a residual the backward re-derives the ReLU mask from x (one activation read less per launch)
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, mean, invstd)
         ctx.meta = (bool(relu), residual is not None, backend, rows)

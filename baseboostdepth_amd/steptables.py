@@ -352,13 +352,13 @@ class StepTables:
 _STEP_CACHE = LRU(256)
 
 
-def step_key(plan, frame_ids, incremental, partial, decomp, S, H, W, device):
+def step_key(plan, frame_ids, incremental, partial, decomp, S, H, W, device, chunk):
     return (tuple(plan.ms), plan.trimin, plan.decomp, tuple(str(f) for f in frame_ids), bool(incremental), bool(partial),
-            bool(decomp), S, H, W, str(device))
+            bool(decomp), S, H, W, str(device), chunk)
 
 
 def get_step_tables(plan, frame_ids, incremental, partial, decomp, S, H, W, device, lib=None, chunk=32):
-    key = step_key(plan, frame_ids, incremental, partial, decomp, S, H, W, device)
+    key = step_key(plan, frame_ids, incremental, partial, decomp, S, H, W, device, chunk)
     hit = _STEP_CACHE.get(key)
     if hit is None:
         t0 = time.perf_counter()

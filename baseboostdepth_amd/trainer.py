@@ -29,6 +29,7 @@ class Trainer:
     dp_capture = False       # data parallel under a step graph: RCCL all-reduces captured into the graph (opt-in)
     _main_stream = None
     max_graphs = 8
+    pose_pad_rows = 0
 
     def __init__(self, options, backend=None):
         self.opt = options
@@ -96,6 +97,9 @@ class Trainer:
         # saves; the early curriculum's 91 signatures all come back within a few hundred steps
         self.capture_after = int(getattr(opt, "graph_capture_after", 2 if getattr(opt, "rand", False) else 0))
         self._sightings = steptables.LRU(8192)
+        # rows the batched pose pass is rounded up to (0 = exact): see `_pose_pairs`.  On for the recipes whose frame sets
+        # change per batch; fixed-frame-set training has ONE row count and pays nothing
+        self.pose_pad_rows = int(getattr(opt, "pose_pad_rows", 32 if getattr(opt, "rand", False) else 0))
         self._capture_checked = False
         self.graph_stats = {"replays": 0, "captures": 0, "eager": 0}
         # data parallel + step graph: capture the bucketed RCCL all-reduces INTO the graph (one graph per step, exchange
@@ -604,7 +608,7 @@ class Trainer:
         if self.device.type == "cuda":
             lib = getattr(self._backend(), "lib", None)
         self.tables = steptables.get_step_tables(self.plan, opt.frame_ids, incremental, partial, bool(opt.decomp),
-                                                 len(opt.scales), opt.height, opt.width, self.device, lib, ops.BN_MAX_GROUPS)
+                                                 len(opt.scales), opt.height, opt.width, self.device, lib, self._pose_chunk())
         return self.tables
 
     def _rows(self, tensor, rows):
@@ -654,13 +658,26 @@ class Trainer:
             return [self._pose_pair(a, b, inv) for a, b, inv in requests]
         out = []
         tables = getattr(self, "tables", None)
-        for c, lo in enumerate(range(0, len(requests), ops.BN_MAX_GROUPS)):
-            chunk = requests[lo:lo + ops.BN_MAX_GROUPS]
+        chunk_size = self._pose_chunk()
+        for c, lo in enumerate(range(0, len(requests), chunk_size)):
+            chunk = requests[lo:lo + chunk_size]
             rows = [a.shape[0] for a, _, _ in chunk]
-            x = torch.cat([torch.cat([a, b], 1) for a, b, _ in chunk], 0)
-            with ops.bn_call_groups(rows):
+            n_real = sum(rows)
+            parts = [torch.cat([a, b], 1) for a, b, _ in chunk]
+            # boosted batches change the pass's row count almost every step, and every new row count is a new problem for
+            # every convolution of the pose network (MIOpen compiles solvers for tens of seconds at first sight): round the
+            # pass up to a multiple of `pose_pad_rows` with one trailing call group of zero rows.  Its BatchNorm statistics
+            # are its own and leave the running statistics alone (`untracked_groups`), nobody reads its outputs and its
+            # gradient contributions are exact zeros - the real calls compute what they compute without it
+            pad = (-n_real) % self.pose_pad_rows if self.pose_pad_rows > 0 and self.models["pose_encoder"].training else 0
+            if pad:
+                parts.append(parts[0].new_zeros((pad,) + tuple(parts[0].shape[1:])))
+            x = torch.cat(parts, 0)
+            with ops.bn_call_groups(rows + ([pad] if pad else []), padding_groups=1 if pad else 0):
                 feats = [self.models["pose_encoder"](x)]
             axisangle, translation = self.models["pose"](feats)
+            if pad:
+                axisangle, translation = axisangle[:n_real], translation[:n_real]
             # the chunk's pose matrices in ONE launch each way: the `invert` flag (negative frame ids, trainer.py:360,384,402)
             # goes row by row as a small device table - part of the step's one table upload
             flags = [int(bool(inv)) for n, (_, _, inv) in zip(rows, chunk) for _ in range(n)]
@@ -671,6 +688,10 @@ class Trainer:
             M = ops.pose_matrix(axisangle[:, 0], translation[:, 0], backend=self._backend(), invert_rows=invert_rows)
             out.extend(torch.split(M, rows, dim=0))
         return out
+
+    def _pose_chunk(self):
+        """Calls per batched pose pass: the grouped BatchNorm takes BBD_BN_MAX_GROUPS groups, one of which is the padding's."""
+        return ops.BN_MAX_GROUPS - (1 if self.pose_pad_rows > 0 else 0)
 
     def _error_pose(self, T):
         Te = T.clone().detach()                       # no pose gradient through the error-induced warp

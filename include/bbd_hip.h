@@ -31,7 +31,7 @@ extern "C" {
  * scratch sizing changed (round 2, was not bumped then); 3 = round 3 (backward tiling / scratch contract); 4 = the
  * depth-wise token weight gradient's scratch contract (one partial row per workgroup) and `add_input` of
  * bbd_dwconv_tokens_fwd became a bit field (round 3, with the bbd_token_ln_* / bbd_colsum additions). */
-#define BBD_ABI_VERSION 5
+#define BBD_ABI_VERSION 6
 
 /* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
  * trainer.py:428).  A "slot" indexes a host array of their base pointers. */
@@ -340,13 +340,18 @@ int bbd_bn_scratch_doubles(int N, int C, int HW);
  * the pose network's per-frame calls (trainer.py:348-418: up to 26 calls per step on <= 12 samples each) run as one
  * batched pass.  save_mean / save_invstd are [G,C]; the running statistics receive G momentum updates in group order
  * and num_batches_tracked += G; grad_gamma / grad_beta are summed over the groups.  scratch:
- * bbd_bn_grouped_scratch_doubles(largest group, G, C, HW) doubles. */
+ * bbd_bn_grouped_scratch_doubles(largest group, G, C, HW) doubles.
+ * untracked_groups (ABI 6; 0 <= . < G): the LAST that many groups are normalised like the others but take no part in the
+ * running statistics or num_batches_tracked - padding rows.  Boosted batches change the batched pose pass's row count
+ * almost every step (mono_dataset.py:87-109), and every new row count is a new convolution problem for MIOpen (tens of
+ * seconds of solver compilation at first sight); the trainer rounds the pass up to a multiple of 32 rows with one
+ * trailing group of zero rows whose outputs nobody reads (their gradients are exact zeros). */
 #define BBD_BN_MAX_GROUPS 32
 int bbd_bn_grouped_scratch_doubles(int max_group_rows, int G, int C, int HW);
 int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                           long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G, int N,
-                           int C, int HW, double eps, double momentum, int relu, void* stream);
+                           long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G,
+                           int untracked_groups, int N, int C, int HW, double eps, double momentum, int relu, void* stream);
 int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
                            const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
                            float* grad_gamma, float* grad_beta, double* scratch, const int32_t* group_rows, int G, int N,

@@ -68,7 +68,7 @@ def test_canonical_order_computes_the_callers_batch():
     from baseboostdepth_amd.trainer import Trainer
     from baseboostdepth_amd.synthetic import synthetic_batch
     H, W = 96, 160
-    ms = [1, 3, 0, 2, 5, 2]
+    ms = [1, 3, 1, 2, 5, 2]          # (epoch >= 10 regime: every sample has temporal frames)
     torch.manual_seed(0)
     opt = make_opt(H, W, len(ms), [0, 1, 2, 3], True)
     tr = Trainer(opt)
@@ -82,7 +82,7 @@ def test_canonical_order_computes_the_callers_batch():
     canon = dict(inputs)
     perm = tr.canonicalize(canon)
     assert perm == [4, 1, 3, 5, 0, 2] and canon["batch_order"] == perm
-    assert canon["ordering"] == [[0, 5, -5], [0, 3, -3], [0, 2, -2], [0, 2, -2], [0, 1, -1], [0, "s"]]
+    assert canon["ordering"] == [[0, 5, -5], [0, 3, -3], [0, 2, -2], [0, 2, -2], [0, 1, -1], [0, 1, -1]]
     out_b, loss_b = tr.process_batch(canon)
     assert abs(float(loss_a["loss"]) - float(loss_b["loss"])) <= 1e-5 * abs(float(loss_a["loss"]))
     for b, p in enumerate(perm):

@@ -303,6 +303,77 @@ def test_grouped_batch_norm_equals_separate_calls(rows, res, relu, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,pad,H,W", [([5, 3, 4], 4, 12, 20), ([12, 2, 7], 11, 48, 160)])
+def test_padding_group_leaves_the_real_call_groups_untouched(rows, pad, H, W):
+    """`ops.bn_call_groups(rows + [pad], padding_groups=1)`: a trailing group of zero rows (what `Trainer._pose_pairs`
+    rounds the batched pose pass up with) - the real groups' outputs, data gradients, running statistics and
+    num_batches_tracked are bit for bit those of the unpadded pass, parameter gradients too (the padding's terms are
+    exact zeros)."""
+    import copy
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.networks.encoder import FusedBatchNorm2d
+    torch.manual_seed(12)
+    C, N = 16, sum(rows)
+    x = torch.randn(N, C, H, W, device=DEV) * 2 + 0.5
+    wgt = torch.randn(N, C, H, W, device=DEV)
+    plain = FusedBatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        plain.weight.uniform_(0.5, 1.5)
+        plain.bias.uniform_(-0.5, 0.5)
+    padded = copy.deepcopy(plain)
+    xa = x.clone().requires_grad_(True)
+    with ops.bn_call_groups(rows):
+        ya = plain(xa, relu=True)
+    (ya * wgt).sum().backward()
+    xb = torch.cat([x, x.new_zeros(pad, C, H, W)]).requires_grad_(True)
+    with ops.bn_call_groups(rows + [pad], padding_groups=1):
+        yb = padded(xb, relu=True)
+    (yb[:N] * wgt).sum().backward()
+    assert torch.equal(yb[:N], ya)
+    assert torch.equal(xb.grad[:N], xa.grad) and not xb.grad[N:].any()
+    assert torch.equal(padded.running_mean, plain.running_mean) and torch.equal(padded.running_var, plain.running_var)
+    assert int(padded.num_batches_tracked) == int(plain.num_batches_tracked) == len(rows)
+    assert torch.equal(padded.weight.grad, plain.weight.grad) and torch.equal(padded.bias.grad, plain.bias.grad)
+
+
+@pytest.mark.gpu
+def test_padded_pose_pass_equals_the_exact_one():
+    """Trainer._pose_pairs with `pose_pad_rows`: poses, pose-network gradients and BatchNorm buffers of the exact pass."""
+    from baseboostdepth_amd.trainer import Trainer
+    import bench
+    torch.manual_seed(3)
+    opt = bench.make_options(4, 0, "md2")
+    opt.height, opt.width = 64, 128
+    tr = Trainer(opt)
+    tr.set_train()
+    frames = [torch.rand(n, 3, 64, 128, device=DEV) for n in (4, 4, 3, 2, 3, 2)]
+    reqs = [(frames[0], frames[1], False), (frames[2], frames[4], True), (frames[3], frames[5], False)]
+    params = [p for k in ("pose_encoder", "pose") for p in tr.models[k].parameters()]
+    state = {k: {n: b.clone() for n, b in tr.models[k].named_buffers()} for k in ("pose_encoder", "pose")}
+
+    def run(pad_rows):
+        for k in state:
+            for n, b in tr.models[k].named_buffers():
+                b.copy_(state[k][n])
+        for p in params:
+            p.grad = None
+        tr.pose_pad_rows = pad_rows
+        Ts = tr._pose_pairs(reqs)
+        sum((T * T).sum() for T in Ts).backward()
+        return ([T.detach().clone() for T in Ts], [p.grad.clone() for p in params if p.grad is not None],
+                [b.clone() for b in tr.models["pose_encoder"].buffers()])
+
+    Ta, ga, ba = run(0)
+    Tb, gb, bb = run(16)               # 9 rows -> 16
+    for a, b in zip(Ta, Tb):
+        assert float((a - b).abs().max()) < 1e-6, float((a - b).abs().max())
+    for a, b in zip(ba, bb):
+        assert torch.equal(a, b)
+    for a, b in zip(ga, gb):           # MIOpen picks solvers per batch size: convolution weight gradients to rounding
+        assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-7
+
+
+@pytest.mark.gpu
 def test_batched_pose_pairs_equal_the_separate_calls():
     """Trainer._pose_pairs: all pose-network calls of a step as ONE pass (call groups in every BatchNorm) give the poses
     and the network gradients of the reference's separate calls."""
