@@ -907,9 +907,15 @@ class Trainer:
         self.set_train()
         return result
 
-    def argmin_masks(self, outputs, scale_index=0):
-        """The reference's `self.ident` bookkeeping (trainer.py:1002-1003 etc.): per sample, where a
-        true-pose reprojection ('norm') or an error-induced one ('guide') won the arg-min."""
+    def argmin_masks(self, outputs, scale_index=0, reference_dicts=False):
+        """The reference's `self.ident` bookkeeping (trainer.py:547; x_min_opt :1002-1003, :1021-1022, :1044-1045 and the
+        non-decomp branch): per sample, where a true-pose reprojection ('norm') or an error-induced one ('guide') won the
+        per-pixel minimum.  The fused launch's arg-min ids follow the reference's `torch.cat` order (true-pose warps,
+        error-induced warps, identity maps), so 'norm' = id < n_T and 'guide' = n_T <= id < n_T + n_E.
+        Returns (norm [B,H,W] bool, guide [B,H,W] bool) in batch order; `reference_dicts=True` gives the reference's own
+        shape instead - (dictor_norm, dictor_guide), keys `(m | 's', 'norm' | 'guide')` for every sample group of the
+        batch, each holding one [n_group,H,W] tensor (samples of the group in batch order; 'guide' only under --decomp
+        and never for the stereo group, as in the reference)."""
         arg = outputs[("bbd", "argmin")][scale_index]
         norm, guide = [], []
         for b, names in enumerate(self.plan.cand_names):
@@ -917,7 +923,20 @@ class Trainer:
             n_e = sum(1 for k, _ in names if k == "E")
             norm.append(arg[b] < n_t)
             guide.append((arg[b] >= n_t) & (arg[b] < n_t + n_e))
-        return torch.stack(norm), torch.stack(guide)
+        norm, guide = torch.stack(norm), torch.stack(guide)
+        if not reference_dicts:
+            return norm, guide
+        ms = self.plan.ms
+        key = lambda m: STEREO if m == 0 else m
+        dictor_norm = {(key(m), "norm"): [] for m in ms}
+        dictor_guide = {(key(m), "guide"): [] for m in ms}
+        # the reference visits the groups in `temp_positive` order; every group appends exactly one tensor to its own key
+        for m in sorted(set(ms)):
+            rows = [b for b, mb in enumerate(ms) if mb == m]
+            dictor_norm[(key(m), "norm")].append(norm[rows])
+            if self.plan.decomp and m != 0:
+                dictor_guide[(key(m), "guide")].append(guide[rows])
+        return dictor_norm, dictor_guide
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:774-829)
     def save_opts(self):

@@ -864,6 +864,7 @@ def main(argv=None):
     # ---- --dp-mode all: the other two multi-rank loops in the same launch, under a watchdog
     if world > 1 and args.dp_mode == "all":
         import threading
+        print_lock = threading.Lock()
         modes = {"graph": {"value": line["value"], "ms_per_step": line["ms_per_step"], "exchange_ms": line["exchange_ms"]}} if line else {}
         if line is not None:
             line["dp_modes"] = modes
@@ -871,14 +872,17 @@ def main(argv=None):
             fired = threading.Event()
 
             def bail(mode=mode):
-                # a hung collective cannot be cancelled from Python: print what has been measured and end the rank (every
-                # rank's own watchdog does the same; the launcher sees N clean exits)
+                # a hung collective cannot be cancelled from Python: print what has been measured and end the rank with the
+                # status of a timeout (124, like `timeout(1)` and --launch-timeout) - the launcher and CI must see that a
+                # mode hung, the line on stdout carries the headline and says which one
                 fired.set()
                 if line is not None:
-                    line["dp_modes"][mode] = "timeout after %.0f s (rank watchdog)" % args.dp_extra_timeout
-                    print(json.dumps(line))
-                    sys.stdout.flush()
-                os._exit(0)
+                    with print_lock:
+                        line["dp_modes"][mode] = "timeout after %.0f s (rank watchdog)" % args.dp_extra_timeout
+                        line["partial"] = "dp mode %s timed out; exit status 124" % mode
+                        print(json.dumps(line))
+                        sys.stdout.flush()
+                os._exit(124)
             dog = threading.Timer(args.dp_extra_timeout, bail)
             dog.daemon = True
             dog.start()
@@ -895,7 +899,8 @@ def main(argv=None):
             if fired.is_set():
                 time.sleep(3600)       # the watchdog is printing / exiting
             if line is not None:
-                line["dp_modes"][mode] = entry
+                with print_lock:       # (the watchdog thread may be printing `line`)
+                    line["dp_modes"][mode] = entry
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

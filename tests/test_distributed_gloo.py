@@ -48,7 +48,7 @@ def _worker_flat(rank, world, port, q, overlap=True):
     bdist = _setup(rank, world, port)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
-    if rank == 1:                      # ranks start different: attach() must broadcast rank 0's weights
+    if rank >= 1:                      # ranks start different: attach() must broadcast rank 0's weights
         for p in net.parameters():
             p.data.add_(1.0)
     tr = _Holder()
@@ -61,8 +61,8 @@ def _worker_flat(rank, world, port, q, overlap=True):
     if overlap:
         assert len(tr.grad_sync.buckets) >= 2
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(8, 6, generator=g)
-    y = torch.randn(8, 1, generator=g)
+    x = torch.randn(4 * world, 6, generator=g)
+    y = torch.randn(4 * world, 1, generator=g)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     flat.zero()
     assert all(p.grad is None for p in net.parameters())
@@ -106,7 +106,7 @@ def _worker_uneven_graphs(rank, world, port, q):
     x = torch.ones(4, 6) * (rank + 1)
     flat.zero()
     h = torch.tanh(l1(x))
-    loss = (l2(h) ** 2).mean() if rank == 0 else (h ** 2).mean()
+    loss = (l2(h) ** 2).mean() if rank % 2 == 0 else (h ** 2).mean()      # odd ranks never touch the last layer
     loss.backward()
     tr.grad_sync()
     # reference: average of the two ranks' gradients computed locally
@@ -116,7 +116,7 @@ def _worker_uneven_graphs(rank, world, port, q):
         a1.load_state_dict(l1.state_dict()); a2.load_state_dict(l2.state_dict())
         xr = torch.ones(4, 6) * (r + 1)
         hr = torch.tanh(a1(xr))
-        ((a2(hr) ** 2).mean() if r == 0 else (hr ** 2).mean()).backward()
+        ((a2(hr) ** 2).mean() if r % 2 == 0 else (hr ** 2).mean()).backward()
         grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                 for p in list(a1.parameters()) + list(a2.parameters())]))
     want = sum(grads) / world
@@ -222,13 +222,22 @@ def test_flat_gradient_average_world2():
         assert err < 1e-6, (rank, err)
 
 
-def test_overlapped_bucketed_average_world2():
-    for rank, err in _run(_worker_flat):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_overlapped_bucketed_average(world):
+    """BASELINE's metric is quoted at 1/2/4/8 GPUs: the bucketed exchange at every one of those world sizes (gloo)."""
+    out = _run(_worker_flat, world)
+    assert [r for r, _ in out] == list(range(world))
+    for rank, err in out:
         assert err < 1e-6, (rank, err)
 
 
-def test_overlapped_average_with_rank_specific_graphs():
-    for rank, err in _run(_worker_uneven_graphs):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_overlapped_average_with_rank_specific_graphs(world):
+    """Bucket order with rank-specific autograd graphs (boosted batches: every rank draws its own frame sets), at 2, 4
+    and 8 ranks: odd ranks never reach the last layer, all ranks must still issue the same collective sequence."""
+    out = _run(_worker_uneven_graphs, world)
+    assert len(out) == world
+    for rank, err in out:
         assert err < 1e-6, (rank, err)
 
 
@@ -236,6 +245,32 @@ def test_overlap_starts_inside_backward_on_the_real_networks():
     for rank, (early, n_buckets, same) in _run(_worker_real_networks):
         assert same
         assert early >= n_buckets - 1, "rank %d launched %d of %d buckets inside backward" % (rank, early, n_buckets)
+
+
+@pytest.mark.parametrize("world,n,batch", [(8, 103, 5), (4, 1001, 12), (8, 39810, 12)])
+def test_loader_shards_a_non_divisible_dataset(world, n, batch):
+    """`order[rank::world]` of one common shuffle with a dataset length that world * batch does not divide (the KITTI
+    split has 39 810 lines): disjoint shards, equal length on every rank, at most world * batch - 1 samples dropped."""
+    from baseboostdepth_amd.datasets import DeviceLoader
+
+    class _DS:
+        epoch = 7
+        is_train = True
+
+        def __len__(self):
+            return n
+
+    seen, lengths = [], set()
+    for rank in range(world):
+        ld = DeviceLoader(_DS(), batch, collate=None, shuffle=True, drop_last=True, num_workers=0, seed=42, rank=rank, world=world)
+        chunks = list(ld._batches())
+        assert all(len(c) == batch for c in chunks) and len(chunks) == len(ld)
+        lengths.add(len(chunks))
+        seen.append({i for c in chunks for i in c})
+    assert len(lengths) == 1, "ranks would run different numbers of steps: %s" % lengths      # (collectives would mis-pair)
+    union = set().union(*seen)
+    assert sum(len(s_) for s_ in seen) == len(union)          # disjoint
+    assert n - len(union) < world * batch
 
 
 def test_loader_shards_indices_by_rank():
