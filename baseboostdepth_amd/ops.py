@@ -436,8 +436,13 @@ def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     ident = torch.empty(plan.NI, H, W, device=target.device, dtype=torch.float32)
     backend._check(target, *frame_tensors.values())
     frames = frame_pointer_array(frame_tensors)
-    backend.run("bbd_identity_loss_grouped_fwd", target, frames, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
-                plan.B, ptr(ident), H, W, int(no_ssim))
+    if _experiment("BBD_IDENT_GROUPED", "0") == "1":       # A/B: round 3's tiled form, one workgroup per (target sample, tile)
+        backend.run("bbd_identity_loss_grouped_fwd", target, frames, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
+                    plan.B, ptr(ident), H, W, int(no_ssim))
+    else:
+        # the streaming form (round 5): a wave per (item, 128-column band, 8 rows), register windows, no LDS
+        backend.run("bbd_identity_loss_fwd", target, frames, ptr(target), ptr(tb["items"]), plan.NI, ptr(ident), H, W,
+                    int(no_ssim))
     return ident
 
 

@@ -40,7 +40,7 @@ SCALES = [0, 1, 2, 3]
 
 def make_options(batch, device_index, config):
     import types
-    config = config.replace("_fresh", "")
+    config = config.replace("_fresh", "").replace("_coherent", "")
     boosted = config not in ("md2", "vit")
     one_scale = config in ("boosted", "boosted15")
     return types.SimpleNamespace(
@@ -338,6 +338,8 @@ def kernel_table(timer, plan, S, config, batch):
 def batch_for(config, batch, rank):
     import random as _random
     draw = _random.Random(1234 + rank)
+    if config.endswith("_coherent"):          # the same draw as the base configuration, stacked canonically
+        return sorted(batch_for(config.replace("_coherent", ""), batch, rank), reverse=True)
     if config in ("md2", "vit"):
         return [1] * batch
     if config == "boosted":
@@ -377,10 +379,22 @@ def run_workload(args, ctx, config, steps, warmup, want_graph, dp_mode):
         want_graph = False
     trainer, opt = build_trainer(want_graph)
     ms = batch_for(config, args.batch, rank)
-    inputs = synthetic_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
+    coherent = config.endswith("_coherent")
+    if coherent:
+        # the regime a TRAINED network produces (coherent arg-min maps, a few live candidates per tile) - constructed:
+        # a planar scene whose frames are true shifts, networks whose heads predict exactly that scene
+        # (synthetic.structured_batch / constant_heads).  Learning rate 0: the optimizer runs the same kernels, the
+        # constructed registration does not drift over the timed steps
+        from baseboostdepth_amd.synthetic import constant_heads, structured_batch
+        constant_heads(trainer)
+        for g in trainer.model_optimizer.param_groups:
+            g["lr"] = 0.0
+        inputs = structured_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
+    else:
+        inputs = synthetic_batch(ms, H, W, opt.scales, device=dev, seed=42 + rank)
     # the identity-candidate noise is drawn INSIDE every step, as the reference does (trainer.py:518-523)
     inputs.pop("noise")
-    if config in ("boosted", "boosted15"):
+    if config in ("boosted", "boosted15", "boosted15_coherent"):
         inputs["cutt"] = torch.tensor(1.35)      # epoch >= 10 regime: incremental + partial pose modes
     backend = ops.default_backend()
 
@@ -455,12 +469,20 @@ def run_workload(args, ctx, config, steps, warmup, want_graph, dp_mode):
         rank_ms = [float(e.item()) / steps * 1e3 for e in every]
         elapsed, median_ms, exchange_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
     S = len(opt.scales)
-    kernels, dom, roofline, cc = kernel_table(timer, trainer.plan, S, config, args.batch)
+    live = None
+    if config.startswith("boosted") or config.startswith("trimin"):
+        # how many candidates win at least one pixel of a backward tile (32x16): what the backward's candidate loop sees
+        from baseboostdepth_amd.synthetic import live_candidates_per_tile
+        with torch.no_grad():
+            out_l, _ = trainer.process_batch(dict(inputs))
+        live = live_candidates_per_tile(out_l[("bbd", "argmin")][0])
+        del out_l
+    kernels, dom, roofline, cc = kernel_table(timer, trainer.plan, S, config.replace("_coherent", ""), args.batch)
     dp = "single" if world == 1 else (("graph-overlap" if trainer.dp_capture else "graph") if trainer.use_graph else "overlap")
     return {"config": config, "trainer": trainer, "opt": opt, "inputs": inputs, "ms": ms, "S": S, "steps": steps, "warmup": warmup,
             "elapsed": elapsed, "median_ms": median_ms, "rank_ms": rank_ms, "kernels": kernels, "dominant": dom, "roofline": roofline,
             "constants": cc, "graph_note": graph_note, "kernel_timing": kernel_timing, "exchange_ms": exchange_ms,
-            "reduce_op": reduce_op, "overlapped": overlapped, "dp_mode": dp,
+            "reduce_op": reduce_op, "overlapped": overlapped, "dp_mode": dp, "live_candidates_per_tile": live,
             "value": args.batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3}
 
 
@@ -656,6 +678,9 @@ def release(res):
 
 
 def workload_name(config, batch, S, ms):
+    if config.endswith("_coherent"):
+        return workload_name(config.replace("_coherent", ""), batch, S, ms) + (
+            "; COHERENT arg-min regime: planar scene, frames = true shifts, heads predicting it (synthetic.structured_batch), lr 0")
     net = "MonoViT (mpvit_small) encoder + HR DepthDecoder" if config == "vit" else "MD2 ResNet-18 encoder+DepthDecoder"
     if config in ("md2", "vit"):
         return "%s+PoseNet training step, 640x192, per-GPU batch %d, frames [0,-1,1], %d scales, HIP fused warp+SSIM+min" % (net, batch, S)
@@ -670,7 +695,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (BASELINE config 2: 12)")
     ap.add_argument("--config", default="md2", choices=["md2", "boosted", "boosted15", "trimin5", "vit", "boosted15_fresh",
-                                                        "trimin5_fresh", "md2_loader"],
+                                                        "trimin5_fresh", "md2_loader", "boosted15_coherent"],
                     help="md2 = BASELINE configs[1]/[3] (the headline); configs[2] (SURVEY 8d config 3): boosted = "
                          "worst case m=7 for every sample, boosted15 = the epoch-15 offset distribution (standard "
                          "draw, fixed seed), trimin5 = early curriculum (epoch 5: m in {0,1,2}, 4 scales); "
@@ -822,7 +847,7 @@ def main(argv=None):
     if world == 1 and args.config == "md2" and not args.no_secondary:
         secondary, t_sec = [], time.perf_counter()
         frozen = {"md2": res["value"]}
-        for cfg in ("boosted", "boosted15", "trimin5", "vit", "boosted15_fresh", "trimin5_fresh", "md2_loader"):
+        for cfg in ("boosted", "boosted15", "boosted15_coherent", "trimin5", "vit", "boosted15_fresh", "trimin5_fresh", "md2_loader"):
             if time.perf_counter() - t_sec > args.secondary_budget:
                 secondary.append({"config": cfg, "skipped": "secondary budget of %.0f s used up" % args.secondary_budget})
                 continue
@@ -846,6 +871,7 @@ def main(argv=None):
                     "value": round(r["value"], 2), "unit": "images/sec", "ms_per_step": round(r["ms_per_step"], 3),
                     "ms_per_step_median": round(r["median_ms"], 3), "steps": r["steps"], "warmup": r["warmup"],
                     "step_graph": r["graph_note"] if r["graph_note"] is not None else bool(r["trainer"].use_graph),
+                    **({"live_candidates_per_backward_tile": r["live_candidates_per_tile"]} if r.get("live_candidates_per_tile") else {}),
                     "roofline": {k: rf.get(k) for k in ("bound", "limiter", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")},
                     "kernels": {k: {f: v[f] for f in ("mean_ms", "alg_MB_per_launch", "frac") if f in v} for k, v in r["kernels"].items()},
                     "kernels_constants_stale": bool(r["constants"] and r["constants"]["stale"]),

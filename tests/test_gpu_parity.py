@@ -548,3 +548,30 @@ def test_disparity_mode_equals_depth_plane_mode(name, backend):
     for s in ca.scales:
         if ca.has("out/depth/%d" % s):
             assert torch.equal(oa[("depth", 0, s)].cpu(), ca.expected("out/depth/%d" % s))
+
+
+@pytest.mark.parametrize("H,W,no_ssim", [(37, 131, False), (16, 67, False), (5, 3, False), (9, 130, True), (192, 640, False),
+                                         (24, 258, False)])
+def test_streaming_identity_pass_equals_the_tiled_forms_on_ragged_sizes(backend, H, W, no_ssim):
+    """Round 5's identity pre-pass (bbd_identity_loss_fwd: register windows, a wave per 128-column band x 8 rows, 16-byte
+    unaligned row loads, reflection on the edge lanes) against round 3's tiled, LDS-staged form
+    (bbd_identity_loss_grouped_fwd) bit for bit - odd widths, widths that are not a multiple of the band, images
+    smaller than one band / one row chunk, --no_ssim."""
+    from baseboostdepth_amd._lib import ptr
+    from baseboostdepth_amd import ops
+    from baseboostdepth_amd.plan import get_plan
+    torch.manual_seed(H * 1000 + W)
+    ms = [2, 1, 0, 3]
+    plan = get_plan([[0, "s"] if m == 0 else [0, m, -m] for m in ms], True, True)
+    frames = {f: (torch.round(torch.rand(len(plan.owners(f)), 3, H, W, device=DEV) * 255) / 255) for f in plan.frames}
+    target = torch.round(torch.rand(len(ms), 3, H, W, device=DEV) * 255) / 255
+    tb = plan.tables(target.device)
+    fp = ops.frame_pointer_array(frames)
+    a = torch.full((plan.NI, H, W), float("nan"), device=DEV)
+    b = torch.full((plan.NI, H, W), float("nan"), device=DEV)
+    backend.run("bbd_identity_loss_fwd", target, fp, ptr(target), ptr(tb["items"]), plan.NI, ptr(a), H, W, int(no_ssim))
+    backend.run("bbd_identity_loss_grouped_fwd", target, fp, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]), plan.B,
+                ptr(b), H, W, int(no_ssim))
+    torch.cuda.synchronize()
+    assert not torch.isnan(a).any() and torch.equal(a, b)
+    assert torch.equal(ops.identity_losses(plan, frames, target, no_ssim, backend), a)
