@@ -238,7 +238,8 @@ def structured_batch(ms, H=192, W=640, scales=(0,), device="cpu", seed=42, trimi
                 field = 1 + gain * F.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)[0]
                 img = img * field
                 for _ in range(occluders):
-                    h, w = int(torch.randint(16, 64, (1,), generator=gen, device=device)), int(torch.randint(32, 128, (1,), generator=gen, device=device))
+                    h = int(torch.randint(max(2, H // 12), max(3, H // 3), (1,), generator=gen, device=device))
+                    w = int(torch.randint(max(2, W // 20), max(3, W // 5), (1,), generator=gen, device=device))
                     y0, x0 = int(torch.randint(0, H - h, (1,), generator=gen, device=device)), int(torch.randint(0, W - w, (1,), generator=gen, device=device))
                     img = img.clone()
                     img[:, y0:y0 + h, x0:x0 + w] = foreign[b, :, y0:y0 + h, margin + x0:margin + x0 + w]

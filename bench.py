@@ -564,6 +564,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                 if done in (3, 10) and time.perf_counter() - t0 > pass_budget * done / n_batches * 3:
                     torch.cuda.synchronize()      # far over budget (e.g. MIOpen compiling solvers for unseen row counts)
                     break
+            t_host = time.perf_counter() - t0          # the training thread is done enqueueing here
             torch.cuda.set_sync_debug_mode("default")
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -572,6 +573,9 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
         g1 = tr.graph_stats
         passes.append({"pass": p + 1, "steps": done, "ms_per_step": round(dt / done * 1e3, 3),
                        "images_per_sec": round(args.batch * done / dt, 2),
+                       # how long the training thread took to ENQUEUE the steps (if this is well below ms_per_step the loop is
+                       # bound by the GPU, not by the host)
+                       "host_enqueue_ms_per_step": round(t_host / done * 1e3, 3),
                        "table_uploads_per_step": round((st["packed_uploads"] + st["single_uploads"]) / done, 3),
                        "table_bytes_per_step": int(st["packed_words"] * 4 / done),
                        "table_build_ms_per_step": round(st.get("build_ms", 0.0) / done, 3),
@@ -819,6 +823,7 @@ def main(argv=None):
                                 "tuning_at_run_time": bool(torch.cuda.tunable.tuning_is_enabled()
                                                            and torch.cuda.tunable.is_enabled())}},
             "roofline": roofline, "kernels": kernels, "kernel_timing": res["kernel_timing"],
+            **({"live_candidates_per_backward_tile": res["live_candidates_per_tile"]} if res.get("live_candidates_per_tile") else {}),
             # what in `kernels` is measured by THIS run (mean_ms, achieved_GBps, frac) and what is read from committed files
             "kernels_constants": "pmc_traffic_MB_per_launch and the instruction count behind issue_bound_ms come from the "
                                  "committed rocprofv3 PMC pass of this workload (roofline.traffic_source); the cycles per "

@@ -160,3 +160,73 @@ def test_canonicalize_permutes_every_tensor_by_its_own_rows():
     assert float(inp["cutt"]) == float(ref["cutt"])
     # a second call composes: the batch is canonical now
     assert tr.canonicalize(inp) is None
+
+
+def test_pose_multipliers_follow_the_trainer_pose_modes():
+    """`synthetic.pose_multipliers` runs Trainer.predict_poses with unit-translation networks: chained steps add up,
+    negative offsets beyond -1 keep the identity pose in incremental mode (trainer.py:364), the partial swap leaves the
+    chain only where |f| = m - 2 (trainer.py:415-418; canonical order: row = sample)."""
+    from baseboostdepth_amd.synthetic import pose_multipliers
+    ms = [7, 5, 3, 1]
+    frames = sorted(list(range(-7, 8)), key=abs)
+    k = pose_multipliers(ms, frames)
+    assert k[(0, 5)] == 5.0 and k[(0, -5)] == 0.0                 # |f| = m - 2: chain kept (empty for negative offsets)
+    assert k[(0, 7)] == 1.0 and k[(0, -7)] == -1.0                # swapped for the direct call's translation
+    assert k[(1, 3)] == 3.0 and k[(1, -3)] == 0.0 and k[(1, 5)] == 1.0
+    assert k[(2, 1)] == 1.0 and k[(2, -1)] == -1.0 and k[(3, 1)] == 1.0
+    plain = pose_multipliers([2, 1], [0, 1, -1, 2, -2, "s"], incremental=False, partial=False, cutt=0.3)
+    assert plain == {(0, 1): 1.0, (1, 1): 1.0, (0, -1): -1.0, (1, -1): -1.0, (0, 2): 1.0, (0, -2): -1.0}
+
+
+def test_structured_batch_registers_the_true_pose_warps():
+    """On `synthetic.structured_batch` with the scene's disparity and the poses the trainer would use, the true-pose
+    warps of the host port register (mean minimum loss far below the random-texture level) and the arg-min map is
+    coherent: most backward tiles see a handful of live candidates, true-pose candidates win most pixels."""
+    import types
+    import torch.nn as nn
+    from host_port import HostPortBackend
+    from baseboostdepth_amd.synthetic import (STRUCT_DISP, live_candidates_per_tile, structured_batch, structured_translation,
+                                              synthetic_batch)
+    from baseboostdepth_amd.trainer import Trainer
+    H, W, ms = 64, 192, [7, 5, 3, 2]
+    tx = structured_translation(H, W)
+
+    class _Enc(nn.Module):
+        def forward(self, x):
+            return [x.new_zeros(x.shape[0], 1, 1, 1)]
+
+    class _Dec(nn.Module):
+        def forward(self, feats):
+            n = feats[0][0].shape[0]
+            t = torch.zeros(n, 2, 1, 3)
+            t[:, 0, 0, 0] = tx
+            return torch.zeros(n, 2, 1, 3), t
+
+    def run(inputs):
+        tr = Trainer.__new__(Trainer)
+        tr.opt = types.SimpleNamespace(height=H, width=W, scales=[0], trimin=True, decomp=True, pose_error=5.5, incremental_skip=True,
+                                       partial_skip=True, batched_pose=False, min_depth=0.1, max_depth=100.0, no_ssim=False,
+                                       disparity_smoothness=1e-3, materialize_warps=False,
+                                       frame_ids=sorted(inputs["frames"], key=lambda f: 99 if f == "s" else abs(f)))
+        tr.device, tr.backend, tr.num_scales = torch.device("cpu"), HostPortBackend(), 4
+        tr.models = {"pose_encoder": _Enc(), "pose": _Dec()}
+        tr.valid_frames_trimin(inputs)
+        out = tr.predict_poses(inputs)
+        out[("disp", 0)] = torch.full((len(ms), 1, H, W), STRUCT_DISP)
+        out.update(tr.generate_images_pred(inputs, out))
+        return tr, out
+
+    tr, out = run(structured_batch(ms, H, W, (0,), seed=3))
+    arg = out[("bbd", "argmin")][0]
+    hist = live_candidates_per_tile(arg)
+    mean_live = sum(k * v for k, v in hist.items()) / sum(hist.values())
+    n_true = sum(int((arg[b] < sum(1 for kind, _ in tr.plan.cand_names[b] if kind == "T")).sum()) for b in range(len(ms)))
+    assert n_true >= 0.8 * arg.numel()
+    coherent_loss = float(out[("bbd", "to_optimise")][0].mean())
+    rand = synthetic_batch(ms, H, W, (0,), seed=3)
+    rand["cutt"] = torch.tensor(1.35)
+    _, out_r = run(rand)
+    assert coherent_loss < 0.5 * float(out_r[("bbd", "to_optimise")][0].mean())
+    hist_r = live_candidates_per_tile(out_r[("bbd", "argmin")][0])
+    mean_live_r = sum(k * v for k, v in hist_r.items()) / sum(hist_r.values())
+    assert mean_live < 0.7 * mean_live_r and mean_live < 8, (hist, hist_r)
