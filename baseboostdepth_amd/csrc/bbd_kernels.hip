@@ -724,27 +724,39 @@ __global__ __launch_bounds__(NT) void identity_loss_grouped_kernel(FramePtrs fra
 constexpr int IROWS = 8;             // output rows per wave
 constexpr int IBAND = 128;           // columns per wave (2 per lane)
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// Window columns x0-1 .. x0+2 of a lane: ALWAYS one 16-byte load at a clamped base column (every lane issues the same
+// instruction: the wait counters stay countable, so the next row's loads can be in flight under the current row's
+// arithmetic - a divergent scalar path for the edge lanes forced s_waitcnt vmcnt(0) after every batch of loads); the two
+// edge lanes of an image row then pick their reflected columns out of the four loaded ones (`pick`, wave-uniform branch).
 struct IdentCols {
-  int c0, c1, c2, c3;                // column indices of window columns x0-1 .. x0+2 (reflected / clamped)
-  bool vec;                          // contiguous and in range: one 16-byte load
+  int base;                          // first loaded column: clamp(x0 - 1, 0, W - 4)
+  int i0, i1, i2, i3;                // which loaded element is window column k (0,1,2,3 for interior lanes)
 };
-__device__ __forceinline__ void ident_row(const float* __restrict__ row, const IdentCols& ic, float out[4]) {
-  if (ic.vec) {
-    const f4u v = *reinterpret_cast<const f4u*>(row + ic.c0);
-    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+__device__ __forceinline__ float ident_pick(const f4u& v, int i) {
+  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ f4u ident_row(const float* __restrict__ row, const IdentCols& ic) {
+  return *reinterpret_cast<const f4u*>(row + ic.base);
+}
+// raw loaded vector -> window columns (called where the values are first needed, not where the load is issued)
+__device__ __forceinline__ void ident_cols(const f4u& v, const IdentCols& ic, bool permute, float out[4]) {
+  if (permute) {                     // (wave-uniform: only waves that hold an edge lane)
+    out[0] = ident_pick(v, ic.i0); out[1] = ident_pick(v, ic.i1); out[2] = ident_pick(v, ic.i2); out[3] = ident_pick(v, ic.i3);
   } else {
-    out[0] = row[ic.c0]; out[1] = row[ic.c1]; out[2] = row[ic.c2]; out[3] = row[ic.c3];
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
   }
 }
 __global__ __launch_bounds__(NT) void identity_rows_kernel(FramePtrs frames, const float* __restrict__ target,
                                                            const int32_t* __restrict__ items, float* __restrict__ ident,
-                                                           int H, int W, int nbands, int nchunks, int nwaves, int no_ssim) {
-  const int wid = xcd_work_item(blockIdx.x, gridDim.x) * (NT / 64) + ((int)threadIdx.x >> 6);
-  if (wid >= nwaves) return;
-  const int per_item = nbands * nchunks;
-  const int item = wid / per_item;
-  const int rem = wid - item * per_item;
-  const int chunk = rem / nbands, band = rem - chunk * nbands;         // a sample's bands of one row chunk side by side
+                                                           int H, int W, int nbands, int nchunks, int blocks_per_item,
+                                                           int no_ssim) {
+  // a block's four waves belong to ONE item (the item index depends on blockIdx only: its descriptor and the frame
+  // pointer are scalar loads); items are dealt to the XCDs in contiguous ranges
+  const int vb = xcd_work_item(blockIdx.x, gridDim.x);
+  const int item = vb / blocks_per_item;
+  const int rem = (vb - item * blocks_per_item) * (NT / 64) + ((int)threadIdx.x >> 6);
+  if (rem >= nbands * nchunks) return;
+  const int chunk = rem / nbands, band = rem - chunk * nbands;         // the bands of one row chunk side by side
   const int b = uniform_load(items + item * 4 + 0), slot = uniform_load(items + item * 4 + 1), srow = uniform_load(items + item * 4 + 2);
   const int hw = H * W;
   const float* tg = target + (size_t)b * 3 * hw;
@@ -754,38 +766,55 @@ __global__ __launch_bounds__(NT) void identity_rows_kernel(FramePtrs frames, con
   const bool active = x0 < W;
   IdentCols ic;
   {
-    const int xc = active ? x0 : (W - 1);      // (bbd_reflect clamps: lanes beyond the image read valid addresses)
-    ic.vec = active && xc >= 1 && xc + 2 <= W - 1;
-    ic.c0 = bbd_reflect(xc - 1, W);
-    ic.c1 = xc;
-    ic.c2 = bbd_reflect(xc + 1, W);
-    ic.c3 = bbd_reflect(xc + 2, W);
+    const int xc = active ? x0 : (W - 1);      // (lanes beyond the image read valid addresses; nothing of theirs is stored)
+    int cb = xc - 1;
+    cb = cb < 0 ? 0 : (cb > W - 4 ? W - 4 : cb);
+    ic.base = cb;
+    ic.i0 = bbd_reflect(xc - 1, W) - cb;
+    ic.i1 = xc - cb;
+    ic.i2 = bbd_reflect(xc + 1, W) - cb;
+    ic.i3 = bbd_reflect(xc + 2, W) - cb;
+    // (an odd-width image's last lane: column x0 + 2 reflects to W - 3 < base for W = 4 only; its pixel does not exist)
+    ic.i0 = ic.i0 < 0 ? 0 : (ic.i0 > 3 ? 3 : ic.i0);
+    ic.i2 = ic.i2 < 0 ? 0 : (ic.i2 > 3 ? 3 : ic.i2);
+    ic.i3 = ic.i3 < 0 ? 0 : (ic.i3 > 3 ? 3 : ic.i3);
   }
+  const bool permute = __builtin_amdgcn_ballot_w64(ic.i0 != 0 || ic.i1 != 1 || ic.i2 != 2 || ic.i3 != 3) != 0ull;
   const int y0 = chunk * IROWS;
   float X[3][3][4], Y[3][3][4];       // [channel][window row][window column]
+  {
+    f4u rx[3][3], ry[3][3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int yc = bbd_reflect(y0 - 1 + r, H);
+    for (int r = 0; r < 3; ++r) {
+      const int yc = bbd_reflect(y0 - 1 + r, H);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      ident_row(sr + ch * hw + yc * W, ic, X[ch][r]);
-      ident_row(tg + ch * hw + yc * W, ic, Y[ch][r]);
+      for (int ch = 0; ch < 3; ++ch) {
+        rx[ch][r] = ident_row(sr + ch * hw + yc * W, ic);
+        ry[ch][r] = ident_row(tg + ch * hw + yc * W, ic);
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        ident_cols(rx[ch][r], ic, permute, X[ch][r]);
+        ident_cols(ry[ch][r], ic, permute, Y[ch][r]);
+      }
   }
   float* out = ident + (size_t)item * hw;
   const bool vec_store = active && (x0 + 2 <= W) && ((W & 1) == 0);
-  for (int i = 0; i < IROWS; ++i) {
+  const int rows = (H - y0) < IROWS ? (H - y0) : IROWS;
+  for (int i = 0; i < rows; ++i) {
     const int y = y0 + i;
-    if (y >= H) break;
-    // the row after next: in flight while this row is evaluated
-    float nx[3][4], ny[3][4];
-    const bool more = (i + 1 < IROWS) && (y + 1 < H);
-    if (more) {
-      const int yc = bbd_reflect(y + 2, H);
+    // the row after next: in flight while this row is evaluated (the last iteration re-reads a row it does not use:
+    // the same instruction stream every iteration)
+    f4u rnx[3], rny[3];
+    {
+      const int yc = bbd_reflect(y + 2 < H + 1 ? y + 2 : H, H);
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        ident_row(sr + ch * hw + yc * W, ic, nx[ch]);
-        ident_row(tg + ch * hw + yc * W, ic, ny[ch]);
+        rnx[ch] = ident_row(sr + ch * hw + yc * W, ic);
+        rny[ch] = ident_row(tg + ch * hw + yc * W, ic);
       }
     }
     float ssim[2][3], l1[2][3];
@@ -820,14 +849,16 @@ __global__ __launch_bounds__(NT) void identity_rows_kernel(FramePtrs frames, con
       if (vec_store) *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
       else { o[0] = o0; if (x0 + 1 < W) o[1] = o1; }
     }
-    if (more) {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
+    for (int ch = 0; ch < 3; ++ch) {
+      float nx[4], ny[4];
+      ident_cols(rnx[ch], ic, permute, nx);
+      ident_cols(rny[ch], ic, permute, ny);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          X[ch][0][c] = X[ch][1][c]; X[ch][1][c] = X[ch][2][c]; X[ch][2][c] = nx[ch][c];
-          Y[ch][0][c] = Y[ch][1][c]; Y[ch][1][c] = Y[ch][2][c]; Y[ch][2][c] = ny[ch][c];
-        }
+      for (int c = 0; c < 4; ++c) {
+        X[ch][0][c] = X[ch][1][c]; X[ch][1][c] = X[ch][2][c]; X[ch][2][c] = nx[c];
+        Y[ch][0][c] = Y[ch][1][c]; Y[ch][1][c] = Y[ch][2][c]; Y[ch][2][c] = ny[c];
+      }
     }
   }
 }
@@ -2520,7 +2551,8 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   if (NI == 0) return 0;
   FramePtrs fp;
   if (fill_frames(frames, &fp)) return BBD_E_BADARG;
-  if (identity_form() == 0) {          // (BBD_EXPERIMENT=1 BBD_IDENT_FORM=0: round 1's tiled form, one workgroup per (item, tile))
+  if (identity_form() == 0 || W < 4) {  // (BBD_EXPERIMENT=1 BBD_IDENT_FORM=0, or an image narrower than one 16-byte load:
+                                        //  round 1's tiled form, one workgroup per (item, tile))
     const int ntiles = bbd_num_tiles(H, W);
     hipLaunchKernelGGL(identity_loss_kernel, dim3((unsigned)(NI * ntiles)), dim3(NT), 0,
                        static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim,
@@ -2528,11 +2560,11 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
     return launch_status();
   }
   const int nbands = (W + IBAND - 1) / IBAND, nchunks = (H + IROWS - 1) / IROWS;
-  const long nwaves = (long)NI * nbands * nchunks;
-  if (nwaves > 0x7fffffffL) return BBD_E_BADARG;
-  const unsigned blocks = (unsigned)((nwaves + NT / 64 - 1) / (NT / 64));
-  hipLaunchKernelGGL(identity_rows_kernel, dim3(blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), fp, target, items,
-                     ident, H, W, nbands, nchunks, (int)nwaves, no_ssim);
+  const int blocks_per_item = (nbands * nchunks + NT / 64 - 1) / (NT / 64);
+  const long blocks = (long)NI * blocks_per_item;
+  if (blocks > 0x7fffffffL) return BBD_E_BADARG;
+  hipLaunchKernelGGL(identity_rows_kernel, dim3((unsigned)blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), fp, target,
+                     items, ident, H, W, nbands, nchunks, blocks_per_item, no_ssim);
   return launch_status();
 }
 

@@ -186,12 +186,12 @@ class Trainer:
                 # the flat buffer in the split-graph loop, the same buckets in the same order with captured collectives)
                 self._sightings.put(key, seen + 1)
                 self.graph_stats["eager"] += 1
-                return self._eager_step(inputs)
+                return self._eager_step_off_default_stream(inputs)
         if entry is None:
             # bound the cache: the least recently replayed signature goes first
             while len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
-            if self._graph_pool is None:
+            if self._graph_pool is None and os.environ.get("BBD_GRAPH_SHARED_POOL", "1") != "0":
                 self._graph_pool = torch.cuda.graph_pool_handle()
             pool = self._graph_pool
             self.graph_stats["captures"] += 1
@@ -329,6 +329,21 @@ class Trainer:
                                    % (num / den, "" if not ok else "; another rank failed the check"))
         self.step += 1
         return outputs, losses
+
+    def _eager_step_off_default_stream(self, inputs):
+        """An eager step of a trainer that ALSO captures step graphs runs on a side stream of its own, never on the
+        default stream: autograd binds every parameter's AccumulateGrad node to the stream of the step that first used it
+        and keeps it while any loss / output of that step is alive - a later capture would then find gradient accumulation
+        queued on the legacy default stream in the middle of a capturing stream (hipGraph capture dies in capture_end)."""
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_eager_stream", None) is None:
+            self._eager_stream = torch.cuda.Stream(device=self.device)
+        side = self._eager_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            result = self._eager_step(inputs)
+        cur.wait_stream(side)
+        return result
 
     def train_step(self, inputs):
         """One optimisation step on a collated batch, as the body of `run_epoch` does it.  The samples are taken in

@@ -99,7 +99,9 @@ def test_canonical_order_computes_the_callers_batch():
 
 def test_signatures_are_captured_on_their_second_sighting(monkeypatch):
     """`graph_capture_after = 1`: a signature's first batch runs eagerly, its second is captured, later ones replay -
-    and the parameters after the sequence equal the all-eager loop's (deterministic convolution solvers)."""
+    and the parameters after the sequence EQUAL the all-eager loop's, bit for bit (deterministic convolution solvers; the
+    identity noise handed in with the batch - drawn inside the step it comes from different generator offsets under
+    capture, and this recipe's near-ties between identity candidates turn 1e-5 of noise into different arg-mins)."""
     from baseboostdepth_amd.trainer import Trainer
     _deterministic_convolutions(monkeypatch)
     H, W, B = 96, 160, 4
@@ -115,13 +117,14 @@ def test_signatures_are_captured_on_their_second_sighting(monkeypatch):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             for i, ms in enumerate(seq):
-                _, losses = tr.train_step(_boosted_batch(ms, H, W, [0, 1, 2, 3], 60 + i, 0.3))
+                batch = _boosted_batch(ms, H, W, [0, 1, 2, 3], 60 + i, 0.3)
+                batch["noise"] = torch.randn(B, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(100 + i)) * 1e-5
+                _, losses = tr.train_step(batch)
         torch.cuda.synchronize()
-        return torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"]), tr
+        return torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"].detach()), tr
 
     pe, le, _ = run(False)
     pg, lg, trg = run(True)
     assert trg.graph_stats == {"eager": 2, "captures": 2, "replays": 4}, trg.graph_stats
     assert trg.step == len(seq) and len(trg._graphs) == 2
-    assert abs(le - lg) <= 1e-5 * abs(le)
-    assert float((pe - pg).abs().max()) <= 1e-5 * float(pe.abs().max())
+    assert le == lg and torch.equal(pe, pg)

@@ -367,8 +367,11 @@ def test_padded_pose_pass_equals_the_exact_one():
     Tb, gb, bb = run(16)               # 9 rows -> 16
     for a, b in zip(Ta, Tb):
         assert float((a - b).abs().max()) < 1e-6, float((a - b).abs().max())
-    for a, b in zip(ba, bb):
-        assert torch.equal(a, b)
+    for a, b in zip(ba, bb):           # (MIOpen picks its solvers per batch size: the activations agree to rounding, and so
+        if a.is_floating_point():      #  do the running statistics; the update COUNT is exact - the padding group is not counted)
+            assert _rel(a.float(), b.float()) < 1e-5
+        else:
+            assert torch.equal(a, b)
     for a, b in zip(ga, gb):           # MIOpen picks solvers per batch size: convolution weight gradients to rounding
         assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-7
 
