@@ -711,158 +711,6 @@ __global__ __launch_bounds__(NT) void identity_loss_grouped_kernel(FramePtrs fra
   }
 }
 
-// Round 5, the streaming form (the training path): NO LDS, no barrier.  The launch is small - 83 MB for MD2, 16 us at 5 TB/s,
-// about the time ONE dependent load -> stage -> barrier -> compute -> store chain of the tiled form takes - so what counts is
-// that every wave's loads are independent of each other and of any other wave: a WAVE owns a band of 128 columns x IROWS rows
-// of one identity item, a lane a 2-pixel strip.  A lane reads the four columns x0-1 .. x0+2 of a row as ONE 16-byte load
-// (4-byte aligned: neighbouring lanes overlap by half, served by L1), keeps the three live rows of source and target of all
-// three channels in registers (72 values) and walks down the band one output row at a time, the next row's six loads in
-// flight while the current row's SSIM runs.  The 3x3 sums run in the reference's row-major order (the tiled form's
-// strip_loss<RESTAT>: the same bits).  Reflection: row indices are wave-uniform; the two edge lanes of an image row take
-// the four-scalar path.  Work order: item-major, dealt to the XCDs in contiguous ranges (the identity candidates of a
-// target sample are consecutive items and re-read its target rows from one L2).
-constexpr int IROWS = 8;             // output rows per wave
-constexpr int IBAND = 128;           // columns per wave (2 per lane)
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-// Window columns x0-1 .. x0+2 of a lane: ALWAYS one 16-byte load at a clamped base column (every lane issues the same
-// instruction: the wait counters stay countable, so the next row's loads can be in flight under the current row's
-// arithmetic - a divergent scalar path for the edge lanes forced s_waitcnt vmcnt(0) after every batch of loads); the two
-// edge lanes of an image row then pick their reflected columns out of the four loaded ones (`pick`, wave-uniform branch).
-struct IdentCols {
-  int base;                          // first loaded column: clamp(x0 - 1, 0, W - 4)
-  int i0, i1, i2, i3;                // which loaded element is window column k (0,1,2,3 for interior lanes)
-};
-__device__ __forceinline__ float ident_pick(const f4u& v, int i) {
-  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
-}
-__device__ __forceinline__ f4u ident_row(const float* __restrict__ row, const IdentCols& ic) {
-  return *reinterpret_cast<const f4u*>(row + ic.base);
-}
-// raw loaded vector -> window columns (called where the values are first needed, not where the load is issued)
-__device__ __forceinline__ void ident_cols(const f4u& v, const IdentCols& ic, bool permute, float out[4]) {
-  if (permute) {                     // (wave-uniform: only waves that hold an edge lane)
-    out[0] = ident_pick(v, ic.i0); out[1] = ident_pick(v, ic.i1); out[2] = ident_pick(v, ic.i2); out[3] = ident_pick(v, ic.i3);
-  } else {
-    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-  }
-}
-__global__ __launch_bounds__(NT) void identity_rows_kernel(FramePtrs frames, const float* __restrict__ target,
-                                                           const int32_t* __restrict__ items, float* __restrict__ ident,
-                                                           int H, int W, int nbands, int nchunks, int blocks_per_item,
-                                                           int no_ssim) {
-  // a block's four waves belong to ONE item (the item index depends on blockIdx only: its descriptor and the frame
-  // pointer are scalar loads); items are dealt to the XCDs in contiguous ranges
-  const int vb = xcd_work_item(blockIdx.x, gridDim.x);
-  const int item = vb / blocks_per_item;
-  const int rem = (vb - item * blocks_per_item) * (NT / 64) + ((int)threadIdx.x >> 6);
-  if (rem >= nbands * nchunks) return;
-  const int chunk = rem / nbands, band = rem - chunk * nbands;         // the bands of one row chunk side by side
-  const int b = uniform_load(items + item * 4 + 0), slot = uniform_load(items + item * 4 + 1), srow = uniform_load(items + item * 4 + 2);
-  const int hw = H * W;
-  const float* tg = target + (size_t)b * 3 * hw;
-  const float* sr = frames.base[slot] + (size_t)srow * 3 * hw;
-  const int lane = (int)threadIdx.x & 63;
-  const int x0 = band * IBAND + 2 * lane;
-  const bool active = x0 < W;
-  IdentCols ic;
-  {
-    const int xc = active ? x0 : (W - 1);      // (lanes beyond the image read valid addresses; nothing of theirs is stored)
-    int cb = xc - 1;
-    cb = cb < 0 ? 0 : (cb > W - 4 ? W - 4 : cb);
-    ic.base = cb;
-    ic.i0 = bbd_reflect(xc - 1, W) - cb;
-    ic.i1 = xc - cb;
-    ic.i2 = bbd_reflect(xc + 1, W) - cb;
-    ic.i3 = bbd_reflect(xc + 2, W) - cb;
-    // (an odd-width image's last lane: column x0 + 2 reflects to W - 3 < base for W = 4 only; its pixel does not exist)
-    ic.i0 = ic.i0 < 0 ? 0 : (ic.i0 > 3 ? 3 : ic.i0);
-    ic.i2 = ic.i2 < 0 ? 0 : (ic.i2 > 3 ? 3 : ic.i2);
-    ic.i3 = ic.i3 < 0 ? 0 : (ic.i3 > 3 ? 3 : ic.i3);
-  }
-  const bool permute = __builtin_amdgcn_ballot_w64(ic.i0 != 0 || ic.i1 != 1 || ic.i2 != 2 || ic.i3 != 3) != 0ull;
-  const int y0 = chunk * IROWS;
-  float X[3][3][4], Y[3][3][4];       // [channel][window row][window column]
-  {
-    f4u rx[3][3], ry[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int yc = bbd_reflect(y0 - 1 + r, H);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        rx[ch][r] = ident_row(sr + ch * hw + yc * W, ic);
-        ry[ch][r] = ident_row(tg + ch * hw + yc * W, ic);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        ident_cols(rx[ch][r], ic, permute, X[ch][r]);
-        ident_cols(ry[ch][r], ic, permute, Y[ch][r]);
-      }
-  }
-  float* out = ident + (size_t)item * hw;
-  const bool vec_store = active && (x0 + 2 <= W) && ((W & 1) == 0);
-  const int rows = (H - y0) < IROWS ? (H - y0) : IROWS;
-  for (int i = 0; i < rows; ++i) {
-    const int y = y0 + i;
-    // the row after next: in flight while this row is evaluated (the last iteration re-reads a row it does not use:
-    // the same instruction stream every iteration)
-    f4u rnx[3], rny[3];
-    {
-      const int yc = bbd_reflect(y + 2 < H + 1 ? y + 2 : H, H);
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        rnx[ch] = ident_row(sr + ch * hw + yc * W, ic);
-        rny[ch] = ident_row(tg + ch * hw + yc * W, ic);
-      }
-    }
-    float ssim[2][3], l1[2][3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float nn[2], dd[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float sx = 0.0f, sxx = 0.0f, sxy = 0.0f, ty = 0.0f, tyy = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float v = X[ch][r][j + c], w = Y[ch][r][j + c];
-            sx += v;
-            sxx += v * v;
-            sxy += v * w;
-            ty += w;
-            tyy += w * w;
-          }
-        float my, gy;
-        bbd_ystats(ty, tyy, &my, &gy);
-        bbd_ssim_nd(sx, sxx, sxy, my, gy, &nn[j], &dd[j]);
-        l1[j][ch] = fabsf(Y[ch][1][j + 1] - X[ch][1][j + 1]);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) ssim[j][ch] = no_ssim ? 0.0f : bbd_ssim_from_ratio(bbd_div(nn[j], dd[j]));
-    }
-    const float o0 = bbd_combine(ssim[0], l1[0], no_ssim), o1 = bbd_combine(ssim[1], l1[1], no_ssim);
-    if (active) {
-      float* o = out + (size_t)y * W + x0;
-      if (vec_store) *reinterpret_cast<float2*>(o) = make_float2(o0, o1);
-      else { o[0] = o0; if (x0 + 1 < W) o[1] = o1; }
-    }
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      float nx[4], ny[4];
-      ident_cols(rnx[ch], ic, permute, nx);
-      ident_cols(rny[ch], ic, permute, ny);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        X[ch][0][c] = X[ch][1][c]; X[ch][1][c] = X[ch][2][c]; X[ch][2][c] = nx[c];
-        Y[ch][0][c] = Y[ch][1][c]; Y[ch][1][c] = Y[ch][2][c]; Y[ch][2][c] = ny[c];
-      }
-    }
-  }
-}
-
 // torch.min(dim) as an order-free update: smaller wins, on equal values the smaller id, a NaN wins over numbers and
 // among NaNs the smaller id (= "first index", "NaN wins and sticks" of the sequential form bbd_min_update)
 __device__ __forceinline__ void min_update_any_order(float cand, int id, float* best, int* arg) {
@@ -2480,10 +2328,6 @@ int xcd_remap_enabled(int S) {
   static const int forced = experiment_knob("BBD_XCD_REMAP");
   return forced >= 0 ? forced : (S == 1);
 }
-int identity_form() {
-  static const int forced = experiment_knob("BBD_IDENT_FORM");
-  return forced >= 0 ? forced : 1;
-}
 int fused_fwd_form(int S, int B, int NP, int ntiles) {
   static const int forced = experiment_knob("BBD_FWD_FORM");
   if (forced >= 0 && forced <= 2) return forced;
@@ -2551,20 +2395,10 @@ int bbd_identity_loss_fwd(const void* const* frames, const float* target, const 
   if (NI == 0) return 0;
   FramePtrs fp;
   if (fill_frames(frames, &fp)) return BBD_E_BADARG;
-  if (identity_form() == 0 || W < 4) {  // (BBD_EXPERIMENT=1 BBD_IDENT_FORM=0, or an image narrower than one 16-byte load:
-                                        //  round 1's tiled form, one workgroup per (item, tile))
-    const int ntiles = bbd_num_tiles(H, W);
-    hipLaunchKernelGGL(identity_loss_kernel, dim3((unsigned)(NI * ntiles)), dim3(NT), 0,
-                       static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim,
-                       xcd_remap_enabled(1));
-    return launch_status();
-  }
-  const int nbands = (W + IBAND - 1) / IBAND, nchunks = (H + IROWS - 1) / IROWS;
-  const int blocks_per_item = (nbands * nchunks + NT / 64 - 1) / (NT / 64);
-  const long blocks = (long)NI * blocks_per_item;
-  if (blocks > 0x7fffffffL) return BBD_E_BADARG;
-  hipLaunchKernelGGL(identity_rows_kernel, dim3((unsigned)blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), fp, target,
-                     items, ident, H, W, nbands, nchunks, blocks_per_item, no_ssim);
+  const int ntiles = bbd_num_tiles(H, W);
+  hipLaunchKernelGGL(identity_loss_kernel, dim3((unsigned)(NI * ntiles)), dim3(NT), 0,
+                     static_cast<hipStream_t>(stream), fp, target, items, ident, H, W, ntiles, no_ssim,
+                     xcd_remap_enabled(1));
   return launch_status();
 }
 

@@ -436,13 +436,10 @@ def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     ident = torch.empty(plan.NI, H, W, device=target.device, dtype=torch.float32)
     backend._check(target, *frame_tensors.values())
     frames = frame_pointer_array(frame_tensors)
-    if _experiment("BBD_IDENT_GROUPED", "0") == "1":       # A/B: round 3's tiled form, one workgroup per (target sample, tile)
-        backend.run("bbd_identity_loss_grouped_fwd", target, frames, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
-                    plan.B, ptr(ident), H, W, int(no_ssim))
-    else:
-        # the streaming form (round 5): a wave per (item, 128-column band, 8 rows), register windows, no LDS
-        backend.run("bbd_identity_loss_fwd", target, frames, ptr(target), ptr(tb["items"]), plan.NI, ptr(ident), H, W,
-                    int(no_ssim))
+    # one workgroup per (target sample, tile) walks the sample's identity candidates (round 3).  Round 5 measured a streaming,
+    # LDS-free form against it - slower (tools/experiments/streaming_identity.hip.txt, profiles/r05/identity_forms.txt)
+    backend.run("bbd_identity_loss_grouped_fwd", target, frames, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
+                plan.B, ptr(ident), H, W, int(no_ssim))
     return ident
 
 

@@ -460,7 +460,7 @@ class Trainer:
                                       rand=getattr(opt, "rand", False), is_train=True, scales=opt.scales, kt=True,
                                       naive_mix=True, trimin=opt.trimin,
                                       seed=getattr(opt, "pytorch_random_seed", 0) + 7919 * self._rank_world()[0])
-        collate = datasets.DeviceCollate(opt.height, opt.width, opt.scales, self.device, self.backend)
+        collate = datasets.DeviceCollate(opt.height, opt.width, opt.scales, self.device, self.backend, cache=self.frame_cache())
         # data parallel: every rank shuffles with the SAME seed and takes every world-th index of that
         # order (disjoint shards of one epoch, equal length); augmentation draws are per-rank
         rank, world = self._rank_world()
@@ -469,6 +469,19 @@ class Trainer:
                                      seed=getattr(opt, "pytorch_random_seed", 0),
                                      workers=getattr(opt, "loader_workers", "process"),
                                      rank=rank, world=world)
+
+    def frame_cache(self):
+        """Decoded frames resident in HBM for the life of the trainer (`datasets.FrameCache`): a KITTI frame is decoded once,
+        not once per use per epoch.  `opt.frame_cache_gb` (default 64: the Eigen-Zhou split's ~45 000 distinct frames are
+        63 GB decoded; capped at half of the free device memory; 0 = off, the reference's behaviour)."""
+        if getattr(self, "_frame_cache", None) is None:
+            gb = float(getattr(self.opt, "frame_cache_gb", 64.0))
+            if self.device.type != "cuda" or gb <= 0:
+                return None
+            from . import datasets
+            free, _ = torch.cuda.mem_get_info(self.device)
+            self._frame_cache = datasets.FrameCache(self.device, int(min(gb * (1 << 30), free // 2)))
+        return self._frame_cache
 
     def kitti_val_loader(self):
         """Validation split of trainer.py:127-131 + ground truth of :150-151, built once: `val_files.txt`
@@ -488,7 +501,7 @@ class Trainer:
         ds = datasets.KITTIRAWDataset(datasets.readlines(files), 0, opt.height, opt.width, kt_path=opt.kt_path,
                                       is_train=False, kt=True, naive_mix=True)
         self._val_loader = datasets.DeviceLoader(ds, 16, datasets.DeviceCollate(opt.height, opt.width, [0], self.device,
-                                                                               self.backend),
+                                                                               self.backend, cache=self.frame_cache()),
                                                  shuffle=False, drop_last=False, num_workers=getattr(opt, "num_workers", 8))
         return self._val_loader
 

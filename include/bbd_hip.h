@@ -114,9 +114,7 @@ int bbd_pose_expand(const float* pose, float* proj, int NP, void* stream);
  *   frames  host array[BBD_MAX_FRAME_SLOTS] of device pointers to [n_f,3,H,W] tensors
  *   target  [B,3,H,W]
  *   items   device int32 [NI][4] = {target sample, slot, row, 0}
- *   ident   out [NI,H,W]
- * Round 5: the streaming form - a wave per (item, 128-column band, 8 rows), a lane keeps the three live rows of
- * source and target in registers and walks down its band; no LDS, no barrier (the training path).            */
+ *   ident   out [NI,H,W]                                                            */
 int bbd_identity_loss_fwd(const void* const* frames, const float* target,
                           const int32_t* items, int NI, float* ident,
                           int H, int W, int no_ssim, void* stream);

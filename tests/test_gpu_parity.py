@@ -550,13 +550,11 @@ def test_disparity_mode_equals_depth_plane_mode(name, backend):
             assert torch.equal(oa[("depth", 0, s)].cpu(), ca.expected("out/depth/%d" % s))
 
 
-@pytest.mark.parametrize("H,W,no_ssim", [(37, 131, False), (16, 67, False), (5, 3, False), (9, 130, True), (192, 640, False),
-                                         (24, 258, False)])
-def test_streaming_identity_pass_equals_the_tiled_forms_on_ragged_sizes(backend, H, W, no_ssim):
-    """Round 5's identity pre-pass (bbd_identity_loss_fwd: register windows, a wave per 128-column band x 8 rows, 16-byte
-    unaligned row loads, reflection on the edge lanes) against round 3's tiled, LDS-staged form
-    (bbd_identity_loss_grouped_fwd) bit for bit - odd widths, widths that are not a multiple of the band, images
-    smaller than one band / one row chunk, --no_ssim."""
+@pytest.mark.parametrize("H,W,no_ssim", [(37, 131, False), (16, 67, False), (5, 3, False), (9, 130, True), (192, 640, False)])
+def test_identity_pass_forms_agree_on_ragged_sizes(backend, H, W, no_ssim):
+    """The two entry points of the identity pre-pass - one workgroup per (item, tile), and the grouped form the training
+    path uses (one workgroup per (target sample, tile) walking the sample's items) - bit for bit on odd widths, partial
+    tiles, images smaller than a tile, --no_ssim."""
     from baseboostdepth_amd._lib import ptr
     from baseboostdepth_amd import ops
     from baseboostdepth_amd.plan import get_plan

@@ -76,3 +76,40 @@ def test_worker_processes_with_shared_ring_equal_thread_pool(tmp_path):
             elif not torch.is_tensor(x[k]):
                 assert x[k] == y[k], k
     assert datasets._RING is None                      # ring released at the end of the epoch
+
+
+@pytest.mark.parametrize("capacity_mb", [160, 40])
+def test_frame_cache_batches_equal_uncached_ones_and_decode_each_frame_once(tmp_path, capacity_mb):
+    """`datasets.FrameCache`: decoded frames stay resident (HBM on the GPU, host memory in this tier), a frame is decoded
+    once and every later use is a table entry.  Two epochs over a small tree: every batch equals the uncached loader's bit
+    for bit, the second epoch decodes (almost) nothing new when the cache holds the tree (160 MB), and a cache too small for it
+    (40 MB: the first batch's frames) passes the rest through its scratch area - same batches."""
+    from baseboostdepth_amd import datasets
+    lines = image_checks.make_kitti_tree(str(tmp_path), frames=20)[:24]
+    H, W, scales = 64, 128, [0, 1]
+
+    def loader(cache, epoch):
+        ds = datasets.KITTIRAWDataset(lines, epoch, H, W, kt_path=str(tmp_path), rand=True, is_train=True, scales=scales, kt=True,
+                                      naive_mix=True, trimin=True, seed=3)
+        col = datasets.DeviceCollate(H, W, scales, "cpu", HostPortBackend(), cache=cache)
+        return datasets.DeviceLoader(ds, 4, col, shuffle=True, drop_last=True, num_workers=2, seed=1, workers="thread")
+
+    cache = datasets.FrameCache("cpu", capacity_mb << 20, scratch_bytes=64 << 20)
+    decoded = []
+    for epoch in (0, 1):
+        before = cache.misses
+        for got, want in zip(loader(cache, epoch), loader(None, epoch)):
+            assert set(got) == set(want)
+            for k, v in want.items():
+                if torch.is_tensor(v) and v.dim() > 0:
+                    assert torch.equal(got[k], v), (epoch, k)
+                else:
+                    assert (float(got[k]) == float(v)) if torch.is_tensor(v) else (got[k] == v), k
+        decoded.append(cache.misses - before)
+    st = cache.stats()
+    if capacity_mb == 160:
+        assert st["passed_through"] == 0 and st["frames"] <= 80          # 20 frames x 2 cameras x 2 drives on disk
+        assert decoded[0] >= st["frames"] and decoded[1] <= 0.2 * decoded[0], decoded      # (epoch 1 draws other frame sets)
+        assert st["hits"] >= st["misses"] > 0
+    else:
+        assert 0 < st["frames"] < 40 and st["passed_through"] > 0 and st["hits"] > 0
