@@ -1060,11 +1060,11 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 #define BBD_BWD2_WARP_BATCH 3
 #endif
 #ifndef BBD_BWD_PRESENT_ONLY
-#define BBD_BWD_PRESENT_ONLY 0
+#define BBD_BWD_PRESENT_ONLY 1   // round 5: the candidate loop visits only the candidates present in the tile (-2.5 % where a
+                                 // tile holds 2-6 of the boosted recipe's 12 warp candidates, neutral where all are alive:
+                                 // profiles/r05/bwd_skip_paths.txt)
 #endif
-#ifndef BBD_BWD_NEAR
-#define BBD_BWD_NEAR 0
-#endif
+
 
 // Round 4, the nine-plane form (the only one since the end of that round; the per-channel form of rounds 2-4 is kept as
 // tools/experiments/per_channel_backward.hip.txt): (1) the coefficient planes of all three colour channels sit in LDS at
@@ -1119,9 +1119,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
   __shared__ float s_red[NT2 / 64][12];
   __shared__ unsigned s_present[NT2 / 64];
   __shared__ int s_count;
-#if BBD_BWD_NEAR
-  __shared__ unsigned s_near[NT2 / 64][NT2 / 64];      // [source wave][wave whose 6 x 34 window the ids lie in]
-#endif
   float (*s_xy)[2 * BPLANE2] = reinterpret_cast<float (*)[2 * BPLANE2]>(s_xybuf);      // [ch][2 * cell + {0: x, 1: y}]
   const BbdDims dm = a.dm;
   const int H = dm.H, W = dm.W, hw = H * W;
@@ -1211,25 +1208,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
       if (BBD_PARG(k) != 255u) mine |= 1u << BBD_PARG(k);
     const unsigned wave_mine = wave_or63(mine);
     if ((threadIdx.x & 63) == 63) s_present[threadIdx.x >> 6] = wave_mine;
-#if BBD_BWD_NEAR
-    // per WAVE: which candidates won a loss pixel in the 6 x 34 window around the wave's 4 rows of the tile (loss rows
-    // 4 w .. 4 w + 5 of the 18-row region): a loss pixel in row r lies in the windows of waves (r - 2) / 4 (if r >= 2... )
-    unsigned nm[NT2 / 64] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < NP_CELLS; ++k) {
-      const int i = k * NT2 + (int)threadIdx.x;
-      const int r = i / CW2;
-      const unsigned bit = (BBD_PARG(k) != 255u && i < CH * CW2) ? (1u << BBD_PARG(k)) : 0u;
-#pragma unroll
-      for (int w8 = 0; w8 < NT2 / 64; ++w8)
-        if (r >= 4 * w8 && r <= 4 * w8 + 5) nm[w8] |= bit;
-    }
-#pragma unroll
-    for (int w8 = 0; w8 < NT2 / 64; ++w8) {
-      const unsigned all = wave_or63(nm[w8]);
-      if ((threadIdx.x & 63) == 63) s_near[threadIdx.x >> 6][w8] = all;
-    }
-#endif
   }
   BBD_STAMP(26);
 #pragma unroll
@@ -1249,15 +1227,6 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
   unsigned present = 0u;
 #pragma unroll
   for (int w8 = 0; w8 < NT2 / 64; ++w8) present |= s_present[w8];
-#if BBD_BWD_NEAR
-  // Which candidates won a loss pixel in or next to this WAVE's four rows of the tile: only for those can the adjoint
-  // gather and the sample-gradient phase of its lanes be non-zero (skipped terms are exact zeros).  Wave-uniform, so the
-  // skip is a scalar branch; with coherent arg-min maps a wave meets a few of the tile's live candidates.
-  unsigned near = 0u;
-#pragma unroll
-  for (int w8 = 0; w8 < NT2 / 64; ++w8) near |= s_near[w8][threadIdx.x >> 6];
-  near = __builtin_amdgcn_readfirstlane(near);
-#endif
 
   int prev = -1;
   CandOrder order;                       // a frame's true-pose and error-induced warps back to back (cache locality)
@@ -1352,17 +1321,8 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
 
     // ---- phase G: adjoint of reflect-pad + 3x3 mean at this thread's 2 texels, channel by channel (no barrier between)
     float gx[3][PPT2];
-#if BBD_BWD_NEAR
-    const bool near_c = (near >> c) & 1u;
-#else
-    const bool near_c = true;
-#endif
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      if (!near_c) {
-        gx[ch][0] = 0.0f; gx[ch][1] = 0.0f;
-        continue;
-      }
       const float4 xy2 = *reinterpret_cast<const float4*>(&s_xy[ch][2 * ((ly + 2) * BS2 + lx0 + 2)]);   // (x0, y0, x1, y1)
       const float xqv[PPT2] = {xy2.x, xy2.z}, yqv[PPT2] = {xy2.y, xy2.w};
       float S3[3][PPT2];
@@ -1428,7 +1388,7 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
     float gP[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) gP[k] = 0.0f;
-    if (q_row_ok && near_c) {
+    if (q_row_ok) {
       // (a fresh scalar load instead of 21 SGPRs held across the C / G phases)
 #pragma unroll
       for (int i = 0; i < 21; ++i) pj[i] = uniform_load(a.pose + (size_t)cd.pose * BBD_PROJ_STRIDE + i);

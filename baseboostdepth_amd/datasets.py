@@ -205,8 +205,9 @@ class FrameCache:
     split are 63 GB decoded; an MI355X has 288 GB.  So: a frame is decoded ONCE, its bytes stay where the collate
     kernels read them anyway, and every later use - same epoch or any later one - is a table entry.  The loader asks
     ahead (`MonoDataset.frame_paths`) which frames a batch needs and tells the decode workers to skip the resident ones.
-    No eviction: when the buffer is full, new frames pass through the scratch area at its end and are decoded again
-    next time (what the reference always does)."""
+    A batch's freshly decoded frames land in a scratch area at the end of the buffer (one DMA from the decode ring); the
+    new ones among them are copied to a resident home (device to device).  No eviction: when the resident area is full,
+    further frames are used from the scratch area and decoded again next time (what the reference always does)."""
 
     def __init__(self, device, capacity_bytes, scratch_bytes=192 << 20):
         self.device = torch.device(device)
@@ -220,16 +221,22 @@ class FrameCache:
     def __contains__(self, path):
         return path in self.index
 
-    def place(self, nbytes):
-        """Where a batch's freshly decoded frames go: (base offset, resident?) - appended to the resident area while it
-        lasts, else into the scratch area."""
-        if self.used + nbytes <= self.capacity:
-            base = self.used
-            self.used += int(nbytes)
-            return base, True
-        if nbytes > self.scratch_bytes:
-            raise RuntimeError("FrameCache scratch area too small: %d bytes needed" % nbytes)
-        return self.capacity, False
+    def admit(self, path, scratch_off, h, w):
+        """A freshly decoded frame sits at `scratch_off` of the scratch area: give it a resident home if it is new and there
+        is room (one device-to-device copy, stream-ordered behind the upload), and say where this batch's kernels read it.
+        A frame another in-flight batch made resident in the meantime takes no second slot."""
+        hit = self.index.get(path)
+        if hit is not None:
+            return hit[0]
+        n = h * w * 3
+        if self.used + n > self.capacity:
+            self.passed_through += 1
+            return self.capacity + scratch_off
+        dst = self.used
+        self.used += n
+        self.buf[dst:dst + n].copy_(self.buf[self.capacity + scratch_off:self.capacity + scratch_off + n], non_blocking=True)
+        self.index[path] = (dst, h, w)
+        return dst
 
     def stats(self):
         return {"frames": len(self.index), "resident_GB": round(self.used / 1e9, 3), "hits": self.hits, "misses": self.misses,
@@ -319,26 +326,23 @@ class DeviceCollate:
             host_src = staging[:used]
         if cache is None:
             assert len(fresh) == len(entries), "frames were skipped but there is no FrameCache to take them from"
-            src, base = host_src.to(dev, non_blocking=True), 0
+            src = host_src.to(dev, non_blocking=True)
         else:
-            base, resident = cache.place(used)
+            if used > cache.scratch_bytes:
+                raise RuntimeError("FrameCache scratch area too small: %d bytes in one batch" % used)
             src = cache.buf
             if used:
-                src[base:base + used].copy_(host_src, non_blocking=True)
+                src[cache.capacity:cache.capacity + used].copy_(host_src, non_blocking=True)
         if done is not None and used:
             done.record()
         jobs = []
         for b, f in entries:
             img = batch[b]["images"][f]
             if img is not None:
-                off, (h, w) = base + fresh_off[(b, f)], img.shape[:2]
+                off, (h, w) = fresh_off[(b, f)], img.shape[:2]
                 if cache is not None:
                     cache.misses += 1
-                    path = batch[b]["paths"][f]
-                    if resident and path not in cache.index:
-                        cache.index[path] = (off, h, w)
-                    elif not resident:
-                        cache.passed_through += 1
+                    off = cache.admit(batch[b]["paths"][f], off, int(h), int(w))
             else:
                 off, h, w = cache.index[batch[b]["paths"][f]]
                 cache.hits += 1

@@ -681,7 +681,11 @@ def run_loader_fed(args, ctx, want_graph, steps=60, warmup=20, workers=None):
         train = lambda b: tr.train_step(b)[1]["loss"]
         # (b) the step fed by it
         fed_decode, _, _, _ = drain(make_loader(False), warmup, steps, train)
-        # (c) the step fed through the HBM-resident frame cache: a frame is decoded once, later uses are table entries
+        # (c) the step fed through the HBM-resident frame cache: a frame is decoded once, later uses are table entries.  The
+        #     DataLoader hands `prefetch x workers` batches to the decode workers before the first one is collated - those
+        #     were planned against an empty cache; a pass over them first (a real epoch has 3 317 batches, these are its
+        #     first forty), then the measurement
+        drain(make_loader(True), 0, 3 * workers + 8, train)
         fed_cached, n, last, _ = drain(make_loader(True), warmup, steps, train)
         finite = bool(torch.isfinite(last.detach()).item())
         cache_stats = cache.stats()

@@ -68,3 +68,31 @@ def test_training_loop_with_periodic_validation(tmp_path):
     assert tr.step == len(lines) // B
     assert set(tr.last_val) == set(tr.depth_metric_names) and all(np.isfinite(v) for v in tr.last_val.values())
     assert tr.best == tr.last_val["de/abs_rel"] or tr.best < tr.last_val["de/abs_rel"]
+
+
+def test_frame_cache_in_hbm_feeds_the_same_batches(tmp_path):
+    """`datasets.FrameCache` on the GPU with decode worker PROCESSES: resident frames are skipped by the workers (they ship
+    nothing for them through the ring), fresh ones are DMA-ed straight into the cache buffer - every batch equals the
+    uncached loader's bit for bit over two epochs, and the second epoch decodes a fraction of the first."""
+    from baseboostdepth_amd import datasets
+    lines = image_checks.make_kitti_tree(str(tmp_path), frames=20)[:24]
+    H, W, scales = 96, 320, [0, 1, 2, 3]
+
+    def loader(cache, epoch):
+        ds = datasets.KITTIRAWDataset(lines, epoch, H, W, kt_path=str(tmp_path), rand=True, is_train=True, scales=scales, kt=True,
+                                      naive_mix=True, trimin=True, seed=3)
+        col = datasets.DeviceCollate(H, W, scales, "cuda:0", cache=cache)
+        return datasets.DeviceLoader(ds, 4, col, shuffle=True, drop_last=True, num_workers=3, seed=1, workers="process")
+
+    cache = datasets.FrameCache("cuda:0", 256 << 20)
+    decoded = []
+    for epoch in (0, 1):
+        before = cache.misses
+        for got, want in zip(loader(cache, epoch), loader(None, epoch)):
+            assert set(got) == set(want)
+            for k, v in want.items():
+                if torch.is_tensor(v) and v.dim() > 0:
+                    assert torch.equal(got[k], v), (epoch, k)
+        decoded.append(cache.misses - before)
+    st = cache.stats()
+    assert st["passed_through"] == 0 and st["hits"] > 0 and decoded[1] <= 0.5 * decoded[0], (st, decoded)

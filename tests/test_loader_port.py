@@ -78,12 +78,12 @@ def test_worker_processes_with_shared_ring_equal_thread_pool(tmp_path):
     assert datasets._RING is None                      # ring released at the end of the epoch
 
 
-@pytest.mark.parametrize("capacity_mb", [160, 40])
+@pytest.mark.parametrize("capacity_mb", [160, 16])
 def test_frame_cache_batches_equal_uncached_ones_and_decode_each_frame_once(tmp_path, capacity_mb):
     """`datasets.FrameCache`: decoded frames stay resident (HBM on the GPU, host memory in this tier), a frame is decoded
     once and every later use is a table entry.  Two epochs over a small tree: every batch equals the uncached loader's bit
     for bit, the second epoch decodes (almost) nothing new when the cache holds the tree (160 MB), and a cache too small for it
-    (40 MB: the first batch's frames) passes the rest through its scratch area - same batches."""
+    (16 MB: eleven frames) uses the rest from its scratch area - same batches."""
     from baseboostdepth_amd import datasets
     lines = image_checks.make_kitti_tree(str(tmp_path), frames=20)[:24]
     H, W, scales = 64, 128, [0, 1]
@@ -112,4 +112,4 @@ def test_frame_cache_batches_equal_uncached_ones_and_decode_each_frame_once(tmp_
         assert decoded[0] >= st["frames"] and decoded[1] <= 0.2 * decoded[0], decoded      # (epoch 1 draws other frame sets)
         assert st["hits"] >= st["misses"] > 0
     else:
-        assert 0 < st["frames"] < 40 and st["passed_through"] > 0 and st["hits"] > 0
+        assert 8 <= st["frames"] <= 12 and st["passed_through"] > 0 and st["hits"] > 0      # (drive 1 frames are 375 x 1242 x 3)
