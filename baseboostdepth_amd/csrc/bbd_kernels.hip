@@ -1060,9 +1060,8 @@ __device__ __forceinline__ void load_window4(const float* plane, int r0, int c0,
 #define BBD_BWD2_WARP_BATCH 3
 #endif
 #ifndef BBD_BWD_PRESENT_ONLY
-#define BBD_BWD_PRESENT_ONLY 1   // round 5: the candidate loop visits only the candidates present in the tile (-2.5 % where a
-                                 // tile holds 2-6 of the boosted recipe's 12 warp candidates, neutral where all are alive:
-                                 // profiles/r05/bwd_skip_paths.txt)
+#define BBD_BWD_PRESENT_ONLY 1   // round 5: for samples with more than four candidates the loop visits only the candidates
+                                 // present in the tile (profiles/r05/bwd_skip_paths.txt)
 #endif
 
 
@@ -1230,24 +1229,25 @@ __global__ __launch_bounds__(NT2, BBD_BWD2_WGS) void warp_ssim_min_bwd9_kernel(B
 
   int prev = -1;
   CandOrder order;                       // a frame's true-pose and error-induced warps back to back (cache locality)
+  order.init(nc);
 #if BBD_BWD_PRESENT_ONLY
-  // Only the candidates that won a pixel in or next to this tile are visited.  The others' pose-gradient partials are
-  // zeros, written here by one lane per candidate - in parallel, instead of one scalar descriptor load (a serial round
-  // trip) per absent candidate in the loop below: a trained network leaves 2-6 of the boosted recipe's 12 warp candidates
-  // alive in a tile (with random-initialised networks all of them are, and this changes nothing)
-  if ((int)threadIdx.x < nc && !((present >> threadIdx.x) & 1u)) {
-    const bbd_cand_t* cp = a.cand + b * BBD_MAX_CAND + threadIdx.x;
-    const int kind = cp->kind, pose = cp->pose;
-    if ((kind & KIND_MASK) == BBD_KIND_WARP) {
-      float* z = a.grad_proj + (((size_t)s * a.NP + pose) * a.ntiles + tc.tile) * 12;
+  // Samples with many candidates (the boosted recipe: 8 / 14 / 18): only the candidates that won a pixel in or next to this
+  // tile are visited.  The others' pose-gradient partials are zeros, written here by one lane per candidate - in parallel,
+  // instead of one scalar descriptor load (a serial round trip) + branch per absent candidate in the loop below: a trained
+  // network leaves 2-6 of the 12 warp candidates alive in a tile (-2.6 % there, profiles/r05/bwd_skip_paths.txt).  MD2's
+  // four candidates keep the plain loop (the block below cost it 0.9 %, present_ab.txt); block-uniform choice.
+  if (nc > 4) {
+    if ((int)threadIdx.x < nc && !((present >> threadIdx.x) & 1u)) {
+      const bbd_cand_t* cp = a.cand + b * BBD_MAX_CAND + threadIdx.x;
+      const int kind = cp->kind, pose = cp->pose;
+      if ((kind & KIND_MASK) == BBD_KIND_WARP) {
+        float* z = a.grad_proj + (((size_t)s * a.NP + pose) * a.ntiles + tc.tile) * 12;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) z[k] = 0.0f;
+        for (int k = 0; k < 12; ++k) z[k] = 0.0f;
+      }
     }
+    order.todo &= present;
   }
-  order.init(nc);
-  order.todo &= present;
-#else
-  order.init(nc);
 #endif
   while (order.more()) {
     bbd_cand_t cd;

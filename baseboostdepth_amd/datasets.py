@@ -12,6 +12,7 @@ whole batch (`DeviceCollate` -> imageops -> csrc/bbd_image.hip), bit-exact again
 directly into the rows of the collated tensors.  `DeviceCollate(batch)` returns exactly the dict
 `Trainer.custom_collate` returns for the reference's per-item dicts.
 """
+import collections
 import os
 import random
 from concurrent.futures import ThreadPoolExecutor
@@ -379,8 +380,8 @@ class DeviceCollate:
                     self.pipe.to_float(level, list(range(len(owners))), t, list(range(len(owners))))
                     out[("color", 0, s)] = t
         if train:
-            cams = torch.from_numpy(np.stack([np.stack([item[k] for item in batch]) for k in ("K", "inv_K", "stereo_T")]))
-            cams = cams.to(dev)                                         # [3,B,4,4], one upload
+            cams = imageops._upload(np.stack([np.stack([item[k] for item in batch]) for k in ("K", "inv_K", "stereo_T")]),
+                                    dev)                                # [3,B,4,4], one asynchronous upload
             out[("K", 0)], out[("inv_K", 0)], out["stereo_T"] = cams[0], cams[1], cams[2]
             out["frames"] = frame_ids
             out["cutt"] = batch[0]["cutt_off"]
@@ -594,14 +595,18 @@ class DeviceLoader:
                                                 num_workers=self.num_workers, prefetch_factor=max(2, self.prefetch),
                                                 persistent_workers=False)
             try:
-                previous = None
+                uploads = collections.deque()
                 for items in inner:
                     batch = self.collate(_unpack_batch(ring, items))
-                    # a slot is rewritten `slots` batches later, the workers run at most `depth` ahead: waiting
-                    # for the PREVIOUS batch's upload here keeps every in-flight DMA clear of the writers
-                    if previous is not None:
-                        previous.synchronize()
-                    previous = items[0]["_ring"][2]
+                    # a slot is rewritten `slots` = depth + 3 batches later and the workers run at most `depth` batches ahead
+                    # of this loop: the slot of the batch the workers may start once this one is handed over belongs to the
+                    # batch collated two iterations ago - its upload must have finished; nothing younger is waited for, so
+                    # this thread stays ahead of the GPU (which it shares with the training step)
+                    uploads.append(items[0]["_ring"][2])
+                    if len(uploads) > 2:
+                        old = uploads.popleft()
+                        if old is not None:
+                            old.synchronize()
                     yield batch
             finally:
                 del inner

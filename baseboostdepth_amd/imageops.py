@@ -103,9 +103,19 @@ class TableBank:
 
     def tensors(self, device):
         if self.device_tensors is None:
-            self.device_tensors = (torch.from_numpy(np.concatenate(self.coef)).to(device),
-                                   torch.from_numpy(np.concatenate(self.bounds)).to(device))
+            self.device_tensors = (_upload(np.concatenate(self.coef), device), _upload(np.concatenate(self.bounds), device))
         return self.device_tensors
+
+
+def _upload(array, device):
+    """Host array -> device tensor without blocking the calling thread on the stream (pinned staging + asynchronous copy;
+    the caching host allocator keeps the staging block until the copy has run).  The loader's producer thread plans and
+    launches batches ahead of the training step: a pageable copy would make it wait for its stream - which shares the GPU
+    with a replaying step graph - three times per batch."""
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    if torch.device(device).type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
 
 
 class _Slot:
@@ -140,7 +150,7 @@ class ImagePipeline:
     def flush(self):
         if not self._pending:
             return
-        arena = torch.from_numpy(np.concatenate(self._arena)).to(self.device)
+        arena = _upload(np.concatenate(self._arena), self.device)
         coef, bounds = self.bank.tensors(self.device) if self.bank.coef else (None, None)
         base = {"arena": arena, "coef": coef, "bounds": bounds}
         import ctypes
