@@ -15,6 +15,7 @@ directly into the rows of the collated tensors.  `DeviceCollate(batch)` returns 
 import collections
 import os
 import random
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -497,6 +498,10 @@ class DeviceLoader:
         self.bytes_per_sample = bytes_per_sample
         self.shuffle, self.drop_last, self.num_workers, self.prefetch, self.seed = shuffle, drop_last, num_workers, prefetch, seed
         self.workers = workers if num_workers > 0 else "thread"
+        # where the wall time of an epoch went, seconds: producer thread waiting for decoded items / planning + launching the
+        # collate / blocked on a full hand-over queue (the consumer is the slower side); consumer waiting for a batch (the
+        # producer is the slower side)
+        self.stats = {"fetch_s": 0.0, "collate_s": 0.0, "producer_blocked_s": 0.0, "consumer_waited_s": 0.0, "batches": 0}
 
     def __len__(self):
         n = len(self.dataset) // self.world
@@ -551,12 +556,14 @@ class DeviceLoader:
                     for batch in self._iterate():
                         ev = torch.cuda.Event()
                         ev.record(stream)
+                        t0 = time.perf_counter()
                         while not stop.is_set():
                             try:
                                 ready.put((batch, ev), timeout=0.1)
                                 break
                             except queue.Full:
                                 continue
+                        self.stats["producer_blocked_s"] += time.perf_counter() - t0
                         if stop.is_set():
                             return
                 ready.put((None, None))
@@ -567,7 +574,9 @@ class DeviceLoader:
         thread.start()
         try:
             while True:
+                t0 = time.perf_counter()
                 batch, ev = ready.get()
+                self.stats["consumer_waited_s"] += time.perf_counter() - t0
                 if batch is None:
                     return
                 if isinstance(batch, BaseException):
@@ -596,8 +605,17 @@ class DeviceLoader:
                                                 persistent_workers=False)
             try:
                 uploads = collections.deque()
-                for items in inner:
+                it = iter(inner)
+                while True:
+                    t0 = time.perf_counter()
+                    items = next(it, None)
+                    t1 = time.perf_counter()
+                    if items is None:
+                        break
                     batch = self.collate(_unpack_batch(ring, items))
+                    self.stats["fetch_s"] += t1 - t0
+                    self.stats["collate_s"] += time.perf_counter() - t1
+                    self.stats["batches"] += 1
                     # a slot is rewritten `slots` = depth + 3 batches later and the workers run at most `depth` batches ahead
                     # of this loop: the slot of the batch the workers may start once this one is handed over belongs to the
                     # batch collated two iterations ago - its upload must have finished; nothing younger is waited for, so
