@@ -572,9 +572,11 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
             torch.cuda.set_sync_debug_mode("warn")
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            done = 0
+            done, per_call = 0, []
             for b in batches:
+                c0 = time.perf_counter()
                 tr.train_step(dict(b))
+                per_call.append(time.perf_counter() - c0)
                 done += 1
                 if done in (3, 10) and time.perf_counter() - t0 > pass_budget * done / n_batches * 3:
                     torch.cuda.synchronize()      # far over budget (e.g. MIOpen compiling solvers for unseen row counts)
@@ -591,6 +593,10 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                        # how long the training thread took to ENQUEUE the steps (if this is well below ms_per_step the loop is
                        # bound by the GPU, not by the host)
                        "host_enqueue_ms_per_step": round(t_host / done * 1e3, 3),
+                       # the train_step CALLS one by one: a few slow ones (a first use of something) or all of them?
+                       "host_call_ms_median": round(sorted(per_call)[len(per_call) // 2] * 1e3, 2),
+                       "host_call_ms_slowest3": [round(v * 1e3, 1) for v in sorted(per_call)[-3:]],
+                       "host_call_slowest_step": int(max(range(len(per_call)), key=per_call.__getitem__)),
                        "table_uploads_per_step": round((st["packed_uploads"] + st["single_uploads"]) / done, 3),
                        "table_bytes_per_step": int(st["packed_words"] * 4 / done),
                        "table_build_ms_per_step": round(st.get("build_ms", 0.0) / done, 3),
@@ -667,20 +673,42 @@ def run_loader_fed(args, ctx, want_graph, steps=60, warmup=20, workers=None):
             return datasets.DeviceLoader(ds, args.batch, collate, num_workers=workers, prefetch=3, seed=0, workers="process")
 
         def drain(loader, n_warm, n_steps, step):
-            n, t0, last, batch = 0, None, None, None
-            drain.loader = loader
-            for i, batch in enumerate(loader):
+            """-> (images/s, images, last loss, last batch, {ms per batch in steady state: waiting for the loader's next batch,
+            inside train_step (host side of the step: table look-ups, copies into the graph's static inputs, the graph
+            launch), and the loader's own producer-side times})."""
+            n, t0, last, batch, t_get, t_step, snap = 0, None, None, None, 0.0, 0.0, None
+            it = iter(loader)
+            i = 0
+            while True:
+                a = time.perf_counter()
+                batch = next(it, None)
+                b = time.perf_counter()
+                if batch is None:
+                    break
                 if i == n_warm:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
+                    t_get = t_step = 0.0
+                    snap = dict(loader.stats)
+                elif i > n_warm:
+                    t_get += b - a
                 if step is not None:
+                    c = time.perf_counter()
                     last = step(batch)
+                    t_step += time.perf_counter() - c
                 if i >= n_warm:
                     n += args.batch
                 if i == n_warm + n_steps - 1:
                     break
+                i += 1
             torch.cuda.synchronize()
-            return n / (time.perf_counter() - t0), n, last, batch
+            dt = time.perf_counter() - t0
+            st, k = loader.stats, max(n // args.batch, 1)
+            loop = {"consumer_waited_for_batch_ms": round(t_get / k * 1e3, 2), "consumer_in_train_step_ms": round(t_step / k * 1e3, 2),
+                    "producer_fetch_ms": round((st["fetch_s"] - snap["fetch_s"]) / max(st["batches"] - snap["batches"], 1) * 1e3, 2),
+                    "producer_collate_ms": round((st["collate_s"] - snap["collate_s"]) / max(st["batches"] - snap["batches"], 1) * 1e3, 2)}
+            it.close() if hasattr(it, "close") else None
+            return n / dt, n, last, batch, loop
 
         # (0) one host thread decoding JPEGs (Pillow, what the reference's loader does per frame): frames per second per core
         from PIL import Image
@@ -692,23 +720,17 @@ def run_loader_fed(args, ctx, want_graph, steps=60, warmup=20, workers=None):
                 im.convert("RGB").load()
         one_thread_decode = len(files) / (time.perf_counter() - t0)
         # (a) the loader alone, every frame decoded at every use (the reference's behaviour): the host's decode ceiling
-        loader_alone, _, _, batch = drain(make_loader(False), 10, steps, None)
+        loader_alone, _, _, batch, _ = drain(make_loader(False), 3 * workers + 8, 200, None)     # (past the prefetched backlog)
         frames_per_sample = sum(1 for k in batch if isinstance(k, tuple) and k[0] == "color" and k[2] == 0)
         train = lambda b: tr.train_step(b)[1]["loss"]
         # (b) the step fed by it
-        fed_decode, _, _, _ = drain(make_loader(False), warmup, steps, train)
+        fed_decode, _, _, _, loop_decode = drain(make_loader(False), warmup, steps, train)
         # (c) the step fed through the HBM-resident frame cache: a frame is decoded once, later uses are table entries.  The
         #     DataLoader hands `prefetch x workers` batches to the decode workers before the first one is collated - those
         #     were planned against an empty cache; a pass over them first (a real epoch has 3 317 batches, these are its
         #     first forty), then the measurement
         drain(make_loader(True), 0, 3 * workers + 8, train)
-        fed_cached, n, last, _ = drain(make_loader(True), warmup, steps, train)
-        st = drain.loader.stats
-        per = max(st["batches"], 1)
-        # who waited for whom in the cached, loader-fed loop (ms per batch over the whole drain, warm-up included)
-        loop_ms = {"producer_fetch_ms": round(st["fetch_s"] / per * 1e3, 2), "producer_collate_ms": round(st["collate_s"] / per * 1e3, 2),
-                   "producer_blocked_on_full_queue_ms": round(st["producer_blocked_s"] / per * 1e3, 2),
-                   "consumer_waited_for_batch_ms": round(st["consumer_waited_s"] / per * 1e3, 2)}
+        fed_cached, n, last, _, loop_ms = drain(make_loader(True), warmup, steps, train)
         finite = bool(torch.isfinite(last.detach()).item())
         cache_stats = cache.stats()
         del cache
@@ -725,7 +747,7 @@ def run_loader_fed(args, ctx, want_graph, steps=60, warmup=20, workers=None):
            "decode_every_use_images_per_sec": round(fed_decode, 2),
            "loader_alone_images_per_sec": round(loader_alone, 1),
            "host_decode_frames_per_sec": round(loader_alone * frames_per_sample, 1),
-           "frame_cache": cache_stats, "loop_ms_per_batch": loop_ms,
+           "frame_cache": cache_stats, "loop_ms_per_batch": loop_ms, "loop_ms_per_batch_decode_every_use": loop_decode,
            "decode_workers": workers, "schedulable_cpus": avail, "cgroup_cpu_quota": quota,
            "one_thread_decode_frames_per_sec": round(one_thread_decode, 1),
            # KITTI (Eigen-Zhou): 39 810 samples name ~45 000 distinct frames -> 1.13 first-time decodes per sample in epoch 1
