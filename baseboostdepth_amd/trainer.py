@@ -694,10 +694,14 @@ class Trainer:
             parts = [torch.cat([a, b], 1) for a, b, _ in chunk]
             # boosted batches change the pass's row count almost every step, and every new row count is a new problem for
             # every convolution of the pose network (MIOpen compiles solvers for tens of seconds at first sight): round the
-            # pass up to a multiple of `pose_pad_rows` with one trailing call group of zero rows.  Its BatchNorm statistics
+            # pass up to the next row count the shipped MIOpen database has find results for (`tuning.POSE_ROW_COUNTS`; beyond
+            # them to a multiple of `pose_pad_rows`) with one trailing call group of zero rows.  Its BatchNorm statistics
             # are its own and leave the running statistics alone (`untracked_groups`), nobody reads its outputs and its
             # gradient contributions are exact zeros - the real calls compute what they compute without it
-            pad = (-n_real) % self.pose_pad_rows if self.pose_pad_rows > 0 and self.models["pose_encoder"].training else 0
+            pad = 0
+            if self.pose_pad_rows > 0 and self.models["pose_encoder"].training:
+                from . import tuning
+                pad = tuning.padded_pose_rows(n_real, self.pose_pad_rows) - n_real
             if pad:
                 parts.append(parts[0].new_zeros((pad,) + tuple(parts[0].shape[1:])))
             x = torch.cat(parts, 0)

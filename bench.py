@@ -276,7 +276,7 @@ def committed_constants(config):
     from baseboostdepth_amd.csrc.build import source_sha16
     now = source_sha16()
     out = {"traffic": None, "traffic_path": None, "isa_mix": {}, "isa_mix_path": None, "source_sha16": now, "stale": []}
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         cand = os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % config)
         if out["traffic"] is None and os.path.isfile(cand):
             out["traffic"], out["traffic_path"] = json.load(open(cand)), os.path.relpath(cand, ROOT)
@@ -573,9 +573,18 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             done, per_call = 0, []
+            prof_step = int(os.environ.get("BBD_BENCH_PROFILE_STEP", "-1")) if p == 0 else -1      # (diagnosis: cProfile one call)
             for b in batches:
                 c0 = time.perf_counter()
-                tr.train_step(dict(b))
+                if done == prof_step:
+                    import cProfile, pstats
+                    pr = cProfile.Profile()
+                    pr.enable()
+                    tr.train_step(dict(b))
+                    pr.disable()
+                    pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(14)
+                else:
+                    tr.train_step(dict(b))
                 per_call.append(time.perf_counter() - c0)
                 done += 1
                 if done in (3, 10) and time.perf_counter() - t0 > pass_budget * done / n_batches * 3:
@@ -585,7 +594,10 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
             torch.cuda.set_sync_debug_mode("default")
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        syncs = sum(1 for w in caught if "synchroniz" in str(w.message).lower())
+        sync_w = [w for w in caught if "synchroniz" in str(w.message).lower()]
+        syncs = len(sync_w)
+        sync_where = sorted({"%s:%d" % (os.path.relpath(w.filename, ROOT) if w.filename.startswith(ROOT) else os.path.basename(w.filename),
+                                        w.lineno) for w in sync_w})
         st = dict(steptables.STATS)
         g1 = tr.graph_stats
         passes.append({"pass": p + 1, "steps": done, "ms_per_step": round(dt / done * 1e3, 3),
@@ -600,7 +612,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                        "table_uploads_per_step": round((st["packed_uploads"] + st["single_uploads"]) / done, 3),
                        "table_bytes_per_step": int(st["packed_words"] * 4 / done),
                        "table_build_ms_per_step": round(st.get("build_ms", 0.0) / done, 3),
-                       "synchronising_calls_per_step": round(syncs / done, 3),
+                       "synchronising_calls_per_step": round(syncs / done, 3), "synchronising_calls_at": sync_where,
                        "eager_steps": g1["eager"] - g0["eager"], "captures": g1["captures"] - g0["captures"],
                        "replays": g1["replays"] - g0["replays"]})
     out = {"config": config, "workload": "%s with a NEW ordering every step: %d pre-resident batches, %d distinct signatures, "
