@@ -28,11 +28,14 @@ POSE_ROW_COUNTS = (32, 64, 192, 208, 224, 240, 256, 272, 288)
 
 
 def padded_pose_rows(n, quantum=32):
-    """Rows the batched pose pass of `n` real rows runs with."""
+    """Rows the batched pose pass of `n` real rows runs with: the next measured row count if it is no further away than the
+    next multiple of `quantum`, else that multiple (a row count MIOpen meets for the first time costs tens of seconds of solver
+    compilation ONCE per machine - its user database keeps the result)."""
+    q = -(-n // quantum) * quantum
     for r in POSE_ROW_COUNTS:
-        if r >= n:
+        if n <= r <= q:
             return r
-    return -(-n // quantum) * quantum
+    return q
 
 
 def _cache_root():

@@ -545,7 +545,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                 ms[i % args.batch] += 1
             i += 1
         return sorted(ms, reverse=True)
-    warm_sets = ([offsets_for_rows(r) for r in (192, 224, 256, 288)] if base.startswith("boosted")
+    warm_sets = ([offsets_for_rows(r) for r in (192, 208, 224, 240, 256, 272, 288)] if base.startswith("boosted")
                  else [[2] * args.batch, [1] * args.batch])          # early curriculum: 48 -> 64 rows, 24 -> 32 rows
     keep = tr.capture_after
     tr.capture_after = 1 << 30

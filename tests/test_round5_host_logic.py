@@ -230,3 +230,22 @@ def test_structured_batch_registers_the_true_pose_warps():
     hist_r = live_candidates_per_tile(out_r[("bbd", "argmin")][0])
     mean_live_r = sum(k * v for k, v in hist_r.items()) / sum(hist_r.values())
     assert mean_live < 0.7 * mean_live_r and mean_live < 8, (hist, hist_r)
+
+
+def test_pose_pass_is_padded_to_measured_row_counts():
+    """`tuning.padded_pose_rows`: the next row count with shipped find results when it is no further than the next multiple of
+    32, else that multiple; every epoch-15 row count of the boosted recipe (24 + 4 k) lands on a measured one with at most
+    15 padding rows."""
+    from baseboostdepth_amd import tuning
+    assert [tuning.padded_pose_rows(n) for n in (9, 24, 33, 48, 100, 129, 180, 292)] == [32, 32, 64, 64, 128, 160, 192, 320]
+    for k in range(39, 67):                      # 180 .. 288 rows: 99 % of the epoch-15 draws
+        n = 24 + 4 * k
+        r = tuning.padded_pose_rows(n)
+        assert r in tuning.POSE_ROW_COUNTS and 0 <= r - n <= 15, (n, r)
+    # every shipped row count has find results in the shipped database (forward problems of the pose encoder's stem:
+    # 6 -> 64 channels, 7x7 stride 2 on 192x640, batch = the row count)
+    import glob, os
+    db = glob.glob(os.path.join(os.path.dirname(tuning.__file__), "miopen_db", "*.ufdb.txt"))[0]
+    text = open(db).read()
+    for r in tuning.POSE_ROW_COUNTS:
+        assert "6-192-640-7x7-64-96-320-%d-3x3-2x2-1x1-0-NCHW-FP32-F" % r in text, r

@@ -25,21 +25,30 @@ done
 # the fresh-ordering regime: every host->device copy of 30 steps with 30 new orderings (no counters with this trace)
 ( cd /tmp && timeout 900 rocprofv3 --memory-copy-trace --stats --output-format csv -d /tmp/prof_fresh -o fresh -- python3 $GRAFT_REPO_ROOT/bench.py --config boosted15_fresh > $GRAFT_REPO_ROOT/$O/bench_boosted15_fresh_under_trace.json 2> /dev/null )
 python - <<'PY' > gpurun_out/r05/memory_copies_boosted15_fresh.txt
-import csv, glob, collections
+import csv, glob, collections, json
 files = glob.glob('/tmp/prof_fresh/**/*memory_copy_trace.csv', recursive=True)
 rows = [r for f in files for r in csv.DictReader(open(f))]
-by = collections.Counter()
-size = collections.Counter()
+print('rocprofv3 --memory-copy-trace of `bench.py --config boosted15_fresh`: 7 warm-up signatures x 2 steps, then 3 passes x 30 steps')
+print('over 30 distinct orderings (pass 1: every per-signature cache cold).  Columns of the trace:', list(rows[0].keys()) if rows else None)
+by = collections.Counter(); dur = collections.Counter()
 for r in rows:
     d = r.get('Direction') or r.get('direction') or '?'
-    n = int(r.get('Size') or r.get('size') or 0) if (r.get('Size') or r.get('size') or '').isdigit() else 0
     by[d] += 1
-    size[d] += n
-    if 'HOST_TO_DEVICE' in d.upper():
-        by['H2D <= 64 KiB' if n <= 65536 else 'H2D > 64 KiB'] += 1
-print('rocprofv3 --memory-copy-trace of `bench.py --config boosted15_fresh` (warm-up + 3 passes x 30 steps, 30 distinct orderings)')
+    try:
+        dur[d] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    except Exception:
+        pass
 for k in sorted(by):
-    print('%-28s %8d copies %14d bytes' % (k, by[k], size.get(k, 0)))
+    print('%-34s %7d copies   %10.3f ms in total' % (k, by[k], dur[k] / 1e6))
+try:
+    line = json.load(open('gpurun_out/r05/bench_boosted15_fresh_under_trace.json'))
+    up = sum(p['table_uploads_per_step'] * p['steps'] for p in line['passes'])
+    print('table uploads counted by steptables.STATS in the three timed passes: %d (pass 1: %.2f per step, passes 2-3: %.2f / %.2f)' % (
+        up, *[p['table_uploads_per_step'] for p in line['passes']]))
+    print('synchronising calls flagged by torch.cuda.set_sync_debug_mode in the timed passes:', [p['synchronising_calls_at'] for p in line['passes']],
+          '(the one entry is the debug mode announcing itself)')
+except Exception as e:
+    print('bench line not parsed:', e)
 PY
 cp gpurun_out/r05/traffic_*.json profiles/r05/ 2>/dev/null     # (this box's copy of the tree: the bench lines below read the fresh counters)
 timeout 1200 python bench.py > $O/bench_md2.json 2> $O/bench_md2.err
