@@ -294,8 +294,9 @@ class _SmoothLossMulti(torch.autograd.Function):
         key = (str(dev), B) + tuple(tuple(d.shape[-2:]) for d in disps)
         den = _SmoothLossMulti._den.get(key)
         if den is None:       # mean over the x-terms' B*h*(w-1) and the y-terms' B*(h-1)*w elements (layers.py:213-216)
-            den = torch.tensor([[B * d.shape[-2] * (d.shape[-1] - 1), B * (d.shape[-2] - 1) * d.shape[-1]] for d in disps],
-                               dtype=torch.float32).to(dev)
+            from .steptables import upload_single      # (pinned + asynchronous: legal wherever this node first runs)
+            den = upload_single([[B * d.shape[-2] * (d.shape[-1] - 1), B * (d.shape[-2] - 1) * d.shape[-1]] for d in disps],
+                                dev, torch.float32)
             _SmoothLossMulti._den[key] = den
         return (sums.sum(dim=(1, 2)) / den).sum(dim=1)
 
@@ -336,8 +337,9 @@ class _CombineLosses(torch.autograd.Function):
         key = (str(loss_sum.device), float(smoothness), tuple(scales))
         w = _CombineLosses._w.get(key)
         if w is None:       # disparity_smoothness / 2**s in fp32: scaling by a power of two commutes with the rounding
-            w = (torch.tensor([float(smoothness)] * len(scales), dtype=torch.float32) /
-                 torch.tensor([2.0 ** s for s in scales], dtype=torch.float32)).to(loss_sum.device)
+            from .steptables import upload_single
+            w = upload_single((torch.tensor([float(smoothness)] * len(scales), dtype=torch.float32) /
+                               torch.tensor([2.0 ** s for s in scales], dtype=torch.float32)), loss_sum.device, torch.float32)
             _CombineLosses._w[key] = w
         per = torch.addcmul(loss_sum / n_px, smooths, w)
         total = per.sum() / num_scales
