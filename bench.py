@@ -541,7 +541,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
         # epoch >= 10 recipe: the pass has 24 + 4 * sum(m - 1) rows (incremental + partial calls, batch 12)
         ms, want = [1] * args.batch, (rows - 24) // 4
         i = 0
-        while sum(m - 1 for m in ms) < want:
+        while sum(m - 1 for m in ms) < want and min(ms) < 7:       # (a small --batch cannot reach the larger row counts)
             if ms[i % args.batch] < 7:
                 ms[i % args.batch] += 1
             i += 1

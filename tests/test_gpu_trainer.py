@@ -377,7 +377,7 @@ def test_bench_line_with_step_graph_and_fallback(capsys, monkeypatch):
     """bench.py replays the step as one hipGraph by default; if capture fails it must fall back to the eager loop
     (and say so) instead of losing the benchmark; `--step-graph off` is the plain eager loop."""
     from baseboostdepth_amd.trainer import Trainer
-    argv = ["--batch", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-eager-ab"]
+    argv = ["--batch", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-eager-ab", "--no-secondary"]
     line = _run_bench_inline(capsys, argv)
     assert line["step_graph"] is True and line["value"] > 0 and line["n_gpus"] == 1 and line["collective"] == "none"
     assert set(line["kernels"]) == {"bbd_identity_loss_fwd", "bbd_warp_ssim_min_disp_fwd", "bbd_warp_ssim_min_disp_bwd"}
