@@ -244,6 +244,14 @@ class PoseSchedule:
             views.append((okey, len(rows), len(per_row), const))
             rows.extend(per_row)
 
+        pos = {}                                 # frame -> {sample: row in the frame's stack}
+
+        def row_of(k, b):
+            table = pos.get(k)
+            if table is None:
+                table = pos[k] = {s: i for i, s in enumerate(plan.owners(k))}
+            return table[b]
+
         if self.incremental:
             step_rows, chains = {}, {}          # (k-1, k) -> request slot
             for f in self.temporal:
@@ -261,8 +269,7 @@ class PoseSchedule:
                         continue
                     own_f = plan.owners(f)
                     # the reference chains with range(f, 0, -1): EMPTY for negative f (identity pose, kept)
-                    chains[f] = [[base[step_rows[(k - 1, k)]] + plan.owners(k).index(b) for k in range(f, 0, -1)]
-                                 for b in own_f]
+                    chains[f] = [[base[step_rows[(k - 1, k)]] + row_of(k, b) for k in range(f, 0, -1)] for b in own_f]
                 if self.decomp:
                     emit(("cam_T_cam_error", 0, f), [(c, -1, ERR) for c in chains[f]])
             nonstereo = [m for m in plan.ms if m != 0]

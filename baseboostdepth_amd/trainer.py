@@ -191,7 +191,7 @@ class Trainer:
             # bound the cache: the least recently replayed signature goes first
             while len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
-            if self._graph_pool is None and os.environ.get("BBD_GRAPH_SHARED_POOL", "1") != "0":
+            if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
             pool = self._graph_pool
             self.graph_stats["captures"] += 1
