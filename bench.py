@@ -498,14 +498,19 @@ def fresh_offsets(config, batch, n, seed=2025):
 
 def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
     """The regime a real `--rand` epoch runs in: EVERY step brings a new batch signature (the loader redraws each
-    sample's frame set, trainer.py:250, 867-886).  `n_batches` pre-resident batches with different orderings, every
-    per-signature cache cold at the first step, device synchronise on both sides of each pass:
-      pass 1  cold: all first sightings (eager steps; every step builds + uploads its tables)
-      pass 2  the same batches again (second sighting: where the signature space is small - the early curriculum's 91
-              multisets - `Trainer` captures a step graph now; otherwise still eager, tables cached)
+    sample's frame set, trainer.py:250, 867-886).  Pre-resident batches with different orderings (90 for the boosted recipe,
+    30 for the early curriculum, whose 91 possible signatures would repeat), every per-signature cache cold at the first
+    step, device synchronise on both sides of each pass:
+      pass 1  new signatures: every step builds + uploads its tables and runs eagerly (a signature that comes back within
+              the pass is captured where the signature space is small).  With 90 orderings it is reported in two parts:
+              steps 1-30 (which also hold the process's allocator growth) and steps 31-90 = the steady state of a regime
+              in which no signature ever comes back
+      pass 2  the first 30 batches again (second sighting: the early curriculum captures a step graph now; the boosted
+              recipe stays eager, tables cached)
       pass 3  third sighting (replays where pass 2 captured)
-    Reported per pass: ms/step, table uploads per step (steptables.STATS) and the synchronising calls per step that
-    torch itself flags (torch.cuda.set_sync_debug_mode("warn"): a pageable host-to-device copy is one)."""
+    Reported per pass: ms/step, the train_step calls one by one (median, slowest three), table uploads and bytes per step
+    (steptables.STATS), host table-build time, and the synchronising calls torch itself flags
+    (torch.cuda.set_sync_debug_mode("warn"): a pageable host-to-device copy is one)."""
     import warnings
     n_batches = 90 if config.startswith("boosted") else n_batches          # (boosted: 30 cold-start + 60 steady-state orderings)
     from baseboostdepth_amd import ops, plan as plan_mod, steptables
