@@ -551,8 +551,9 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                 ms[i % args.batch] += 1
             i += 1
         return sorted(ms, reverse=True)
-    warm_sets = ([offsets_for_rows(r) for r in (192, 208, 224, 240, 256, 272, 288)] if base.startswith("boosted")
-                 else [[2] * args.batch, [1] * args.batch])          # early curriculum: 48 -> 64 rows, 24 -> 32 rows
+    warm_sets = ([offsets_for_rows(r) for r in (160, 192, 208, 224, 240, 256, 272, 288, 320)] if base.startswith("boosted")
+                 else [[2] * args.batch, [1] * args.batch, [2] * (args.batch // 2) + [1] * (args.batch - args.batch // 2)])
+    # (early curriculum: 48, 24 -> 32 and 36 -> 48 rows)
     keep = tr.capture_after
     tr.capture_after = 1 << 30
     for k, wms in enumerate(warm_sets):
