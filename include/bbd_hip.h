@@ -30,7 +30,9 @@ extern "C" {
  * header, would otherwise mis-marshal pointers into a kernel).  1 = round 1; 2 = bbd_bn_act_bwd gained `beta`, BN
  * scratch sizing changed (round 2, was not bumped then); 3 = round 3 (backward tiling / scratch contract); 4 = the
  * depth-wise token weight gradient's scratch contract (one partial row per workgroup) and `add_input` of
- * bbd_dwconv_tokens_fwd became a bit field (round 3, with the bbd_token_ln_* / bbd_colsum additions). */
+ * bbd_dwconv_tokens_fwd became a bit field (round 3, with the bbd_token_ln_* / bbd_colsum additions); 5 = round 4 (the
+ * work-item table of the fused launches, per-row `invert` of the pose matrices, the multi-scale smoothness launches);
+ * 6 = round 5: bbd_bn_act_grouped_fwd gained `untracked_groups` (the padding group of the batched pose pass). */
 #define BBD_ABI_VERSION 6
 
 /* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
