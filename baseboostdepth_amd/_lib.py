@@ -20,7 +20,7 @@ PROJ_STRIDE = 24
 KIND_WARP, KIND_IDENT, FLAG_NO_POSE_GRAD = 0, 1, 0x100
 COMPOSE_STRIDE, COMPOSE_ERROR, COMPOSE_REPLACE = 12, 1, 2
 PAIR_SHIFT = 16        # bits 16-23 of bbd_cand_t.kind: 1 + index of the pass partner (hint), 0 = none
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -72,6 +72,8 @@ SIGNATURES = {
     "bbd_bn_grouped_scratch_doubles": [_i, _i, _i, _i],
     "bbd_bn_act_grouped_fwd": [_p] * 12 + [_i, _i, _i, _i, _i, _d, _d, _i, _p],
     "bbd_bn_act_grouped_bwd": [_p] * 13 + [_i, _i, _i, _i, _i, _p],
+    "bbd_bn_act_grouped_dev_fwd": [_p] * 12 + [_i, _i, _i, _i, _i, _d, _d, _i, _p],
+    "bbd_bn_act_grouped_dev_bwd": [_p] * 13 + [_i, _i, _i, _i, _i, _i, _p],
     "bbd_reflect_pad1_fwd": [_p, _p, _i, _i, _i, _p],
     "bbd_reflect_pad1_bwd": [_p, _p, _i, _i, _i, _p],
     "bbd_maxpool3s2_fwd": [_p, _p, _p, _i, _i, _i, _p],

@@ -53,8 +53,17 @@ struct BnArgs {
   // a separate call of the layer (one batched pass of a network that the reference calls G times); blockIdx.z = g
   int G;
   int untracked;         // the last `untracked` groups are normalised like the others but leave the running statistics alone
+  // device-resident group table (bbd_bn_act_grouped_dev_*): rows[0..G] then, at [BBD_BN_MAX_GROUPS + 1], the number of
+  // tracked groups - a launch whose arguments do not depend on the batch signature, so that ONE captured step graph
+  // serves every ordering with the same padded row count.  Groups may be empty there.  NULL: the by-value table below
+  const int32_t* rows_dev;
   int rows[BBD_BN_MAX_GROUPS + 1];
 };
+
+__device__ __forceinline__ int group_row(const BnArgs& a, int g) { return a.rows_dev ? a.rows_dev[g] : a.rows[g]; }
+__device__ __forceinline__ int tracked_groups(const BnArgs& a) {
+  return a.rows_dev ? a.rows_dev[BBD_BN_MAX_GROUPS + 1] : a.G - a.untracked;
+}
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -100,7 +109,7 @@ __device__ __forceinline__ void stats_slice(const BnArgs& a, int c, int grp, int
   double ds = 0.0, dss = 0.0;
   const bool vec = (a.HW & 3) == 0;
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
+  for (int n = group_row(a, grp) + sub; n < group_row(a, grp + 1); n += NT / 64) {
     const float* p = a.x + ((size_t)n * a.C + c) * a.HW;
     if (vec) {
       for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
@@ -124,7 +133,8 @@ __device__ __forceinline__ void stats_slice(const BnArgs& a, int c, int grp, int
 
 // mean / invstd of one (channel, group) from its totals
 __device__ __forceinline__ void group_moments(const BnArgs& a, int grp, double ts, double tss, double* mean, double* var) {
-  const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
+  const double cnt = (double)(group_row(a, grp + 1) - group_row(a, grp)) * (double)a.HW;
+  if (!(cnt > 0.0)) { *mean = 0.0; *var = 0.0; return; }      // an empty group of a device-resident table
   *mean = ts / cnt;
   double v = tss / cnt - (*mean) * (*mean);
   *var = v > 0.0 ? v : 0.0;
@@ -135,11 +145,12 @@ template <typename Totals>
 __device__ __forceinline__ void update_running(const BnArgs& a, int c, Totals totals) {
   if (a.run_mean) {
     float rm = a.run_mean[c], rv = a.run_var[c];
-    for (int q = 0; q < a.G - a.untracked; ++q) {
+    const int tracked = tracked_groups(a);
+    for (int q = 0; q < tracked; ++q) {
       double qs, qss, qmean, qvar;
       totals(q, &qs, &qss);
       group_moments(a, q, qs, qss, &qmean, &qvar);
-      const double qcnt = (double)(a.rows[q + 1] - a.rows[q]) * (double)a.HW;
+      const double qcnt = (double)(group_row(a, q + 1) - group_row(a, q)) * (double)a.HW;
       const double unbiased = qcnt > 1.0 ? qvar * qcnt / (qcnt - 1.0) : qvar;
       rm = (1.0f - a.momentum) * rm + a.momentum * (float)qmean;
       rv = (1.0f - a.momentum) * rv + a.momentum * (float)unbiased;
@@ -147,7 +158,7 @@ __device__ __forceinline__ void update_running(const BnArgs& a, int c, Totals to
     a.run_mean[c] = rm;
     a.run_var[c] = rv;
   }
-  if (a.batches && c == 0) *a.batches += a.G - a.untracked;
+  if (a.batches && c == 0) *a.batches += tracked_groups(a);
 }
 
 // forward apply of slice k
@@ -157,7 +168,7 @@ __device__ __forceinline__ void apply_slice(const BnArgs& a, int c, int grp, int
   plane_slice(a.HW, split, k, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
+  for (int n = group_row(a, grp) + sub; n < group_row(a, grp + 1); n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
       for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
@@ -198,7 +209,7 @@ __device__ __forceinline__ void bwd_reduce_slice(const BnArgs& a, int c, int grp
   double dg = 0.0, dgx = 0.0;
   const bool vec = (a.HW & 3) == 0;
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
+  for (int n = group_row(a, grp) + sub; n < group_row(a, grp + 1); n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     float sg = 0.0f, sgx = 0.0f;
     if (vec) {
@@ -245,7 +256,7 @@ __device__ __forceinline__ void bwd_apply_slice(const BnArgs& a, int c, int grp,
   plane_slice(a.HW, split, k, &lo, &hi);
   const bool vec = (a.HW & 3) == 0;
   const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  for (int n = a.rows[grp] + sub; n < a.rows[grp + 1]; n += NT / 64) {
+  for (int n = group_row(a, grp) + sub; n < group_row(a, grp + 1); n += NT / 64) {
     const size_t base = ((size_t)n * a.C + c) * a.HW;
     if (vec) {
       for (int i = lo + 4 * lane; i < hi; i += 4 * 64) {
@@ -284,7 +295,7 @@ __device__ __forceinline__ void bwd_apply_slice(const BnArgs& a, int c, int grp,
 // per-(channel, group) sums of the two partial columns written by the two-launch reduction kernels
 __device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, double* t0, double* t1) {
   double s0 = 0.0, s1 = 0.0;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   for (int k = 0; k < split; ++k) {
     s0 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2];
     s1 += a.part[(((size_t)c * a.G + grp) * a.split + k) * 2 + 1];
@@ -296,7 +307,7 @@ __device__ __forceinline__ void group_totals(const BnArgs& a, int c, int grp, do
 __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
   __shared__ double sh[4];
   const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   if ((int)blockIdx.x >= split) return;      // the grid is sized for the largest group
   double ts, tss;
   stats_slice(a, c, grp, split, blockIdx.x, sh, &ts, &tss);
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(BnArgs a) {
 __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
   __shared__ float s_mean, s_scale, s_shift;
   const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   if ((int)blockIdx.x >= split) return;
   if (threadIdx.x == 0) {
     double ts, tss, mean, var;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(BnArgs a) {
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
   __shared__ double sh[4];
   const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   if ((int)blockIdx.x >= split) return;
   double tg, tgx;
   bwd_reduce_slice(a, c, grp, split, blockIdx.x, sh, &tg, &tgx);
@@ -345,12 +356,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(BnArgs a) {
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(BnArgs a) {
   __shared__ float s_k[3];
   const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   if ((int)blockIdx.x >= split) return;
   if (threadIdx.x == 0) {
     double tg, tgx;
     group_totals(a, c, grp, &tg, &tgx);
-    const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
+    const double cnt = (double)(group_row(a, grp + 1) - group_row(a, grp)) * (double)a.HW;
     s_k[0] = (float)(tg / cnt);
     s_k[1] = (float)(tgx / cnt);
     s_k[2] = a.gamma[c] * a.invstd[(size_t)grp * a.C + c];
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_small_kernel(BnArgs a) {
   __shared__ double sh[4];
   __shared__ float s_mean, s_scale, s_shift;
   const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   double ts = 0.0, tss = 0.0;
   for (int k = 0; k < split; ++k) {          // the same slices, added in the same order, as the two-launch form
     double ks, kss;
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_small_kernel(BnArgs a) {
   __shared__ double sh[4];
   __shared__ float s_k[3];
   const int c = blockIdx.y, grp = blockIdx.z;
-  const int split = pick_split(a.rows[grp + 1] - a.rows[grp], a.HW);
+  const int split = pick_split(group_row(a, grp + 1) - group_row(a, grp), a.HW);
   double tg = 0.0, tgx = 0.0;
   for (int k = 0; k < split; ++k) {
     double kg, kgx;
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_small_kernel(BnArgs a) {
     tg += kg; tgx += kgx;
   }
   if (threadIdx.x == 0) {
-    const double cnt = (double)(a.rows[grp + 1] - a.rows[grp]) * (double)a.HW;
+    const double cnt = (double)(group_row(a, grp + 1) - group_row(a, grp)) * (double)a.HW;
     s_k[0] = (float)(tg / cnt);
     s_k[1] = (float)(tgx / cnt);
     s_k[2] = a.gamma[c] * a.invstd[(size_t)grp * a.C + c];
@@ -897,6 +908,48 @@ int fill_groups(const int32_t* group_rows, int G, int N, BnArgs* a) {
 }
 }  // namespace
 
+namespace {
+int launch_bn_fwd(BnArgs& a, int biggest, bool running, hipStream_t st) {
+  a.split = pick_split(biggest, a.HW);
+  if ((long long)biggest * a.HW <= BN_SMALL_ELEMS) {       // one launch (+ a C-thread one for the cross-group results)
+    hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(1, (unsigned)a.C, (unsigned)a.G), dim3(NT), 0, st, a);
+    if (a.G > 1 && running)
+      hipLaunchKernelGGL(bn_running_small_kernel, dim3((unsigned)((a.C + 63) / 64)), dim3(64), 0, st, a);
+    return status();
+  }
+  const dim3 grid((unsigned)a.split, (unsigned)a.C, (unsigned)a.G);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, st, a);
+  return status();
+}
+int launch_bn_bwd(BnArgs& a, int biggest, hipStream_t st) {
+  a.split = pick_split(biggest, a.HW);
+  if ((long long)biggest * a.HW <= BN_SMALL_ELEMS) {
+    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, (unsigned)a.C, (unsigned)a.G), dim3(NT), 0, st, a);
+    if (a.G > 1) hipLaunchKernelGGL(bn_param_grad_small_kernel, dim3((unsigned)((a.C + 63) / 64)), dim3(64), 0, st, a);
+    return status();
+  }
+  const dim3 grid((unsigned)a.split, (unsigned)a.C, (unsigned)a.G);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
+  return status();
+}
+void fill_fwd(BnArgs& a, const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+              float* save_mean, float* save_invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+              double* scratch, int N, int C, int HW, double eps, double momentum, int relu) {
+  a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.y = y; a.part = scratch; a.mean = save_mean;
+  a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.batches = num_batches_tracked; a.N = N; a.C = C; a.HW = HW;
+  a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
+}
+void fill_bwd(BnArgs& a, const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+              const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual, float* grad_gamma,
+              float* grad_beta, double* scratch, int N, int C, int HW, int relu) {
+  a.x = x; a.y = const_cast<float*>(y); a.dy = grad_y; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(save_mean);
+  a.invstd = const_cast<float*>(save_invstd); a.dx = grad_x; a.dres = grad_residual; a.dgamma = grad_gamma;
+  a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.relu = relu;
+}
+}  // namespace
+
 int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                            float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                            long long* num_batches_tracked, double* scratch, const int32_t* group_rows, int G,
@@ -908,21 +961,10 @@ int bbd_bn_act_grouped_fwd(const float* x, const float* residual, const float* g
   BnArgs a = {};
   const int biggest = fill_groups(group_rows, G, N, &a);
   if (!biggest) return BBD_E_BADARG;
-  a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.y = y; a.part = scratch; a.mean = save_mean;
-  a.invstd = save_invstd; a.run_mean = running_mean; a.run_var = running_var; a.batches = num_batches_tracked; a.N = N; a.C = C; a.HW = HW;
-  a.split = pick_split(biggest, HW); a.relu = relu; a.eps = (float)eps; a.momentum = (float)momentum;
+  fill_fwd(a, x, residual, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, scratch,
+           N, C, HW, eps, momentum, relu);
   a.untracked = untracked_groups;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if ((long long)biggest * HW <= BN_SMALL_ELEMS) {       // one launch (+ a C-thread one for the cross-group results)
-    hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(1, (unsigned)C, (unsigned)G), dim3(NT), 0, st, a);
-    if (G > 1 && (running_mean || num_batches_tracked))
-      hipLaunchKernelGGL(bn_running_small_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, a);
-    return status();
-  }
-  const dim3 grid((unsigned)a.split, (unsigned)C, (unsigned)G);
-  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(NT), 0, st, a);
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, st, a);
-  return status();
+  return launch_bn_fwd(a, biggest, running_mean || num_batches_tracked, static_cast<hipStream_t>(stream));
 }
 
 int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
@@ -935,19 +977,41 @@ int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, 
   BnArgs a = {};
   const int biggest = fill_groups(group_rows, G, N, &a);
   if (!biggest) return BBD_E_BADARG;
-  a.x = x; a.y = const_cast<float*>(y); a.dy = grad_y; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(save_mean);
-  a.invstd = const_cast<float*>(save_invstd); a.dx = grad_x; a.dres = grad_residual; a.dgamma = grad_gamma;
-  a.dbeta = grad_beta; a.part = scratch; a.N = N; a.C = C; a.HW = HW; a.split = pick_split(biggest, HW); a.relu = relu;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if ((long long)biggest * HW <= BN_SMALL_ELEMS) {
-    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(1, (unsigned)C, (unsigned)G), dim3(NT), 0, st, a);
-    if (G > 1) hipLaunchKernelGGL(bn_param_grad_small_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, st, a);
-    return status();
-  }
-  const dim3 grid((unsigned)a.split, (unsigned)C, (unsigned)G);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NT), 0, st, a);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, a);
-  return status();
+  fill_bwd(a, x, y, grad_y, gamma, beta, save_mean, save_invstd, grad_x, grad_residual, grad_gamma, grad_beta, scratch, N, C,
+           HW, relu);
+  return launch_bn_bwd(a, biggest, static_cast<hipStream_t>(stream));
+}
+
+// Device-resident group table (ABI 7): the same launches with NOTHING of the batch signature in their arguments.
+int bbd_bn_act_grouped_dev_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                               float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, double* scratch, const int32_t* group_table, int G,
+                               int max_group_rows, int N, int C, int HW, double eps, double momentum, int relu,
+                               void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch || !group_table || N <= 0 || C <= 0 || HW <= 0)
+    return BBD_E_BADARG;
+  if (G < 1 || G > BBD_BN_MAX_GROUPS || max_group_rows < 1 || max_group_rows > N) return BBD_E_BADARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return BBD_E_BADARG;
+  BnArgs a = {};
+  fill_fwd(a, x, residual, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, scratch,
+           N, C, HW, eps, momentum, relu);
+  a.G = G; a.rows_dev = group_table;
+  return launch_bn_fwd(a, max_group_rows, running_mean || num_batches_tracked, static_cast<hipStream_t>(stream));
+}
+
+int bbd_bn_act_grouped_dev_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
+                               float* grad_gamma, float* grad_beta, double* scratch, const int32_t* group_table, int G,
+                               int max_group_rows, int N, int C, int HW, int relu, void* stream) {
+  if (!x || !grad_y || !gamma || !save_mean || !save_invstd || !grad_x || !grad_gamma || !grad_beta || !scratch ||
+      !group_table || N <= 0 || C <= 0 || HW <= 0 || (relu && !y && !beta))
+    return BBD_E_BADARG;
+  if (G < 1 || G > BBD_BN_MAX_GROUPS || max_group_rows < 1 || max_group_rows > N) return BBD_E_BADARG;
+  BnArgs a = {};
+  fill_bwd(a, x, y, grad_y, gamma, beta, save_mean, save_invstd, grad_x, grad_residual, grad_gamma, grad_beta, scratch, N, C,
+           HW, relu);
+  a.G = G; a.rows_dev = group_table;
+  return launch_bn_bwd(a, max_group_rows, static_cast<hipStream_t>(stream));
 }
 
 int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,

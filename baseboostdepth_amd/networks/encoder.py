@@ -29,7 +29,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                                       self.momentum, self.eps, relu, num_batches_tracked=self.num_batches_tracked)
         if self.training and x.is_cuda:
             from .. import ops
-            assert ops._bn_groups is None, "a batched pass with call groups needs the fused BatchNorm path"
+            assert ops._bn_groups is None and ops._bn_device is None, \
+                "a batched pass with call groups needs the fused BatchNorm path"
         y = super().forward(x)
         if residual is not None:
             y = y + residual

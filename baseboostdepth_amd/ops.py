@@ -127,6 +127,10 @@ class HipBackend:
 _BACKEND = None
 
 
+def _frame_list(frame_tensors):
+    return [frame_tensors] if torch.is_tensor(frame_tensors) else list(frame_tensors.values())
+
+
 def default_backend():
     global _BACKEND
     if _BACKEND is None:
@@ -135,8 +139,15 @@ def default_backend():
 
 
 def frame_pointer_array(frame_tensors):
-    """Host array[MAX_FRAME_SLOTS] of base addresses; `frame_tensors` maps frame id -> [n,3,H,W]."""
+    """Host array[MAX_FRAME_SLOTS] of base addresses; `frame_tensors` maps frame id -> [n,3,H,W] - or IS one pool tensor
+    [F,3,H,W] holding every frame of the step (`pooled.PooledStep`): all slots then point at it and the tables address
+    it by row."""
     arr = (ctypes.c_void_p * MAX_FRAME_SLOTS)()
+    if torch.is_tensor(frame_tensors):
+        assert frame_tensors.is_contiguous() and frame_tensors.dtype == torch.float32
+        for i in range(MAX_FRAME_SLOTS):
+            arr[i] = frame_tensors.data_ptr()
+        return arr
     for f, t in frame_tensors.items():
         assert t.is_contiguous() and t.dtype == torch.float32
         arr[frame_slot(f)] = t.data_ptr()
@@ -429,6 +440,35 @@ def pose_compose(steps, table, pose_error, backend=None):
     return _PoseCompose.apply(steps, table, pose_error, backend or default_backend())
 
 
+class _PoseComposeStatic(torch.autograd.Function):
+    """`_PoseCompose` on tables that are views of the step's static table buffer (`pooled.PooledStep`): NO rows of which
+    the trailing ones are constant no-op rows, `off` = R + 1 entries."""
+
+    @staticmethod
+    def forward(ctx, steps, tab, off, refs, NO, pose_error, backend):
+        steps = steps.contiguous()
+        out = torch.empty(NO, 4, 4, device=steps.device, dtype=torch.float32)
+        backend._check(steps, tab, off, refs)
+        assert off.numel() == steps.shape[0] + 1 and tab.shape[0] >= NO
+        backend.run("bbd_pose_compose_fwd", steps, ptr(steps), ptr(tab), ptr(out), NO, float(pose_error))
+        ctx.save_for_backward(steps, tab, off, refs)
+        ctx.backend = backend
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        steps, tab, off, refs = ctx.saved_tensors
+        gout = gout.contiguous()
+        gsteps = torch.empty_like(steps)
+        ctx.backend.run("bbd_pose_compose_bwd", steps, ptr(steps), ptr(tab), ptr(off), ptr(refs), ptr(gout), ptr(gsteps),
+                        steps.shape[0])
+        return gsteps, None, None, None, None, None, None
+
+
+def pose_compose_static(steps, tab, off, refs, NO, pose_error, backend=None):
+    return _PoseComposeStatic.apply(steps, tab, off, refs, NO, pose_error, backend or default_backend())
+
+
 # ---------------------------------------------------------------------------- identity pre-pass
 def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     """[NI,H,W] identity photometric losses (no gradient: inputs are images)."""
@@ -436,7 +476,7 @@ def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     B, _, H, W = target.shape
     tb = plan.tables(target.device)
     ident = torch.empty(plan.NI, H, W, device=target.device, dtype=torch.float32)
-    backend._check(target, *frame_tensors.values())
+    backend._check(target, *_frame_list(frame_tensors))
     frames = frame_pointer_array(frame_tensors)
     # one workgroup per (target sample, tile) walks the sample's identity candidates (round 3).  Round 5 measured a streaming,
     # LDS-free form against it - slower (tools/experiments/streaming_identity.hip.txt, profiles/r05/identity_forms.txt)
@@ -454,11 +494,14 @@ def pose_table(plan, K, inv_K, poses):
     The kernels form P = (K@T)[:3,:] themselves (reference CPU rounding order, bbd_math.h).
     """
     tb = plan.tables(K.device)
-    NP = plan.NP
     T_all = torch.cat([poses[job] for job in plan.pose_jobs], dim=0)
-    K_all = K.index_select(0, tb["k_rows"])
-    iK_all = inv_K.index_select(0, tb["k_rows"])
-    pad = torch.zeros(NP, POSE_STRIDE - 37, device=K.device, dtype=torch.float32)
+    return pose_table_rows(T_all, K.index_select(0, tb["k_rows"]), inv_K.index_select(0, tb["k_rows"]))
+
+
+def pose_table_rows(T_all, K_all, iK_all):
+    """[NP,40] pose-table rows from the already gathered per-row matrices ([NP,4,4] each)."""
+    NP = T_all.shape[0]
+    pad = torch.zeros(NP, POSE_STRIDE - 37, device=T_all.device, dtype=torch.float32)
     return torch.cat([K_all[:, :3, :].reshape(NP, 12), T_all.reshape(NP, 16),
                       iK_all[:, :3, :3].reshape(NP, 9), pad], dim=1).contiguous()
 
@@ -486,7 +529,7 @@ class _FusedReprojectionMin(torch.autograd.Function):
         argmin = torch.empty(S, B, H, W, device=dev, dtype=torch.uint8)
         partial = torch.empty(S, B, ntiles, device=dev, dtype=torch.float32)
         warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
-        backend._check(depth, proj, target, ident, noise, *frame_tensors.values())
+        backend._check(depth, proj, target, ident, noise, *_frame_list(frame_tensors))
         frames = frame_pointer_array(frame_tensors)
         # pose table (K | T | inv_K) -> projection table (P | inv_K), once per step
         ptab = torch.empty(plan.NP, PROJ_STRIDE, device=dev, dtype=torch.float32)
@@ -560,7 +603,7 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         partial = torch.empty(S, B, ntiles, device=dev, dtype=torch.float32)
         warped = torch.empty(S, plan.NP, 3, H, W, device=dev, dtype=torch.float32) if materialize else None
         depth = torch.empty(S, B, H, W, device=dev, dtype=torch.float32) if want_depth else None
-        backend._check(proj, target, ident, noise, *disps, *frame_tensors.values())
+        backend._check(proj, target, ident, noise, *disps, *_frame_list(frame_tensors))
         frames = frame_pointer_array(frame_tensors)
         ptab = torch.empty(plan.NP, PROJ_STRIDE, device=dev, dtype=torch.float32)
         backend.run("bbd_pose_expand", proj, ptr(proj), ptr(ptab), plan.NP)
@@ -594,7 +637,9 @@ class _FusedReprojectionMinDisp(torch.autograd.Function):
         gscale = g_sum.contiguous().to(torch.float32)
         grad_up = torch.empty(S, B, H, W, device=dev, dtype=torch.float32)
         ntb = backend.num_tiles_bwd(H, W)
-        gp_partial = torch.empty(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
+        # (a plan view over static tables has more pose-table rows than the step uses: the launch never writes those)
+        make = torch.zeros if getattr(plan, "zero_partials", False) else torch.empty
+        gp_partial = make(S, plan.NP, ntb, 12, device=dev, dtype=torch.float32)
         backend.run("bbd_warp_ssim_min_disp_bwd", target, frames, ptr(target), _ptr_array(disps), _hw_array(disps), lo, hi,
                     ptr(depth), ptr(ptab), ptr(tb["cand"]), ptr(tb["ncand"]), ptr(backend.fused_work_items(plan, S, H, W, True, dev)),
                     ptr(argmin), ptr(gscale), ptr(grad_up), ptr(gp_partial), S, B, plan.NP, H, W, no_ssim)
@@ -1136,6 +1181,7 @@ def residual_add(x, branch, mask, backend=None):
 BN_MAX_GROUPS = 32          # BBD_BN_MAX_GROUPS of include/bbd_hip.h
 _bn_groups = None           # row counts of the call groups of the batched pass being run (None = one group)
 _bn_untracked = 0           # trailing groups of it that are padding (no running-statistics update)
+_bn_device = None           # (device group table, G, largest group) of `bn_call_groups_device`, or None
 
 
 class bn_call_groups:
@@ -1162,6 +1208,26 @@ class bn_call_groups:
         _bn_groups, _bn_untracked = self.prev
 
 
+class bn_call_groups_device:
+    """`with ops.bn_call_groups_device(table, G, max_rows):` - the call groups of `bn_call_groups`, read from a DEVICE table
+    (int32 [BN_MAX_GROUPS + 2]: rows[0..G], number of tracked groups at index BN_MAX_GROUPS + 1; groups may be empty) by
+    `bbd_bn_act_grouped_dev_*`: nothing of the batch signature is in the launch arguments, so one captured step graph
+    serves every ordering with the same padded row count (`pooled.PooledStep`).  `max_rows` bounds every group."""
+
+    def __init__(self, table, groups, max_rows):
+        assert table.dtype == torch.int32 and table.numel() >= BN_MAX_GROUPS + 2 and 1 <= groups <= BN_MAX_GROUPS
+        self.spec = (table, int(groups), int(max_rows))
+
+    def __enter__(self):
+        global _bn_device
+        self.prev, _bn_device = _bn_device, self.spec
+        return self
+
+    def __exit__(self, *exc):
+        global _bn_device
+        _bn_device = self.prev
+
+
 def _group_table(rows):
     arr = (ctypes.c_int32 * (len(rows) + 1))()
     for i, r in enumerate(rows):
@@ -1181,10 +1247,25 @@ class _BatchNormAct(torch.autograd.Function):
             residual = residual.contiguous()
             assert residual.shape == x.shape
         backend._check(x, weight, bias, residual, running_mean, running_var)
+        y = torch.empty_like(x)
+        if _bn_device is not None:
+            # group table on the device: the launch arguments hold nothing of the batch signature
+            table, G, biggest = _bn_device
+            assert _bn_groups is None and biggest <= N
+            rows = (table, G, biggest)
+            mean = torch.empty(G, C, device=x.device, dtype=torch.float32)
+            invstd = torch.empty(G, C, device=x.device, dtype=torch.float32)
+            scratch = torch.empty(backend.lib.bn_grouped_scratch_doubles(biggest, G, C, H * W), device=x.device,
+                                  dtype=torch.float64)
+            backend.run("bbd_bn_act_grouped_dev_fwd", x, ptr(x), ptr(residual), ptr(weight), ptr(bias), ptr(y), ptr(mean),
+                        ptr(invstd), ptr(running_mean), ptr(running_var), ptr(batches), ptr(scratch), ptr(table), G,
+                        biggest, N, C, H * W, float(eps), float(momentum), int(relu))
+            ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, mean, invstd)
+            ctx.meta = (bool(relu), residual is not None, backend, rows)
+            return y
         rows = _bn_groups if _bn_groups is not None else [N]
         assert sum(rows) == N, "ops.bn_call_groups does not describe this batch (%s vs %d rows)" % (rows, N)
         G = len(rows)
-        y = torch.empty_like(x)
         mean = torch.empty(G, C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(G, C, device=x.device, dtype=torch.float32)
         scratch = torch.empty(backend.lib.bn_grouped_scratch_doubles(max(rows), G, C, H * W), device=x.device,
@@ -1202,12 +1283,20 @@ class _BatchNormAct(torch.autograd.Function):
         x, y, weight, bias, mean, invstd = ctx.saved_tensors
         relu, has_res, backend, rows = ctx.meta
         N, C, H, W = x.shape
-        G = len(rows)
         grad_y = grad_y.contiguous()
         grad_x = torch.empty_like(x)
         grad_res = torch.empty_like(x) if has_res else None
         grad_w = torch.empty(C, device=x.device, dtype=torch.float32)
         grad_b = torch.empty(C, device=x.device, dtype=torch.float32)
+        if isinstance(rows, tuple):                     # device group table (bn_call_groups_device)
+            table, G, biggest = rows
+            scratch = torch.empty(backend.lib.bn_grouped_scratch_doubles(biggest, G, C, H * W), device=x.device,
+                                  dtype=torch.float64)
+            backend.run("bbd_bn_act_grouped_dev_bwd", x, ptr(x), ptr(y), ptr(grad_y), ptr(weight), ptr(bias), ptr(mean),
+                        ptr(invstd), ptr(grad_x), ptr(grad_res), ptr(grad_w), ptr(grad_b), ptr(scratch), ptr(table), G,
+                        biggest, N, C, H * W, int(relu))
+            return grad_x, grad_w, grad_b, grad_res, None, None, None, None, None, None, None
+        G = len(rows)
         scratch = torch.empty(backend.lib.bn_grouped_scratch_doubles(max(rows), G, C, H * W), device=x.device,
                               dtype=torch.float64)
         backend.run("bbd_bn_act_grouped_bwd", x, ptr(x), ptr(y), ptr(grad_y), ptr(weight), ptr(bias), ptr(mean),

@@ -30,6 +30,9 @@ class Trainer:
     _main_stream = None
     max_graphs = 8
     pose_pad_rows = 0
+    pooled_step = False      # `--rand`: the step in pooled form (`pooled.PooledStep`), one step graph per pose-row bucket
+    _pooled = None
+    last_pooled = None       # `pooled.PooledTables` of the last batch that ran in pooled form
 
     def __init__(self, options, backend=None):
         self.opt = options
@@ -102,6 +105,11 @@ class Trainer:
         self.pose_pad_rows = int(getattr(opt, "pose_pad_rows", 32 if getattr(opt, "rand", False) else 0))
         self._capture_checked = False
         self.graph_stats = {"replays": 0, "captures": 0, "eager": 0}
+        # `--rand` recipes: the step in pooled form (`pooled.PooledStep`: one frame pool, static step tables, shapes that
+        # depend on the padded pose rows only), so that ONE step graph serves every ordering of a row-count bucket
+        self.pooled_step = bool(getattr(opt, "pooled_step", getattr(opt, "rand", False))) and self.device.type == "cuda" \
+            and os.environ.get("BBD_POOLED_STEP", "1") != "0"
+        self._pooled = None
         # data parallel + step graph: capture the bucketed RCCL all-reduces INTO the graph (one graph per step, exchange
         # overlapped with backward inside the replay) instead of two graphs around one exposed all-reduce.  Opt-in:
         # multi-rank RCCL capture cannot be exercised on the one-GPU boxes this was built on
@@ -167,12 +175,154 @@ class Trainer:
         return (str(inputs["ordering"]), str(inputs.get("frames")), float(inputs["cutt"]), tuple(self.opt.scales), shapes,
                 tuple(g["lr"] for g in self.model_optimizer.param_groups))
 
+    def _graph_signature(self, inputs):
+        """(pooled tables | None, graph key, noise handed in?) of a batch.  In pooled form (`--rand`) the step's launches
+        depend on the batch through the padded pose rows, the group grid of the pose pass's BatchNorms and its row bound only:
+        ONE graph per row-count bucket, whatever the ordering (<= 14 for epochs >= 10, one for the early curriculum);
+        otherwise the key is the whole signature."""
+        tab = None
+        if self.pooled_step:
+            self.valid_frames = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
+            self.valid_frames_trimin(inputs)
+            tab = self._pooled_tables(inputs)
+        has_noise = inputs.get("noise") is not None
+        if tab is not None:
+            key = ("pooled", tab.R, tab.G, tab.bound, has_noise, bool(self.maxing_valid_frames), tuple(self.opt.scales),
+                   tuple(g["lr"] for g in self.model_optimizer.param_groups))
+        else:
+            key = self._graph_key(inputs)
+        return tab, key, has_noise
+
+    def _snapshot_state(self):
+        params = [p for g in self.model_optimizer.param_groups for p in g["params"]]
+        buffers = [b for m in self.models.values() for b in m.buffers()]
+        had_state = len(self.model_optimizer.state) > 0
+        return (params, buffers, [p.detach().clone() for p in params], [b.detach().clone() for b in buffers],
+                {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
+                 for p, st in self.model_optimizer.state.items()} if had_state else None, self.step)
+
+    def _restore_state(self, snap):
+        params, buffers, snap_p, snap_b, snap_s, step0 = snap
+        with torch.no_grad():
+            for p, v in zip(params, snap_p):
+                p.copy_(v)
+            for b, v in zip(buffers, snap_b):
+                b.copy_(v)
+            for p, st in self.model_optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if snap_s is not None and p in snap_s and k in snap_s[p]:
+                            v.copy_(snap_s[p][k])
+                        else:
+                            v.zero_()          # fresh Adam state: exp_avg = exp_avg_sq = step = 0
+        self.step = step0
+
+    def _capture(self, key, inputs, tab, has_noise, first_checked_capture=False):
+        """Warm-up (that must not train) + capture of `process_batch + backward + optimizer.step` for a graph key."""
+        # bound the cache: the least recently replayed signature goes first
+        while len(self._graphs) >= self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        pool = self._graph_pool
+        self.graph_stats["captures"] += 1
+        # a signature that has already run eagerly has warmed MIOpen / the allocator for its shapes: one warm-up step
+        warm_steps = 1 if ((self._sightings.get(key) or 0) > 0 or (tab is not None and self._graphs)) else 3
+        if tab is not None:
+            static = dict(inputs)           # the pooled step owns its static buffers: `load` copies the batch into them
+            scales = list(self.opt.scales)
+
+            def run_forward():
+                return self._pooled.forward(tab.R, tab.G, tab.bound, has_noise)
+        else:
+            static = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inputs.items()}
+
+            def run_forward():
+                return self.process_batch(dict(static))
+        # eager warm-up (allocator, MIOpen solutions, Adam state tensors) must not TRAIN: parameters,
+        # BatchNorm buffers, the optimizer state and the step counter are restored afterwards, so the
+        # first batch of a signature is counted once (by the replay that follows), like on the eager path
+        snap = self._snapshot_state()
+        warm = torch.cuda.Stream(device=self.device)
+        warm.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(warm):
+            # NO collective in the warm-up: a cache miss is a per-rank event (ranks draw different frame sets
+            # under --rand / the boosted recipe), so a rank that warms up must issue exactly the collectives of a
+            # rank that replays - the ONE exchange after the replay - or the ranks' all-reduces mis-pair
+            self._local_only = True
+            if hasattr(self.grad_sync, "paused"):
+                self.grad_sync.paused = True
+            try:
+                for _ in range(warm_steps):
+                    self._eager_step(dict(static))
+            finally:
+                self._local_only = False
+                if hasattr(self.grad_sync, "paused"):
+                    self.grad_sync.paused = False
+            self._restore_state(snap)
+        torch.cuda.current_stream(self.device).wait_stream(warm)
+        graph, tail = torch.cuda.CUDAGraph(), None
+        if tab is not None:
+            self._pooled.load(static, tab, scales)
+        if self.grad_sync is None:
+            self.model_optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph, pool=pool):
+                outputs, losses = run_forward()
+                losses["loss"].backward()
+                self.model_optimizer.step()
+        elif self.dp_capture:
+            # Captured collectives have only ever run with the ONE rank a single-GPU box allows (DESIGN.md 6), so the
+            # first captured signature is checked against the eager data-parallel step on the same batch: one eager
+            # step WITH its exchange gives the reference gradients, the state is restored, and after the first replay
+            # the flat gradient buffer must agree (every rank takes this path on its first signature: same collectives on
+            # all of them).  BBD_DP_CAPTURE_CHECK=0 skips it.
+            # (a one-shot flag, not "the cache is empty": LRU eviction empties the cache on a per-rank event, and a
+            # rank that re-ran the check alone would issue an exchange its peers do not - ADVICE r4)
+            check = first_checked_capture and os.environ.get("BBD_DP_CAPTURE_CHECK", "1") != "0"
+            self._capture_checked = True
+            if check:
+                snap2 = self._snapshot_state()
+                self._eager_step(dict(static))
+                self._capture_reference = self.flat_grads.flat.detach().clone()      # the exchanged (averaged) gradients
+                self._restore_state(snap2)
+                if tab is not None:
+                    self._pooled.load(static, tab, scales)
+            # data parallel, collectives captured: ONE graph.  The post-accumulate hooks fire while backward is being
+            # captured, so every bucket's pack + RCCL all-reduce becomes a node on RCCL's stream, forked from and
+            # joined to the capturing stream by the work handles' waits - the replay overlaps the exchange with
+            # the rest of backward like the eager overlapped loop does, with no host in between
+            self.flat_grads.zero()
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                outputs, losses = run_forward()
+                losses["loss"].backward()
+                self.grad_sync()
+                self.model_optimizer.step()
+        else:
+            # data parallel: the step is split in two graphs around ONE eager exchange of the flat gradient
+            # buffer - forward + backward + pack | all-reduce (RCCL, outside any capture) | optimizer.  The
+            # collective's ~1 ms is not overlapped with backward, in exchange for ~1 350 launches per step
+            # leaving the host (an eager multi-rank loop is host-bound on a busy node).  thread_local capture
+            # mode: the process group's watchdog thread may query events while this thread captures.
+            self.flat_grads.zero()
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                outputs, losses = run_forward()
+                losses["loss"].backward()
+                self.flat_grads.pack()
+            tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
+                self.model_optimizer.step()
+        # the graph's launches hold raw device addresses of the step tables / plan buffers: the entry keeps them alive
+        # itself (not only through the retained autograd nodes of `losses`)
+        keep = (getattr(self, "tables", None), getattr(self, "plan", None), self._pooled)
+        entry = self._graphs[key] = (graph, tail, None if tab is not None else static, outputs, losses, keep)
+        return entry
+
     def _graph_step(self, inputs):
-        """Capture `process_batch + backward + optimizer.step` for this batch signature once, then replay it:
+        """Capture `process_batch + backward + optimizer.step` for this batch's graph key once, then replay it:
         ~1 340 launches per step become one hipGraphLaunch, which takes the training thread's 16 ms of
-        launch work off the host (BaseBoostDepth's `--rand` batches change their frame sets per batch, so
-        they keep the eager path; fixed-frame-set training - the MD2 baseline - replays)."""
-        key = self._graph_key(inputs)
+        launch work off the host.  Fixed-frame-set training (the MD2 baseline) has one key; BaseBoostDepth's `--rand`
+        batches change their frame sets per batch and run in pooled form, where the key is the row-count bucket."""
+        tab, key, has_noise = self._graph_signature(inputs)
         entry = self._graphs.get(key)
         if entry is not None:
             self._graphs[key] = self._graphs.pop(key)       # most recently used last
@@ -181,154 +331,109 @@ class Trainer:
         first_checked_capture = bool(self.grad_sync is not None and self.dp_capture and not self._capture_checked)
         if entry is None and not first_checked_capture:
             seen = self._sightings.get(key) or 0
-            if seen < self.capture_after:
+            if seen < (0 if tab is not None else self.capture_after):      # (a bucket's graph is captured at first sight)
                 # not captured (yet): an eager step issues exactly the collectives of a replaying rank (one exchange of
                 # the flat buffer in the split-graph loop, the same buckets in the same order with captured collectives)
                 self._sightings.put(key, seen + 1)
                 self.graph_stats["eager"] += 1
                 return self._eager_step_off_default_stream(inputs)
         if entry is None:
-            # bound the cache: the least recently replayed signature goes first
-            while len(self._graphs) >= self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
-            pool = self._graph_pool
-            self.graph_stats["captures"] += 1
-            # a signature that has already run eagerly has warmed MIOpen / the allocator for its shapes: one warm-up step
-            warm_steps = 1 if (self._sightings.get(key) or 0) > 0 else 3
-            static = {k: (v.clone() if torch.is_tensor(v) and v.is_cuda else v) for k, v in inputs.items()}
-            # eager warm-up (allocator, MIOpen solutions, Adam state tensors) must not TRAIN: parameters,
-            # BatchNorm buffers, the optimizer state and the step counter are restored afterwards, so the
-            # first batch of a signature is counted once (by the replay below), like on the eager path
-            had_state = len(self.model_optimizer.state) > 0
-            params = [p for g in self.model_optimizer.param_groups for p in g["params"]]
-            buffers = [b for m in self.models.values() for b in m.buffers()]
-            snap_p = [p.detach().clone() for p in params]
-            snap_b = [b.detach().clone() for b in buffers]
-            snap_s = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
-                      for p, st in self.model_optimizer.state.items()} if had_state else None
-            step0 = self.step
-            warm = torch.cuda.Stream(device=self.device)
-            warm.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(warm):
-                # NO collective in the warm-up: a cache miss is a per-rank event (ranks draw different frame sets
-                # under --rand / the boosted recipe), so a rank that warms up must issue exactly the collectives of a
-                # rank that replays - the ONE exchange after the replay below - or the ranks' all-reduces mis-pair
-                self._local_only = True
-                if hasattr(self.grad_sync, "paused"):
-                    self.grad_sync.paused = True
-                try:
-                    for _ in range(warm_steps):
-                        self._eager_step(dict(static))
-                finally:
-                    self._local_only = False
-                    if hasattr(self.grad_sync, "paused"):
-                        self.grad_sync.paused = False
-                with torch.no_grad():
-                    for p, v in zip(params, snap_p):
-                        p.copy_(v)
-                    for b, v in zip(buffers, snap_b):
-                        b.copy_(v)
-                    for p, st in self.model_optimizer.state.items():
-                        for k, v in st.items():
-                            if torch.is_tensor(v):
-                                if snap_s is not None and p in snap_s and k in snap_s[p]:
-                                    v.copy_(snap_s[p][k])
-                                else:
-                                    v.zero_()          # fresh Adam state: exp_avg = exp_avg_sq = step = 0
-            self.step = step0
-            torch.cuda.current_stream(self.device).wait_stream(warm)
-            graph, tail = torch.cuda.CUDAGraph(), None
-            if self.grad_sync is None:
-                self.model_optimizer.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph, pool=pool):
-                    outputs, losses = self.process_batch(dict(static))
-                    losses["loss"].backward()
-                    self.model_optimizer.step()
-            elif self.dp_capture:
-                # Captured collectives have only ever run with the ONE rank a single-GPU box allows, so the
-                # first captured signature is checked against the eager data-parallel step on the same batch: one eager
-                # step WITH its exchange gives the reference gradients, the state is restored, and after the first replay
-                # below the flat gradient buffer must agree (every rank takes this path on its first signature: same collectives on
-                # all of them).  BBD_DP_CAPTURE_CHECK=0 skips it.
-                # (a one-shot flag, not "the cache is empty": LRU eviction empties the cache on a per-rank event, and a
-                # rank that re-ran the check alone would issue an exchange its peers do not - ADVICE r4)
-                check = first_checked_capture and os.environ.get("BBD_DP_CAPTURE_CHECK", "1") != "0"
-                self._capture_checked = True
-                if check:
-                    snap2_p = [p.detach().clone() for p in params]
-                    snap2_b = [b.detach().clone() for b in buffers]
-                    snap2_s = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)}
-                               for p, st in self.model_optimizer.state.items()}
-                    self._eager_step(dict(static))
-                    self._capture_reference = self.flat_grads.flat.detach().clone()      # the exchanged (averaged) gradients
-                    with torch.no_grad():
-                        for p, v in zip(params, snap2_p):
-                            p.copy_(v)
-                        for b, v in zip(buffers, snap2_b):
-                            b.copy_(v)
-                        for p, st in self.model_optimizer.state.items():
-                            for k, v in st.items():
-                                if torch.is_tensor(v):
-                                    v.copy_(snap2_s[p][k]) if (p in snap2_s and k in snap2_s[p]) else v.zero_()
-                    self.step = step0
-                # data parallel, collectives captured: ONE graph.  The post-accumulate hooks fire while backward is being
-                # captured, so every bucket's pack + RCCL all-reduce becomes a node on RCCL's stream, forked from and
-                # joined to the capturing stream by the work handles' waits - the replay overlaps the exchange with
-                # the rest of backward like the eager overlapped loop does, with no host in between
-                self.flat_grads.zero()
-                with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
-                    outputs, losses = self.process_batch(dict(static))
-                    losses["loss"].backward()
-                    self.grad_sync()
-                    self.model_optimizer.step()
-            else:
-                # data parallel: the step is split in two graphs around ONE eager exchange of the flat gradient
-                # buffer - forward + backward + pack | all-reduce (RCCL, outside any capture) | optimizer.  The
-                # collective's ~1 ms is not overlapped with backward, in exchange for ~1 350 launches per step
-                # leaving the host (an eager multi-rank loop is host-bound on a busy node).  thread_local capture
-                # mode: the process group's watchdog thread may query events while this thread captures.
-                self.flat_grads.zero()
-                with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
-                    outputs, losses = self.process_batch(dict(static))
-                    losses["loss"].backward()
-                    self.flat_grads.pack()
-                tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(tail, pool=pool, capture_error_mode="thread_local"):
-                    self.model_optimizer.step()
-            entry = self._graphs[key] = (graph, tail, static, outputs, losses)
-        graph, tail, static, outputs, losses = entry
+            entry = self._capture(key, inputs, tab, has_noise, first_checked_capture)
+        graph, tail, static, outputs, losses, _ = entry
         self.graph_stats["replays"] += 1
-        for k, v in inputs.items():
-            if torch.is_tensor(v) and v.is_cuda:
-                static[k].copy_(v, non_blocking=True)
+        if tab is not None:
+            self._pooled.load(inputs, tab, list(self.opt.scales))
+            outputs = self._pooled.with_pose_views(outputs, tab)
+        else:
+            for k, v in inputs.items():
+                if torch.is_tensor(v) and v.is_cuda:
+                    static[k].copy_(v, non_blocking=True)
         graph.replay()
         if tail is not None:
             self.grad_sync.exchange()
             tail.replay()
-        ref = getattr(self, "_capture_reference", None)
-        if ref is not None:
-            # first replay of the first captured-collective graph vs the eager data-parallel step (see the capture above);
-            # the bar is the run-to-run spread of MIOpen's atomics-based weight gradients, far below a wrong exchange
-            self._capture_reference = None
-            num = float((self.flat_grads.flat - ref).abs().sum())
-            den = float(ref.abs().sum()) + 1e-30
-            ok = num / den < 1e-3
-            world_ok = ok
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                # the verdict is collective: a rank that raised alone would leave its peers waiting in their next all-reduce
-                flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                world_ok = bool(float(flag) > 0.5)
-            if not world_ok:
-                raise RuntimeError("step graph with captured collectives disagrees with the eager data-parallel step on its "
-                                   "first batch (relative L1 difference of the exchanged gradients on this rank %.3e%s): "
-                                   "refusing to train on it; use dp_capture=False (split graphs around one exposed all-reduce)"
-                                   % (num / den, "" if not ok else "; another rank failed the check"))
+        self._verify_captured_exchange()
         self.step += 1
         return outputs, losses
+
+    def _verify_captured_exchange(self):
+        """First replay of the first captured-collective graph vs the eager data-parallel step on the same batch (see
+        `_capture`); the bar is the run-to-run spread of MIOpen's atomics-based weight gradients, far below a wrong exchange."""
+        ref = getattr(self, "_capture_reference", None)
+        if ref is None:
+            return
+        self._capture_reference = None
+        num = float((self.flat_grads.flat - ref).abs().sum())
+        den = float(ref.abs().sum()) + 1e-30
+        ok = num / den < 1e-3
+        world_ok = ok
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the verdict is collective: a rank that raised alone would leave its peers waiting in their next all-reduce
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            world_ok = bool(float(flag) > 0.5)
+        if not world_ok:
+            raise RuntimeError("step graph with captured collectives disagrees with the eager data-parallel step on its "
+                               "first batch (relative L1 difference of the exchanged gradients on this rank %.3e%s): "
+                               "refusing to train on it; use dp_capture=False (split graphs around one exposed all-reduce)"
+                               % (num / den, "" if not ok else "; another rank failed the check"))
+
+    def prewarm(self, epoch=None, seed=0):
+        """Before the first step of a `--rand` curriculum phase: capture the step graph of EVERY pose-row bucket the phase
+        can meet (the pooled form's graph keys: <= 14 for epochs >= 10, one for the early curriculum) on synthetic batches,
+        so that no training step pays for a capture, for the allocator meeting a new activation size or for MIOpen loading
+        a row count's solvers (round 5: a fresh process ran its first 30 steps at half speed).  The warm-up steps inside a
+        capture restore parameters, buffers, optimizer state and the step counter: nothing is trained.  Without step
+        graphs the buckets get one restored eager step each.  Returns {"buckets": n, "seconds": t}."""
+        import time
+        if not self.pooled_step:
+            return {"buckets": 0, "seconds": 0.0}
+        from . import pooled, synthetic
+        t0 = time.perf_counter()
+        opt = self.opt
+        epoch = self.epoch if epoch is None else epoch
+        early = bool(getattr(opt, "rand", True)) and epoch < 10
+        scales = list(opt.scales)
+        cutt = 0.1 + 0.04 * epoch if epoch < 10 else 0.15 * epoch - 0.9
+        if self._pooled is None:
+            self._pooled = pooled.PooledStep(self)
+        keep_frames = list(opt.frame_ids)
+        done = 0
+        for ms in self._pooled.bucket_orderings(early):
+            batch = synthetic.synthetic_batch(ms, opt.height, opt.width, scales, device=self.device, seed=seed + done)
+            batch.pop("noise")
+            batch["cutt"] = torch.tensor(cutt)
+            opt.frame_ids = sorted(batch["frames"], key=_frame_sort_key)
+            if self.use_graph:
+                tab, key, has_noise = self._graph_signature(batch)
+                if tab is None or key in self._graphs:
+                    continue
+                first = bool(self.grad_sync is not None and self.dp_capture and not self._capture_checked)
+                snap = self._snapshot_state() if first else None
+                entry = self._capture(key, batch, tab, has_noise, first)
+                if first:
+                    # captured collectives: the one-shot check against the eager exchange needs the graph's first replay
+                    self._pooled.load(batch, tab, scales)
+                    entry[0].replay()
+                    self._verify_captured_exchange()
+                    self._restore_state(snap)
+            else:
+                snap = self._snapshot_state()
+                self._local_only = True
+                if hasattr(self.grad_sync, "paused"):
+                    self.grad_sync.paused = True
+                try:
+                    self._eager_step(batch)
+                finally:
+                    self._local_only = False
+                    if hasattr(self.grad_sync, "paused"):
+                        self.grad_sync.paused = False
+                self._restore_state(snap)
+            done += 1
+        opt.frame_ids = keep_frames
+        torch.cuda.synchronize(self.device)
+        return {"buckets": done, "seconds": round(time.perf_counter() - t0, 3)}
 
     def _eager_step_off_default_stream(self, inputs):
         """An eager step of a trainer that ALSO captures step graphs runs on a side stream of its own, never on the
@@ -435,6 +540,8 @@ class Trainer:
         self.set_train()
         if getattr(self.opt, "rand", False):
             self.opt.scales = [0, 1, 2, 3] if self.epoch < 10 else [0]
+            if self.pooled_step and getattr(self.opt, "prewarm", True):
+                self.last_prewarm = self.prewarm(self.epoch)      # (graphs already captured for this phase / lr are skipped)
         last = None
         log_frequency = getattr(self.opt, "log_frequency", 0)
         for self.batch_idx, inputs in enumerate(loader):
@@ -557,6 +664,14 @@ class Trainer:
         if is_train:
             self.valid_frames = list(set([el for sub in inputs["ordering"] for el in sub if el != 0]))
             self.valid_frames_trimin(inputs)
+            tab = self._pooled_tables(inputs)
+            if tab is not None:
+                # pooled form (`--rand`): the batch goes into the static frame pool / table buffer (ONE table upload), the
+                # step runs on them with shapes that depend on the padded pose rows only
+                ps = self._pooled
+                ps.load(inputs, tab, list(self.opt.scales))
+                outputs, losses = ps.forward(tab.R, tab.G, tab.bound, inputs.get("noise") is not None)
+                return ps.with_pose_views(outputs, tab), losses
             self._step_tables(inputs)          # the step's ONE table upload goes out before its first launch
             side = self._pose_stream()
             if side is None:
@@ -638,6 +753,27 @@ class Trainer:
         self.tables = steptables.get_step_tables(self.plan, opt.frame_ids, incremental, partial, bool(opt.decomp),
                                                  len(opt.scales), opt.height, opt.width, self.device, lib, self._pose_chunk())
         return self.tables
+
+    def _pooled_tables(self, inputs):
+        """`pooled.PooledTables` of this batch when the step can run in pooled form, else None (the per-signature path):
+        needs the fused disparity-mode launches, the batched pose pass, the composition kernel and a batch of the trainer's
+        batch size."""
+        if not self.pooled_step:
+            return None
+        opt, plan = self.opt, self.plan
+        if (getattr(opt, "materialize_warps", False) or not getattr(opt, "fused_disp", True) or len(opt.scales) > 4
+                or not ops.FUSED_POSE_COMPOSE or not self._batched_pose_pairs() or plan.B != opt.batch_size):
+            return None
+        cutt = inputs["cutt"]
+        if torch.is_tensor(cutt) and cutt.is_cuda:
+            cutt = inputs["cutt"] = cutt.detach().cpu()
+        self.maxing_valid_frames = float(cutt) > 0.5
+        if self._pooled is None:
+            from . import pooled
+            self._pooled = pooled.PooledStep(self)
+        self.tables = None
+        self.last_pooled = self._pooled.tables_for(plan, inputs)
+        return self.last_pooled
 
     def _rows(self, tensor, rows):
         if rows is None or (len(rows) == tensor.shape[0] and list(rows) == list(range(tensor.shape[0]))):

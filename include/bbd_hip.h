@@ -32,8 +32,10 @@ extern "C" {
  * depth-wise token weight gradient's scratch contract (one partial row per workgroup) and `add_input` of
  * bbd_dwconv_tokens_fwd became a bit field (round 3, with the bbd_token_ln_* / bbd_colsum additions); 5 = round 4 (the
  * work-item table of the fused launches, per-row `invert` of the pose matrices, the multi-scale smoothness launches);
- * 6 = round 5: bbd_bn_act_grouped_fwd gained `untracked_groups` (the padding group of the batched pose pass). */
-#define BBD_ABI_VERSION 6
+ * 6 = round 5: bbd_bn_act_grouped_fwd gained `untracked_groups` (the padding group of the batched pose pass);
+ * 7 = round 6: bbd_bn_act_grouped_dev_fwd / _bwd (group table resident on the device: launches whose arguments do not
+ * depend on the batch signature). */
+#define BBD_ABI_VERSION 7
 
 /* Source frames live in separate tensors, one per frame id (inputs[("color", f, 0)],
  * trainer.py:428).  A "slot" indexes a host array of their base pointers. */
@@ -358,6 +360,25 @@ int bbd_bn_act_grouped_bwd(const float* x, const float* y, const float* grad_y, 
                            const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
                            float* grad_gamma, float* grad_beta, double* scratch, const int32_t* group_rows, int G, int N,
                            int C, int HW, int relu, void* stream);
+/* The same two launches with the group table RESIDENT ON THE DEVICE (ABI 7): group_table = device int32
+ * [BBD_BN_MAX_GROUPS + 2] = { rows[0] = 0, rows[1], ..., rows[G] = N, (unused up to index BBD_BN_MAX_GROUPS),
+ * [BBD_BN_MAX_GROUPS + 1] = number of TRACKED groups }.  Groups may be EMPTY (rows[g+1] == rows[g]: nothing is read or
+ * written for them); the groups from the tracked count on are the padding of bbd_bn_act_grouped_fwd's `untracked_groups`.
+ * max_group_rows (host) bounds every group's row count (it sizes the grid and the scratch:
+ * bbd_bn_grouped_scratch_doubles(max_group_rows, G, C, HW)); a group holds its own statistics exactly as in the
+ * host-table form - bit for bit the same numbers.  Why: the boosted recipe redraws every sample's frame set per item
+ * (mono_dataset.py:87-109), so the pose pass's call groups change every step; with the table on the device NOTHING in the
+ * launch arguments depends on the batch signature, and one captured step graph serves every ordering that shares the
+ * padded row count (the table is a section of the step's one table upload). */
+int bbd_bn_act_grouped_dev_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                               float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, double* scratch, const int32_t* group_table, int G,
+                               int max_group_rows, int N, int C, int HW, double eps, double momentum, int relu,
+                               void* stream);
+int bbd_bn_act_grouped_dev_bwd(const float* x, const float* y, const float* grad_y, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
+                               float* grad_gamma, float* grad_beta, double* scratch, const int32_t* group_table, int G,
+                               int max_group_rows, int N, int C, int HW, int relu, void* stream);
 int bbd_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                    long long* num_batches_tracked, double* scratch, int N, int C, int HW, double eps,

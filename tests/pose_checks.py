@@ -13,7 +13,18 @@ def _fkey(f):
     return "s" if f == "s" else str(int(f))
 
 
-def check_pose_case(name, backend, device):
+class _FixedDisparities(torch.nn.Module):
+    """Stands in for encoder + depth decoder in the pooled form of the step: hands out the fixture's disparity maps."""
+
+    def __init__(self, disp=None):
+        super().__init__()
+        self.disp = disp
+
+    def forward(self, x):
+        return None if self.disp is None else {("disp", s): d for s, d in self.disp.items()}
+
+
+def check_pose_case(name, backend, device, pooled=False):
     case = Case(name, device=device)
     opt = make_opt(case, materialize_warps=False)
     tr = bare_trainer(opt, backend, device)
@@ -23,8 +34,17 @@ def check_pose_case(name, backend, device):
     inputs = dict(case.inputs)
     inputs["noise"] = case.noise
     tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
-    tr.valid_frames_trimin(inputs)
-    outputs = tr.predict_poses(inputs)
+    if pooled:
+        # the whole step in pooled form (pooled.PooledStep: frame pool, static tables, device call groups): the reference's
+        # pose keys come back as row ranges of its two pose buffers
+        tr.pooled_step, tr.pose_pad_rows = True, 32
+        tr.models.update(encoder=_FixedDisparities(), depth=_FixedDisparities(case.disp))
+        all_outputs, losses = tr.process_batch(inputs)
+        assert tr.last_pooled is not None and ("bbd", "pose_matrices") in all_outputs
+        outputs = {k: v for k, v in all_outputs.items() if k[0].startswith("cam_T_cam")}
+    else:
+        tr.valid_frames_trimin(inputs)
+        outputs = tr.predict_poses(inputs)
     # every pose tensor the reference produced, same key set, same values
     want = {k for k in case.z.files if k.startswith("out/cam_T_cam")}
     got = {"out/%s/%s/%s" % (k[0], _fkey(k[1]), _fkey(k[2])) for k in outputs}
@@ -34,10 +54,13 @@ def check_pose_case(name, backend, device):
         assert outputs[k].shape == e.shape, k
         got_k = outputs[k].detach().cpu()
         assert torch.allclose(got_k, e, atol=2e-6, rtol=1e-5), (k, float((got_k - e).abs().max()))
-    for s in case.scales:
-        outputs[("disp", s)] = case.disp[s]
-    outputs.update(tr.generate_images_pred(inputs, outputs))
-    losses = tr.compute_losses(inputs, outputs)
+    if pooled:
+        outputs = all_outputs
+    else:
+        for s in case.scales:
+            outputs[("disp", s)] = case.disp[s]
+        outputs.update(tr.generate_images_pred(inputs, outputs))
+        losses = tr.compute_losses(inputs, outputs)
     # poses differ from the reference's by fp32 round-off of a different op graph, so use the
     # tolerance protocol (loss 1e-5, arg-min equal off ties)
     report = compare_with_golden(case, tr, outputs, losses, map_tol=1e-4, tie_margin=2e-4, check_warps=False)

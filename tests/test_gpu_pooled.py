@@ -1,0 +1,295 @@
+"""GPU tier: the pooled form of the training step (`baseboostdepth_amd/pooled.py`) - one frame pool, static fixed-offset
+step tables, shapes that depend on the batch through the padded pose rows only - and the step graphs keyed on it.
+
+The reference redraws every sample's frame set per item (mono_dataset.py:87-109), restacks per batch (trainer.py:867-886)
+and overwrites `frame_ids` per batch (trainer.py:250): what is computed must not depend on which form runs it."""
+import warnings
+
+import pytest
+import torch
+
+from test_gpu_trainer import _deterministic_convolutions, make_opt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(ms, H, W, scales, seed, cutt, noise_seed=None):
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    b = synthetic_batch(ms, H, W, scales, device=DEV, seed=seed)
+    b.pop("noise")
+    b["cutt"] = torch.tensor(cutt)
+    if noise_seed is not None:
+        b["noise"] = torch.randn(len(ms), H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(noise_seed)) * 1e-5
+    return b
+
+
+# ------------------------------------------------------------------------------------------ BatchNorm with a device group table
+@pytest.mark.parametrize("N,C,HW,rows,untracked,relu,residual", [
+    (13, 8, (12, 20), [4, 3, 2, 4], 1, True, False),
+    (13, 8, (12, 20), [4, 3, 2, 4], 1, True, True),
+    (40, 64, (48, 160), [12, 12, 4, 12], 1, True, False),         # two-launch form
+    (9, 16, (6, 10), [5, 4], 0, False, False),
+    (7, 4, (3, 5), [7], 0, True, False),
+])
+def test_grouped_batch_norm_with_a_device_table_equals_the_host_table_form(N, C, HW, rows, untracked, relu, residual):
+    """bbd_bn_act_grouped_dev_* (ABI 7): the group table read from device memory, empty groups after the real ones, the
+    launch sized for a larger group than any present - the host-table launches' numbers, bit for bit: outputs, saved
+    statistics, running statistics, batch counter, data / residual / parameter gradients."""
+    from baseboostdepth_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(N * 131 + C)
+    x = torch.randn(N, C, *HW, device=DEV, generator=gen)
+    res = torch.randn(N, C, *HW, device=DEV, generator=gen) if residual else None
+    gy = torch.randn(N, C, *HW, device=DEV, generator=gen)
+    w0 = torch.rand(C, device=DEV, generator=gen) + 0.5
+    b0 = torch.randn(C, device=DEV, generator=gen)
+
+    def run(device_table):
+        xx = x.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True) if residual else None
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        nb = torch.zeros((), dtype=torch.int64, device=DEV)
+        if device_table:
+            G = ops.BN_MAX_GROUPS
+            tab = torch.zeros(G + 2, dtype=torch.int32)
+            acc = 0
+            for i, r in enumerate(rows):
+                acc += r
+                tab[i + 1] = acc
+            tab[len(rows) + 1:G + 1] = N
+            tab[G + 1] = len(rows) - untracked
+            ctx = ops.bn_call_groups_device(tab.to(DEV), 8 if len(rows) <= 8 else G, max(rows) + 3)
+        else:
+            ctx = ops.bn_call_groups(rows, padding_groups=untracked)
+        with ctx:
+            y = ops.batch_norm_act(xx, w, b, rr, rm, rv, 0.1, 1e-5, relu, num_batches_tracked=nb)
+        y.backward(gy)
+        return y.detach(), rm, rv, nb, xx.grad, (rr.grad if residual else None), w.grad, b.grad
+
+    a, d = run(False), run(True)
+    names = ["y", "running_mean", "running_var", "num_batches_tracked", "grad_x", "grad_residual", "grad_weight", "grad_bias"]
+    for name, u, v in zip(names, a, d):
+        assert (u is None) == (v is None), name
+        if u is not None:
+            assert torch.equal(u, v), (name, float((u.float() - v.float()).abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ pooled step == per-signature step
+@pytest.mark.parametrize("scales,cutt,ms", [
+    ([0], 1.35, [7, 5, 4, 3]), ([0], 1.35, [3, 1, 2, 5]), ([0], 1.35, [1, 1, 1, 1]),
+    ([0, 1, 2, 3], 0.3, [2, 1, 1, 0]), ([0, 1, 2, 3], 0.3, [0, 0, 2, 0]),
+])
+def test_pooled_step_equals_the_per_signature_step(scales, cutt, ms, monkeypatch):
+    """The same trainer, the same batch (noise handed in), `process_batch` + backward in both forms: per-pixel minimum,
+    arg-min, identity maps, depth and every pose output BIT FOR BIT; loss and gradients to summation order (the pose
+    table's gradient partials are reduced over a table of another height)."""
+    from baseboostdepth_amd.trainer import Trainer
+    _deterministic_convolutions(monkeypatch)
+    H, W, B = 96, 160, len(ms)
+    torch.manual_seed(0)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.rand = True
+    tr = Trainer(opt)
+    tr.opt.scales = list(scales)
+    tr.set_train()
+    state = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in tr.models.items()}
+    batch = _batch(ms, H, W, scales, 3, cutt, noise_seed=9)
+    tr.opt.frame_ids = sorted(batch["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+
+    def run(pooled):
+        tr.pooled_step = pooled
+        for k, m in tr.models.items():
+            m.load_state_dict(state[k])
+        tr.model_optimizer.zero_grad(set_to_none=True)
+        outputs, losses = tr.process_batch(dict(batch))
+        assert (("bbd", "pose_matrices") in outputs) == pooled
+        losses["loss"].backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for k, m in tr.models.items() for n, p in m.named_parameters(prefix=k) if p.grad is not None}
+        bufs = {"%s.%s" % (k, n): b.detach().clone() for k, m in tr.models.items() for n, b in m.named_buffers()}
+        return outputs, float(losses["loss"].detach()), grads, bufs
+
+    oa, la, ga, ba = run(False)
+    ob, lb, gb, bb = run(True)
+    assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)
+    plan = tr.plan
+    assert torch.equal(oa[("bbd", "to_optimise")], ob[("bbd", "to_optimise")])
+    assert torch.equal(oa[("bbd", "argmin")], ob[("bbd", "argmin")])
+    assert torch.equal(oa[("bbd", "identity")], ob[("bbd", "identity")][:plan.NI])
+    for k, v in oa.items():
+        if isinstance(k, tuple) and k[0] in ("disp", "depth", "cam_T_cam", "cam_T_cam_step", "cam_T_cam_error"):
+            assert k in ob and torch.equal(v, ob[k]), k
+    assert {k for k in ob if k[0].startswith("cam_T")} == {k for k in oa if k[0].startswith("cam_T")}
+    assert set(ga) == set(gb)
+    for n in ga:
+        scale = float(ga[n].abs().max()) + 1e-20
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * scale, (n, float((ga[n] - gb[n]).abs().max()) / scale)
+    for n in ba:                 # BatchNorm running statistics and batch counters: the padding groups are untracked
+        assert torch.equal(ba[n], bb[n]), n
+
+
+# ------------------------------------------------------------------------------------------ one graph, many orderings
+@pytest.mark.parametrize("scales,cutt,orderings", [
+    # epoch >= 10 (incremental + partial), B = 4: all of these pad to 48 pose rows with the large group grid
+    ([0], 1.35, [[7, 7, 1, 1], [7, 4, 2, 1], [7, 3, 3, 1], [7, 3, 2, 2], [7, 6, 1, 1], [7, 3, 1, 1], [7, 5, 1, 1]]),
+    # early curriculum: ONE row count whatever the ordering
+    ([0, 1, 2, 3], 0.3, [[2, 1, 1, 0], [2, 2, 1, 1], [1, 1, 1, 1], [2, 2, 2, 0], [2, 1, 0, 0], [0, 0, 0, 0], [2, 2, 2, 2]]),
+])
+def test_many_orderings_replay_one_graph_and_equal_the_eager_loop_bit_for_bit(scales, cutt, orderings, monkeypatch):
+    """>= 6 different orderings (every step a new signature) through ONE captured step graph: parameters and loss after the
+    sequence EQUAL the all-eager loop's, bit for bit (deterministic convolution solvers, the identity noise handed in)."""
+    from baseboostdepth_amd.trainer import Trainer
+    _deterministic_convolutions(monkeypatch)
+    H, W, B = 96, 160, 4
+
+    def run(graph):
+        opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+        opt.rand, opt.step_graph = True, graph
+        torch.manual_seed(5)
+        tr = Trainer(opt)
+        tr.opt.scales = list(scales)
+        tr.set_train()
+        seen = set()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i, ms in enumerate(orderings):
+                _, losses = tr.train_step(_batch(ms, H, W, scales, 60 + i, cutt, noise_seed=100 + i))
+                seen.add((tr.last_pooled.R, tr.last_pooled.G, tr.last_pooled.bound))
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"].detach()), tr, seen
+
+    pe, le, tre, rows_e = run(False)
+    pg, lg, trg, rows_g = run(True)
+    assert len(rows_g) == 1, rows_g                      # one row-count bucket ...
+    assert trg.graph_stats == {"eager": 0, "captures": 1, "replays": len(orderings)}, trg.graph_stats      # ... one graph
+    assert len(trg._graphs) == 1 and trg.step == len(orderings)
+    assert trg._pooled.stats["fallbacks"] == 0
+    assert le == lg and torch.equal(pe, pg)
+    for k, m in tre.models.items():
+        bg = dict(trg.models[k].named_buffers())
+        for n, be in m.named_buffers():
+            assert torch.equal(be, bg[n]), (k, n)
+
+
+def test_one_upload_per_step_and_no_synchronising_call_in_pooled_form():
+    """Pooled eager steps with a new ordering each: ONE packed table upload per step (the static table buffer), no single
+    uploads, nothing that synchronises the training thread (torch's sync debug mode raises on a pageable copy / .item())."""
+    from baseboostdepth_amd import steptables
+    from baseboostdepth_amd.trainer import Trainer
+    H, W, B = 96, 160, 4
+    torch.manual_seed(0)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.rand = True
+    tr = Trainer(opt)
+    tr.opt.scales = [0]
+    tr.set_train()
+    tr.train_step(_batch([7, 6, 5, 4], H, W, [0], 39, 1.35))
+    torch.cuda.synchronize()
+    for i, ms in enumerate([[7, 5, 4, 3], [6, 6, 2, 1], [7, 7, 7, 1], [5, 4, 3, 3], [7, 3, 2, 2]]):
+        b = _batch(ms, H, W, [0], 40 + i, 1.35)
+        steptables.reset_stats()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            _, l = tr.train_step(b)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert steptables.STATS["packed_uploads"] == 1 and steptables.STATS["single_uploads"] == 0, steptables.STATS
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(l["loss"]))
+
+
+def test_prewarm_captures_every_bucket_and_trains_nothing(monkeypatch):
+    """`Trainer.prewarm()`: the graphs of the phase's row-count buckets are captured on synthetic batches before the first
+    step - parameters, buffers, optimizer state and step counter untouched - and fresh orderings then only replay."""
+    from baseboostdepth_amd.trainer import Trainer
+    _deterministic_convolutions(monkeypatch)
+    H, W, B = 96, 160, 4
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.rand, opt.step_graph = True, True
+    torch.manual_seed(2)
+    tr = Trainer(opt)
+    tr.set_train()
+    before = torch.cat([p.detach().flatten().clone() for p in tr.parameters_to_train])
+    bufs = {"%s.%s" % (k, n): b.detach().clone() for k, m in tr.models.items() for n, b in m.named_buffers()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        info = tr.prewarm(epoch=3)                        # early curriculum: one bucket
+        assert info["buckets"] == 1 and len(tr._graphs) == 1 and tr.step == 0
+        tr.opt.scales = [0]
+        info = tr.prewarm(epoch=15)                       # epoch >= 10: every bucket the draws reach
+    assert info["buckets"] >= 3 and len(tr._graphs) == 1 + info["buckets"] and tr.step == 0
+    assert torch.equal(before, torch.cat([p.detach().flatten() for p in tr.parameters_to_train]))
+    for k, m in tr.models.items():
+        for n, b in m.named_buffers():
+            assert torch.equal(b, bufs["%s.%s" % (k, n)]), (k, n)
+    assert all(not st or float(st["step"]) == 0 for st in tr.model_optimizer.state.values())
+    captures = tr.graph_stats["captures"]
+    import random
+    rnd = random.Random(7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(8):
+            ms = sorted(rnd.choices(range(1, 8), [.050, .050, .077, .094, .139, .142, .448], k=B), reverse=True)
+            _, losses = tr.train_step(_batch(ms, H, W, [0], 80 + i, 1.35))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(losses["loss"])) and tr.step == 8
+    assert tr.graph_stats["replays"] == 8 and tr.graph_stats["eager"] == 0
+    assert tr.graph_stats["captures"] - captures <= 1          # (a bucket the seeded draws of prewarm() did not meet)
+
+
+# ------------------------------------------------------------------------------------------ golden vectors through the pool
+@pytest.mark.parametrize("name", ["pose_plain_3105_32x64", "pose_incr_3215_32x64", "pose_incr_partial_4327_32x64",
+                                  "pose_md2_b2_32x64"])
+def test_pose_modes_through_the_pooled_path_against_reference_vectors(name):
+    """The three pose modes of trainer.py:310-419 through the pooled step (pool gathers, device call groups, static
+    composition table, pose-table gather) against the SAME reference-generated fixtures as the per-signature path."""
+    from pose_checks import check_pose_case
+    from baseboostdepth_amd import ops
+    check_pose_case(name, ops.default_backend(), DEV, pooled=True)
+
+
+@pytest.mark.parametrize("name", ["tri_3105_32x64", "tri_7765_32x64", "tri_2102_32x64", "md2_b2_32x64", "tri_7_b1_192x640"])
+def test_fused_path_through_the_frame_pool_matches_reference_bit_for_bit(name):
+    """The golden `tri_*` / MD2 cases with the reference's own poses placed into the pooled step's pose buffers: min-loss
+    maps, arg-min ids, depth and identity maps bit for bit, gradients to the 1e-4 bar (frames read from the pool by row,
+    candidate / identity / pose-table rows from the static tables)."""
+    from golden_io import Case
+    from fused_runner import make_opt as case_opt, bare_trainer, compare_with_golden, compare_grads
+    from baseboostdepth_amd import ops, pooled
+    from baseboostdepth_amd.plan import STEREO
+    case = Case(name, device=DEV)
+    opt = case_opt(case, materialize_warps=False)
+    tr = bare_trainer(opt, ops.default_backend(), DEV)
+    tr.pooled_step, tr._pooled, tr.pose_pad_rows = True, None, 0
+    inputs = dict(case.inputs)
+    inputs["noise"] = case.noise
+    tr.opt.frame_ids = sorted(inputs["frames"], key=lambda it: float("inf") if isinstance(it, str) else abs(it))
+    tr.valid_frames_trimin(inputs)
+    inputs["cutt"] = torch.tensor(0.3)                  # poses are given per warp job (the plain pose mode's layout)
+    tr._batched_pose_pairs = lambda: True
+    tab = tr._pooled_tables(inputs)
+    assert tab is not None
+    ps = tr._pooled
+    ps.load(inputs, tab, list(opt.scales))
+    c = ps.caps
+    M = torch.eye(4, device=DEV).repeat(tab.R, 1, 1)
+    out = torch.eye(4, device=DEV).repeat(c.NO, 1, 1)
+    perr = case.poses_error()
+    leaves = {}
+    for okey, buf, o0, n, const in tab.pose_views:
+        f = okey[2]
+        src = case.poses[f] if okey[0] == "cam_T_cam" else perr[f]
+        assert src.shape[0] == n, (okey, src.shape, n)
+        leaves[okey] = src
+    Mrows = [M[i:i + 1] for i in range(tab.R)]
+    Orows = [out[i:i + 1] for i in range(c.NO)]
+    for okey, buf, o0, n, const in tab.pose_views:
+        for j in range(n):
+            (Mrows if buf == "M" else Orows)[o0 + j] = leaves[okey][j:j + 1]
+    M, out = torch.cat(Mrows, 0), torch.cat(Orows, 0)
+    outputs = {("disp", s): case.disp[s] for s in case.scales}
+    outputs, losses = ps.loss_part(M, out, outputs, True)
+    report = compare_with_golden(case, tr, outputs, losses, check_warps=False, exact=True)
+    losses["loss"].backward()
+    compare_grads(case, report)
