@@ -211,38 +211,78 @@ class FrameCache:
     new ones among them are copied to a resident home (device to device).  No eviction: when the resident area is full,
     further frames are used from the scratch area and decoded again next time (what the reference always does)."""
 
-    def __init__(self, device, capacity_bytes, scratch_bytes=192 << 20):
+    def __init__(self, device, capacity_bytes, scratch_bytes=192 << 20, regions=2):
+        """`regions` scratch areas of `scratch_bytes` each: every `DeviceCollate` that uses the cache takes one of its own
+        (`attach`) - two loaders iterated at the same time (training + validation, each with its own thread and stream) never
+        upload into the same bytes."""
+        import threading
         self.device = torch.device(device)
         self.scratch_bytes = int(scratch_bytes)
+        self.regions = max(1, int(regions))
         self.capacity = max(int(capacity_bytes), 0)
-        self.buf = torch.empty(self.capacity + self.scratch_bytes, dtype=torch.uint8, device=self.device)
+        self.buf = torch.empty(self.capacity + self.regions * self.scratch_bytes, dtype=torch.uint8, device=self.device)
         self.index = {}                 # path -> (byte offset, h, w)
         self.used = 0
-        self.hits = self.misses = self.passed_through = 0
+        self.hits = self.misses = self.passed_through = self.oversized = 0
+        self._held = set()              # scratch regions in use
+        self._lock = threading.Lock()   # admit / index / used are shared by the loaders' threads
+        self._ready = None              # event behind the last resident copy: a reader on another stream waits for it
 
     def __contains__(self, path):
         return path in self.index
 
-    def admit(self, path, scratch_off, h, w):
-        """A freshly decoded frame sits at `scratch_off` of the scratch area: give it a resident home if it is new and there
-        is room (one device-to-device copy, stream-ordered behind the upload), and say where this batch's kernels read it.
-        A frame another in-flight batch made resident in the meantime takes no second slot."""
-        hit = self.index.get(path)
-        if hit is not None:
-            return hit[0]
+    def attach(self, owner):
+        """Byte offset of a scratch area of this cache for the exclusive use of `owner` (a collate) for as long as it lives:
+        the area returns to the cache when the owner is garbage-collected (the trainer builds a new collate every epoch)."""
+        import weakref
+        with self._lock:
+            free = [i for i in range(self.regions) if i not in self._held]
+            if not free:
+                raise RuntimeError("FrameCache: more than %d collates alive on a cache built with that many scratch regions"
+                                   % self.regions)
+            self._held.add(free[0])
+            weakref.finalize(owner, self._release, free[0])
+            return self.capacity + free[0] * self.scratch_bytes
+
+    def _release(self, region):
+        with self._lock:
+            self._held.discard(region)
+
+    def wait_ready(self):
+        """Make the current stream wait for the resident copies other streams have enqueued (a frame admitted by another
+        loader's stream may be read as resident here before its copy has run otherwise)."""
+        ev = self._ready
+        if ev is not None and self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def mark_ready(self):
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._ready = ev
+
+    def admit(self, path, src_off, h, w):
+        """A freshly decoded frame sits at byte `src_off` of the buffer (inside the caller's scratch area): give it a
+        resident home if it is new and there is room (one device-to-device copy, stream-ordered behind the upload), and say
+        where this batch's kernels read it.  A frame another in-flight batch made resident in the meantime takes no second
+        slot.  Thread-safe: slot assignment and the index are guarded."""
         n = h * w * 3
-        if self.used + n > self.capacity:
-            self.passed_through += 1
-            return self.capacity + scratch_off
-        dst = self.used
-        self.used += n
-        self.buf[dst:dst + n].copy_(self.buf[self.capacity + scratch_off:self.capacity + scratch_off + n], non_blocking=True)
-        self.index[path] = (dst, h, w)
-        return dst
+        with self._lock:
+            hit = self.index.get(path)
+            if hit is not None:
+                return hit[0]
+            if self.used + n > self.capacity:
+                self.passed_through += 1
+                return src_off
+            dst = self.used
+            self.used += n
+            self.buf[dst:dst + n].copy_(self.buf[src_off:src_off + n], non_blocking=True)
+            self.index[path] = (dst, h, w)
+            return dst
 
     def stats(self):
         return {"frames": len(self.index), "resident_GB": round(self.used / 1e9, 3), "hits": self.hits, "misses": self.misses,
-                "passed_through": self.passed_through}
+                "passed_through": self.passed_through, "oversized_batches": self.oversized}
 
 
 class DeviceCollate:
@@ -256,6 +296,7 @@ class DeviceCollate:
     def __init__(self, height, width, scales, device, backend=None, ring=3, pack_threads=8, canonical=True, cache=None):
         self.height, self.width, self.scales = height, width, list(scales)
         self.cache = cache                 # FrameCache: decoded frames stay in HBM, a frame is decoded once (None: off)
+        self._scratch = cache.attach(self) if cache is not None else 0      # this collate's own scratch area of the cache
         # training batches are stacked in `plan.canonical_permutation` order (largest frame offset first): the loader's
         # order is a random shuffle anyway, and the trainer then meets far fewer distinct batch signatures
         self.canonical = bool(canonical)
@@ -329,27 +370,67 @@ class DeviceCollate:
         if cache is None:
             assert len(fresh) == len(entries), "frames were skipped but there is no FrameCache to take them from"
             src = host_src.to(dev, non_blocking=True)
+            if done is not None and used:
+                done.record()
+            jobs = []
+            for b, f in entries:
+                h, w = batch[b]["images"][f].shape[:2]
+                jobs.append((int(fresh_off[(b, f)]), int(h), int(w), batch[b]["flip"]))
+            level0 = self.pipe.resize(src, jobs, H, W)                       # uint8 [n_img, H, W, 3]
         else:
-            if used > cache.scratch_bytes:
-                raise RuntimeError("FrameCache scratch area too small: %d bytes in one batch" % used)
-            src = cache.buf
-            if used:
-                src[cache.capacity:cache.capacity + used].copy_(host_src, non_blocking=True)
-        if done is not None and used:
-            done.record()
-        jobs = []
-        for b, f in entries:
-            img = batch[b]["images"][f]
-            if img is not None:
-                off, (h, w) = fresh_off[(b, f)], img.shape[:2]
-                if cache is not None:
-                    cache.misses += 1
-                    off = cache.admit(batch[b]["paths"][f], off, int(h), int(w))
+            src, base = cache.buf, self._scratch
+            cache.wait_ready()
+            # the batch's fresh frames normally fit this collate's scratch area: ONE upload.  A batch that does not (a cold or
+            # full cache under the boosted recipe: 120-168 full-resolution frames, 170-235 MB) goes through it in several
+            # spans of the staging buffer - upload, admit, resize, next span (stream-ordered, so the area is free again)
+            spans, lo = [], 0
+            for e in sorted(fresh, key=fresh_off.__getitem__):
+                end = fresh_off[e] + batch[e[0]]["images"][e[1]].size
+                if end - lo > cache.scratch_bytes:
+                    if fresh_off[e] == lo:
+                        raise RuntimeError("FrameCache scratch area smaller than one frame (%d bytes)" % (end - lo))
+                    spans.append((lo, fresh_off[e]))
+                    lo = fresh_off[e]
+            spans.append((lo, used))
+            if len(spans) > 1:
+                cache.oversized += 1
+            parts, order = [], []
+            for k, (lo, hi) in enumerate(spans):
+                if hi > lo:
+                    src[base:base + hi - lo].copy_(host_src[lo:hi], non_blocking=True)
+                if len(spans) == 1:
+                    group = list(range(len(entries)))
+                else:
+                    group = [i for i, e in enumerate(entries)
+                             if batch[e[0]]["images"][e[1]] is not None and lo <= fresh_off[e] < hi]
+                    if k == len(spans) - 1:         # resident frames can be read at any time: with the last span
+                        group += [i for i, e in enumerate(entries) if batch[e[0]]["images"][e[1]] is None]
+                jobs = []
+                for i in group:
+                    b, f = entries[i]
+                    img = batch[b]["images"][f]
+                    if img is not None:
+                        h, w = img.shape[:2]
+                        cache.misses += 1
+                        off = cache.admit(batch[b]["paths"][f], base + fresh_off[(b, f)] - lo, int(h), int(w))
+                    else:
+                        off, h, w = cache.index[batch[b]["paths"][f]]
+                        cache.hits += 1
+                    jobs.append((int(off), int(h), int(w), batch[b]["flip"]))
+                parts.append(self.pipe.resize(src, jobs, H, W))
+                order += group
+                if len(spans) > 1:
+                    self.pipe.flush()              # this span's kernels are enqueued before the next upload overwrites it
+            if done is not None and used:
+                done.record()
+            cache.mark_ready()
+            if len(parts) == 1 and order == list(range(len(entries))):
+                level0 = parts[0]
             else:
-                off, h, w = cache.index[batch[b]["paths"][f]]
-                cache.hits += 1
-            jobs.append((int(off), int(h), int(w), batch[b]["flip"]))
-        level0 = self.pipe.resize(src, jobs, H, W)                       # uint8 [n_img, H, W, 3]
+                inverse = [0] * len(entries)
+                for row, i in enumerate(order):
+                    inverse[i] = row
+                level0 = torch.cat(parts, 0).index_select(0, imageops._upload(np.asarray(inverse, dtype=np.int64), dev))
         where = {e: i for i, e in enumerate(entries)}
         # ---- ("color", f, 0) and ("color_aug", f, 0)
         for f in frame_ids:

@@ -44,8 +44,14 @@ def owners_of(ms, f):
 def canonical_permutation(ms):
     """Order in which `Trainer.train_step` takes the samples of a batch: largest frame offset first (stable).  The
     loss is a mean over all pixels of all samples and BatchNorm statistics are sums over the batch, so the step does not
-    depend on the order mathematically - and the loader's order is a random shuffle anyway - but the number of distinct
-    batch SIGNATURES does: 3^12 orderings of the early curriculum's m in {0,1,2} are 91 multisets, so step graphs and
+    depend on the order mathematically - with ONE exception, the reference's `--partial_skip` rule, which keeps the chained
+    translation of frame f for ROW NUMBERS r with |f| == m_r - 2 of the non-stereo sample list while the rows of f's stack
+    belong to f's owners (trainer.py:331, 415-418): on a shuffled batch the decision meets mismatched samples, on the
+    canonical order (owners of f = a prefix of the list) it always meets the sample's own m.  Every canonical batch is a
+    valid reference outcome (it is what the reference computes when the loader happens to deliver that order), the
+    distribution over an epoch is not the reference's; `opt.canonical_order = False` keeps the caller's order and with it
+    the reference's row rule on it (tests/test_round6_host_logic.py pins both).  The loader's order is a random shuffle
+    anyway - but the number of distinct batch SIGNATURES depends on it: 3^12 orderings of the early curriculum's m in {0,1,2} are 91 multisets, so step graphs and
     table uploads are reused; and samples with the most candidates come first, which is the fused launches' work order."""
     return sorted(range(len(ms)), key=lambda b: -ms[b])
 

@@ -111,16 +111,17 @@ class PooledTables:
 
         # ---- the pose pass: R rows, real pairs first, padding pairs (zero row) behind them
         n_real = sched.total_rows
-        early = bool(early_rows) and not maxing and n_real <= early_rows and len(sched.requests) <= SMALL_GROUPS // 2
-        if early:
-            # early curriculum: ONE row count and the small group grid whatever the ordering - every shape of the step is
-            # fixed (at most 4 calls: frames +-1, +-2; the padding in at most 4 groups)
+        # early curriculum (at most 4 calls: frames +-1, +-2): the small group grid whatever the ordering, the padding in at
+        # most 4 groups.  `early_rows` > 0 pads every batch of the phase to that ONE row count (one graph, but the pose pass
+        # then always runs the phase's maximum: measured 0.79 of the frozen batch at 48 rows for a mean of 31 real ones);
+        # the default rounds up to the next measured row count like the later epochs do (32 | 48 rows for batch 12)
+        early = not maxing and len(sched.requests) <= SMALL_GROUPS // 2
+        pad_groups = SMALL_GROUPS - SMALL_GROUPS // 2 if early else MAX_PAD_GROUPS
+        if early and early_rows and n_real <= early_rows:
             R = max_pad = early_rows
-            pad_groups = SMALL_GROUPS - SMALL_GROUPS // 2
         else:
             R = tuning.padded_pose_rows(max(n_real, 1), pad_quantum)
             max_pad = R - lowest_rows(R, pad_quantum)
-            pad_groups = MAX_PAD_GROUPS
         if R > caps.R:
             raise ValueError("more pose rows than the tables hold")
         self.R, self.n_real = R, n_real
@@ -143,6 +144,7 @@ class PooledTables:
             pad -= rows[-1]
         assert len(rows) <= ops.BN_MAX_GROUPS and (not sched.rows or max(sched.rows) <= self.bound)
         self.G = SMALL_GROUPS if len(rows) <= SMALL_GROUPS else ops.BN_MAX_GROUPS
+        assert not early or self.G == SMALL_GROUPS
         g = sec("groups")
         g[1:len(rows) + 1] = np.cumsum(rows)
         g[len(rows) + 1:ops.BN_MAX_GROUPS + 1] = R
@@ -207,6 +209,9 @@ class PooledTables:
         for i, (b, slot, row, _) in enumerate(plan.ident_items):
             items[i] = (b, 0, prow(_slot_frame(slot), row), 0)
         sec("ident_off")[:] = plan.ident_off
+        # frames a table row refers to (a batch dict may list frames nothing reads: they need not be there)
+        self.needed_aug = {0} | {fr for _, (fa, _), (fb, _), _, _ in sched.requests for fr in (fa, fb)}
+        self.needed = set(plan.frames) | self.needed_aug
         self.host = torch.from_numpy(hb)
         if pinned:
             self.host = self.host.pin_memory()
@@ -241,10 +246,14 @@ class PooledStep:
 
     # ------------------------------------------------------------------ host tables per signature
     def early_rows(self):
-        """The early curriculum's ONE pose-pass row count: every warp job of frames +-1 (+-2 with tri-minimisation) on all B
-        samples (mono_dataset.py:59-66), rounded to a row count MIOpen has find results for."""
-        per = 2 * (2 if self.trainer.opt.trimin else 1) * self.B
-        return tuning.padded_pose_rows(per, max(self.trainer.pose_pad_rows, 1))
+        """`opt.early_pose_rows = "max"`: ONE pose-pass row count for the whole early curriculum - every warp job of frames
+        +-1 (+-2 with tri-minimisation) on all B samples (mono_dataset.py:59-66), rounded to a row count MIOpen has find
+        results for; an int: that row count; default 0: the next measured row count at or above the batch's own."""
+        want = getattr(self.trainer.opt, "early_pose_rows", 0)
+        if want == "max":
+            per = 2 * (2 if self.trainer.opt.trimin else 1) * self.B
+            return tuning.padded_pose_rows(per, max(self.trainer.pose_pad_rows, 1))
+        return int(want or 0)
 
     def tables_for(self, plan, inputs):
         """PooledTables of this batch (None: the batch does not fit the pooled form and takes the per-signature path)."""
@@ -266,6 +275,8 @@ class PooledStep:
             except ValueError:
                 hit = False
                 self.stats["fallbacks"] += 1
+            if hit and tr.pose_pad_rows > 0:
+                tuning.note_pose_rows(hit.R)            # (warns once per row count MIOpen has no find results for)
             self.cache.put(key, hit)
             self.stats["builds"] += 1
             self.stats["build_ms"] += (time.perf_counter() - t0) * 1e3
@@ -284,7 +295,20 @@ class PooledStep:
         opt, B = self.trainer.opt, self.B
         trimin = bool(opt.trimin)
         if early:
-            return [[2 if trimin else 1] * B]
+            top = 2 if trimin else 1
+            # (all samples at the largest offset = the phase's largest pass; then smaller ones down to the smallest row count)
+            cands = [[top] * B] + [[top] * k + [1] * (B - k) for k in range(B - 1, -1, -1)] + [[1] * k + [0] * (B - k) for k in range(B - 1, 0, -1)]
+            seen, out = set(), []
+            quantum = max(self.trainer.pose_pad_rows, 1)
+            for ms in cands:
+                if not trimin and min(ms) == 0:
+                    continue
+                n = sum(2 * min(m, top) for m in ms)        # frames +-1 (+-2): one row per sample and frame
+                R = self.early_rows() if self.early_rows() and n <= self.early_rows() else tuning.padded_pose_rows(max(n, 1), quantum)
+                if R not in seen:
+                    seen.add(R)
+                    out.append(ms)
+            return out
         top = 7 if trimin else 5
         quantum = max(self.trainer.pose_pad_rows, 1)
         seen, out = set(), []
@@ -342,11 +366,11 @@ class PooledStep:
         """The batch into the static buffers (device-to-device copies on the current stream + ONE pinned table upload)."""
         self.allocate(scales)
         for f, (at, n) in tab.frame_rows.items():
-            src = inputs[("color", f, 0)]
-            self.pool_color[at:at + n].copy_(src, non_blocking=True)
-            if f != STEREO:
-                aug = inputs[("color_aug", f, 0)]
-                self.pool_aug[at:at + n].copy_(aug, non_blocking=True)
+            if f not in tab.needed and ("color", f, 0) not in inputs:
+                continue
+            self.pool_color[at:at + n].copy_(inputs[("color", f, 0)], non_blocking=True)
+            if f != STEREO and (f in tab.needed_aug or ("color_aug", f, 0) in inputs):
+                self.pool_aug[at:at + n].copy_(inputs[("color_aug", f, 0)], non_blocking=True)
         for s in scales:
             if s:
                 src = inputs[("color", 0, s)]

@@ -490,7 +490,9 @@ class Trainer:
             if isinstance(key, tuple) and len(key) >= 2 and key[0] in ("color", "color_aug") and key[1] != 0:
                 old_own, new_own = owners_of(ms, key[1]), owners_of(new_ms, key[1])
                 if t.shape[0] != len(old_own):
-                    continue
+                    # permuting everything else would pair this stack's frames with the wrong samples
+                    raise ValueError("canonicalize: %r has %d rows, the batch's ordering gives frame %r %d owners"
+                                     % (key, t.shape[0], key[1], len(old_own)))
                 rows = tuple(old_own.index(perm[b]) for b in new_own)
             elif t.shape[0] == B:
                 rows = tuple(perm)
@@ -587,7 +589,10 @@ class Trainer:
                 return None
             from . import datasets
             free, _ = torch.cuda.mem_get_info(self.device)
-            self._frame_cache = datasets.FrameCache(self.device, int(min(gb * (1 << 30), free // 2)))
+            # scratch area: one boosted batch with nothing resident yet (resume at a late epoch, or a cache smaller than the
+            # data set) carries up to 16 full-resolution KITTI frames per sample (1242 x 375 x 3 bytes each)
+            scratch = max(192 << 20, int(self.opt.batch_size * 17 * 1242 * 375 * 3 * 1.1))
+            self._frame_cache = datasets.FrameCache(self.device, int(min(gb * (1 << 30), free // 2)), scratch_bytes=scratch)
         return self._frame_cache
 
     def kitti_val_loader(self):
@@ -607,8 +612,11 @@ class Trainer:
         self.set_ground_truth(np.load(gt, fix_imports=True, encoding="latin1", allow_pickle=True)["data"])
         ds = datasets.KITTIRAWDataset(datasets.readlines(files), 0, opt.height, opt.width, kt_path=opt.kt_path,
                                       is_train=False, kt=True, naive_mix=True)
+        # no FrameCache here: validation runs in the middle of an epoch (log_frequency) while the training loader's producer
+        # thread is collating on its own stream, and its 4 424 frames are read once per pass anyway (the reference decodes them
+        # every time too); the cache's scratch areas are per collate and its index is locked, should a caller share one
         self._val_loader = datasets.DeviceLoader(ds, 16, datasets.DeviceCollate(opt.height, opt.width, [0], self.device,
-                                                                               self.backend, cache=self.frame_cache()),
+                                                                               self.backend, cache=None),
                                                  shuffle=False, drop_last=False, num_workers=getattr(opt, "num_workers", 8))
         return self._val_loader
 
@@ -840,6 +848,9 @@ class Trainer:
                 pad = tuning.padded_pose_rows(n_real, self.pose_pad_rows) - n_real
             if pad:
                 parts.append(parts[0].new_zeros((pad,) + tuple(parts[0].shape[1:])))
+            if self.pose_pad_rows > 0 and self.models["pose_encoder"].training:
+                from . import tuning
+                tuning.note_pose_rows(n_real + pad)        # (warns once per row count MIOpen has no find results for)
             x = torch.cat(parts, 0)
             with ops.bn_call_groups(rows + ([pad] if pad else []), padding_groups=1 if pad else 0):
                 feats = [self.models["pose_encoder"](x)]

@@ -64,7 +64,95 @@ def _fingerprint():
 
 # what the last use_shipped_db() / use_shipped_gemm_db() did, for callers that report it (bench.py): the private MIOpen
 # copy is one MIOpen appends to, so a run that found it already there also sees earlier runs' find results
-STATUS = {"miopen_db": None, "miopen_db_prewarmed": None, "gemm_db": None, "gemm_db_accepted": None, "gemm_db_why": None}
+STATUS = {"miopen_db": None, "miopen_db_prewarmed": None, "miopen_db_accepted": None, "miopen_db_why": None,
+          "gemm_db": None, "gemm_db_accepted": None, "gemm_db_why": None}
+
+
+def shipped_db_tag():
+    """Version tag in the shipped find database's file name, `<arch><CUs>.HIP.<tag>.ufdb.txt` (MIOpen only opens the file
+    whose tag is its OWN `major_minor_patch_tweak`: a database recorded with another build is ignored without a word)."""
+    for f in sorted(os.listdir(DB_DIR)) if os.path.isdir(DB_DIR) else []:
+        if f.endswith(".ufdb.txt") and ".HIP." in f:
+            return f.split(".HIP.", 1)[1][:-len(".ufdb.txt")]
+    return None
+
+
+def running_miopen_tag():
+    """`major_minor_patch_tweak` of the MIOpen this process will use: PyTorch-ROCm bundles its own libMIOpen.so, whose
+    version banner (" MIOpen version 3.5.0.<tweak>") is read from the library file (one scan of ~0.3 s, remembered in the
+    per-user cache directory by the file's size and mtime).  Falls back to `torch.backends.cudnn.version()`'s
+    major_minor_patch when the banner cannot be found; None when neither is available."""
+    import mmap
+    import re
+    import torch
+    lib = os.path.join(os.path.dirname(torch.__file__), "lib", "libMIOpen.so")
+    if os.path.isfile(lib):
+        st = os.stat(lib)
+        memo = os.path.join(_cache_root(), "miopen_tag_%d_%d.txt" % (st.st_size, int(st.st_mtime)))
+        try:
+            with open(memo) as fh:
+                tag = fh.read().strip()
+            if tag:
+                return tag
+        except OSError:
+            pass
+        try:
+            with open(lib, "rb") as fh:
+                mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                i = mm.find(b" MIOpen version ")
+                tag = None
+                if i >= 0:
+                    m = re.match(rb" MIOpen version (\d+)\.(\d+)\.(\d+)\.([0-9A-Za-z\-]+)", mm[i:i + 96])
+                    if m:
+                        tag = "_".join(g.decode() for g in m.groups())
+                mm.close()
+            if tag:
+                try:
+                    os.makedirs(os.path.dirname(memo), exist_ok=True)
+                    with open(memo, "w") as fh:
+                        fh.write(tag)
+                except OSError:
+                    pass
+                return tag
+        except (OSError, ValueError):
+            pass
+    try:
+        v = torch.backends.cudnn.version()
+    except Exception:
+        v = None
+    if v:
+        return "%d_%d_%d" % (v // 1000000, (v // 1000) % 1000, v % 1000)
+    return None
+
+
+def miopen_db_accepted():
+    """(True, None) when the shipped find database carries the running MIOpen's version tag - the condition under which
+    MIOpen reads it; otherwise (False, why).  Like `gemm_db_accepted` for the TunableOp table."""
+    shipped, running = shipped_db_tag(), running_miopen_tag()
+    if shipped is None:
+        return False, "no find database shipped"
+    if running is None:
+        return False, "the running MIOpen's version could not be determined"
+    if shipped == running or (running.count("_") == 2 and shipped.startswith(running + "_")):
+        return True, None
+    return False, "database recorded with MIOpen %s, this process runs MIOpen %s" % (shipped, running)
+
+
+_warned_rows = set()
+
+
+def note_pose_rows(rows):
+    """Called with the row count of every batched pose pass: warns ONCE per row count the shipped database has no find
+    results for (MIOpen compiles that problem's solvers at first use - tens of seconds on the training thread, once per
+    machine; `POSE_ROW_COUNTS` are measured for batch size 12, the reference's)."""
+    if rows in POSE_ROW_COUNTS or rows in _warned_rows:
+        return False
+    _warned_rows.add(rows)
+    import warnings
+    warnings.warn("batched pose pass with %d rows: the shipped MIOpen database has find results for %s rows only (batch size "
+                  "12); MIOpen compiles this row count's solvers at first use - expect a stall of tens of seconds, once per "
+                  "machine (tools/miopen_tune_pose.sh records more row counts)" % (rows, list(POSE_ROW_COUNTS)))
+    return True
 
 
 def use_shipped_db():
@@ -89,6 +177,15 @@ def use_shipped_db():
             pass
         shutil.rmtree(tmp, ignore_errors=True)
     os.makedirs(os.path.join(db, "cache"), exist_ok=True)
+    if STATUS["miopen_db_accepted"] is None:
+        # MIOpen drops a database of another build without a word: say so (once per process)
+        ok, why = miopen_db_accepted()
+        STATUS.update(miopen_db_accepted=ok, miopen_db_why=why)
+        if not ok:
+            import warnings
+            warnings.warn("the shipped MIOpen find database will be ignored (%s): convolutions take MIOpen's heuristic solvers "
+                          "(slower, and every new pose-pass row count compiles solvers for tens of seconds); re-record it with "
+                          "tools/miopen_tune.sh" % why)
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(db, "cache"))
     return db

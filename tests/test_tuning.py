@@ -26,7 +26,7 @@ def test_explicit_call_points_miopen_at_a_private_copy_of_the_shipped_database(t
     shipped = os.path.join(ROOT, "baseboostdepth_amd", "miopen_db")
     assert sorted(f for f in os.listdir(db) if f.endswith(".txt")) == sorted(f for f in os.listdir(shipped) if f.endswith(".txt"))
     again = _probe(BBD_MIOPEN_CACHE=str(tmp_path))
-    assert again[1] == db and len(os.listdir(str(tmp_path))) == 1       # reused, not re-copied
+    assert again[1] == db and len([d for d in os.listdir(str(tmp_path)) if d.startswith("miopen_db_")]) == 1       # reused, not re-copied
 
 
 def test_caller_settings_win_and_the_switch_disables():
@@ -63,3 +63,44 @@ def test_gemm_table_is_shipped_and_wired_only_on_explicit_call():
                           "from baseboostdepth_amd import tuning; print(tuning.use_shipped_gemm_db() if not torch.cuda.is_available() else 'gpu')"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.stdout.split()[:2] in (["0", "None"], ["0", "gpu"]), (out.stdout, out.stderr[-800:])
+
+
+def test_a_database_of_another_miopen_build_is_reported(monkeypatch, tmp_path):
+    """MIOpen opens only the find database whose file name carries its OWN version tag and ignores any other without a
+    word: `use_shipped_db()` compares the shipped tag with the running library's and says so (warning + STATUS), like
+    `gemm_db_accepted` does for the TunableOp table."""
+    import warnings
+    from baseboostdepth_amd import tuning
+    assert tuning.shipped_db_tag().startswith("3_5_0_")
+    ok, why = tuning.miopen_db_accepted()
+    assert ok and why is None, why                      # this image's PyTorch bundles the MIOpen the database was recorded with
+    monkeypatch.setattr(tuning, "running_miopen_tag", lambda: "3_6_0_20260101-1-2-gdeadbeef")
+    ok, why = tuning.miopen_db_accepted()
+    assert not ok and "3_6_0_20260101" in why and tuning.shipped_db_tag() in why
+    monkeypatch.setenv("BBD_MIOPEN_CACHE", str(tmp_path))
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("MIOPEN_CUSTOM_CACHE_DIR", raising=False)
+    monkeypatch.setitem(tuning.STATUS, "miopen_db_accepted", None)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tuning.use_shipped_db()
+    assert any("will be ignored" in str(w.message) for w in caught)
+    assert tuning.STATUS["miopen_db_accepted"] is False and "3_6_0" in tuning.STATUS["miopen_db_why"]
+    # major_minor_patch alone (the fallback when the library's banner cannot be read) accepts any tweak of that version
+    monkeypatch.setattr(tuning, "running_miopen_tag", lambda: "3_5_0")
+    assert tuning.miopen_db_accepted() == (True, None)
+
+
+def test_an_untuned_pose_row_count_warns_once():
+    import warnings
+    from baseboostdepth_amd import tuning
+    tuning._warned_rows.discard(100)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        assert tuning.note_pose_rows(96) is False              # measured
+        assert tuning.note_pose_rows(100) is True
+        assert tuning.note_pose_rows(100) is False             # once
+    assert len(caught) == 1 and "100 rows" in str(caught[0].message) and "tens of seconds" in str(caught[0].message)
+    # the rounding rule only ever lands on a measured row count inside the table's range
+    for n in range(1, 321):
+        assert tuning.padded_pose_rows(n, 32) in tuning.POSE_ROW_COUNTS
