@@ -48,6 +48,14 @@ _FLAGS = [
     ("--step_graph", dict(action="store_true")), ("--loader_workers", dict(type=str, default="process", choices=["process", "thread"])),
     # the step's pose-network calls as one batched pass with per-call BatchNorm statistics (default) or one by one
     ("--separate_pose_calls", dict(dest="batched_pose", action="store_false")),
+    # --rand recipes run the step in pooled form (pooled.py: one frame pool, static step tables, one step graph per pose-row
+    # bucket, captured by Trainer.prewarm() at the start of every epoch) and replay step graphs by default
+    ("--per_signature_step", dict(dest="pooled_step", action="store_false", default=None)),
+    ("--no_prewarm", dict(dest="prewarm", action="store_false")),
+    ("--no_step_graph", dict(action="store_true")),
+    # early curriculum: 0 = pad the pose pass to the next measured row count (32 | 48 for batch 12); "max" or a number = ONE
+    # row count for the whole phase (one graph; the pass then always runs the phase's largest size)
+    ("--early_pose_rows", dict(type=str, default="0")),
 ]
 # other zoos / datasets of the reference: parsed, refused when set
 _OUT_OF_SCOPE = ["--SYNS_eval", "--SQL", "--SQL_L", "--CA_depth", "--DIFFNet", "--chamfer", "--stereo_guide",
@@ -70,4 +78,8 @@ class MonodepthOptions:
         bad = [f for f in _OUT_OF_SCOPE if getattr(self.options, f[2:])]
         if bad:
             self.parser.error("%s select parts of the reference that are outside this build's scope" % ", ".join(bad))
+        if self.options.rand and not self.options.no_step_graph:
+            self.options.step_graph = True
+        if self.options.early_pose_rows != "max":
+            self.options.early_pose_rows = int(self.options.early_pose_rows)
         return self.options

@@ -107,8 +107,9 @@ class Trainer:
         self.graph_stats = {"replays": 0, "captures": 0, "eager": 0}
         # `--rand` recipes: the step in pooled form (`pooled.PooledStep`: one frame pool, static step tables, shapes that
         # depend on the padded pose rows only), so that ONE step graph serves every ordering of a row-count bucket
-        self.pooled_step = bool(getattr(opt, "pooled_step", getattr(opt, "rand", False))) and self.device.type == "cuda" \
-            and os.environ.get("BBD_POOLED_STEP", "1") != "0"
+        want_pooled = getattr(opt, "pooled_step", None)
+        want_pooled = getattr(opt, "rand", False) if want_pooled is None else want_pooled
+        self.pooled_step = bool(want_pooled) and self.device.type == "cuda" and os.environ.get("BBD_POOLED_STEP", "1") != "0"
         self._pooled = None
         # data parallel + step graph: capture the bucketed RCCL all-reduces INTO the graph (one graph per step, exchange
         # overlapped with backward inside the replay) instead of two graphs around one exposed all-reduce.  Opt-in:

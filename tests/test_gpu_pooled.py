@@ -295,3 +295,22 @@ def test_fused_path_through_the_frame_pool_matches_reference_bit_for_bit(name):
     report = compare_with_golden(case, tr, outputs, losses, check_warps=False, exact=True)
     losses["loss"].backward()
     compare_grads(case, report)
+
+
+def test_bucketed_graphs_under_data_parallel_with_the_gradient_pack_inside_the_graph():
+    """`BBD_DP_FORCE_ATTACH=1`, one rank over RCCL: the pooled step graphs with the flat-gradient pack inside the graph (the
+    split-graph loop) and with the bucketed all-reduces captured into it, seven orderings of one bucket each, against the
+    eager data-parallel loop (tools/ddp_check.py --pooled)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BBD_BUCKET_BYTES="4000000", MASTER_PORT=str(port))
+    env.pop("BBD_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_check.py"), "--pooled"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert "DDP_POOLED_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])

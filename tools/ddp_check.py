@@ -114,6 +114,61 @@ def capture_mode():
     dist.destroy_process_group()
 
 
+def pooled_mode():
+    """--pooled: ONE rank over RCCL (`BBD_DP_FORCE_ATTACH=1`): the bucketed step graphs of the `--rand` recipe (pooled form:
+    ONE graph per pose-row bucket, `Trainer._graph_step`) under data parallelism - the flat-gradient pack inside the graph
+    (split-graph loop: graph | all-reduce | optimizer graph) and the captured-collective form (bucketed RCCL all-reduces as
+    nodes of the one graph) - each over seven different orderings of one bucket against the eager data-parallel loop of the
+    same trainer: one capture, seven replays, same parameters.  So the first multi-GPU run does not also debut a new
+    capture path."""
+    import warnings
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29518")
+    os.environ["BBD_DP_FORCE_ATTACH"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    torch.backends.cudnn.deterministic = True
+    orderings = [[7, 7, 1, 1], [7, 4, 2, 1], [7, 3, 3, 1], [7, 3, 2, 2], [7, 6, 1, 1], [7, 3, 1, 1], [7, 5, 1, 1]]     # 48 pose rows each
+    Hs, Ws = 96, 160
+
+    def run(step_graph, capture):
+        opt = bench.make_options(B, 0, "boosted15")
+        opt.height, opt.width, opt.rand = Hs, Ws, True
+        opt.step_graph, opt.fused_adam = step_graph, True
+        opt.scales = [0, 1, 2, 3]
+        torch.manual_seed(7)
+        tr = Trainer(opt)
+        tr.opt.scales = [0]
+        tr.dp_capture = capture
+        tr.set_train()
+        bdist.attach(trainer=tr)
+        assert tr.grad_sync is not None and tr.flat_grads is not None and tr.pooled_step
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i, ms in enumerate(orderings):
+                b = synthetic_batch(ms, Hs, Ws, [0], device="cuda:0", seed=300 + i)
+                b["cutt"] = torch.tensor(1.35)
+                b["noise"] = torch.randn(B, Hs, Ws, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(i)) * 1e-5
+                _, losses = tr.train_step(b)
+        torch.cuda.synchronize()
+        assert tr.step == len(orderings) and tr._pooled.stats["fallbacks"] == 0
+        return torch.cat([p.detach().flatten() for p in tr.parameters_to_train]), float(losses["loss"]), tr
+
+    pe, le, _ = run(False, False)
+    for capture in (False, True):
+        pg, lg, tr = run(True, capture)
+        assert tr.dp_capture == capture
+        assert tr.graph_stats == {"eager": 0, "captures": 1, "replays": len(orderings)}, tr.graph_stats
+        graph, tail = list(tr._graphs.values())[0][:2]
+        assert (tail is None) == capture                         # split graphs keep an optimizer graph behind the exchange
+        diff = float((pg - pe).abs().max())
+        print("pooled step graph (%s) vs eager data-parallel loop: max parameter difference %.3e; loss %.6f vs %.6f"
+              % ("captured collectives" if capture else "split around the exchange", diff, lg, le))
+        assert diff <= 1e-5 * max(1.0, float(pe.abs().max())), diff
+    print("DDP_POOLED_OK")
+    dist.destroy_process_group()
+
+
 def main():
     rank, _, world = bdist.init_from_env()
     torch.cuda.set_device(0)
@@ -173,6 +228,8 @@ def main():
 if __name__ == "__main__":
     if "--capture" in sys.argv:
         capture_mode()
+    elif "--pooled" in sys.argv:
+        pooled_mode()
     elif "--graph" in sys.argv:
         graph_mode()
     else:
