@@ -37,8 +37,6 @@ SIGNATURES = {
     "bbd_pose_expand": [_p, _p, _i, _p],
     "bbd_identity_loss_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
     "bbd_identity_loss_grouped_fwd": [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p],
-    "bbd_identity_loss_stream_supported": [_i, _i],
-    "bbd_identity_loss_stream_fwd": [_p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p],
     "bbd_warp_ssim_min_fwd": [_p] * 12 + [_i] * 6 + [_p],
     "bbd_warp_ssim_min_bwd": [_p] * 10 + [_i] * 6 + [_p],
     "bbd_fused_work_items": [_i, _i, _i, _i, _i, _p, _p],

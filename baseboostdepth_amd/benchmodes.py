@@ -149,7 +149,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
             torch.cuda.set_sync_debug_mode("warn")
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            done, per_call = 0, []
+            done, per_call, rows_real, rows_run = 0, [], [], []
             prof_step = int(os.environ.get("BBD_BENCH_PROFILE_STEP", "-1")) if p == 0 else -1      # (diagnosis: cProfile one call)
             n_seg = len(seg)
             for b in seg:
@@ -164,6 +164,9 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                 else:
                     tr.train_step(dict(b))
                 per_call.append(time.perf_counter() - c0)
+                if tr.last_pooled is not None:
+                    rows_real.append(tr.last_pooled.n_real)
+                    rows_run.append(tr.last_pooled.R)
                 done += 1
                 if done in (3, 10) and time.perf_counter() - t0 > pass_budget * done / 30 * 3:
                     torch.cuda.synchronize()      # far over budget (e.g. MIOpen compiling solvers for unseen row counts)
@@ -192,7 +195,11 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                        "table_build_ms_per_step": round(st.get("build_ms", 0.0) / done, 3),
                        "synchronising_calls_per_step": round(syncs / done, 3), "synchronising_calls_at": sync_where,
                        "eager_steps": g1["eager"] - g0["eager"], "captures": g1["captures"] - g0["captures"],
-                       "replays": g1["replays"] - g0["replays"]})
+                       "replays": g1["replays"] - g0["replays"],
+                       # rows of the batched pose pass (the step's dominant cost under the boosted recipe): what the batches'
+                       # frame sets ask for, and what ran after rounding up to a measured row count
+                       "pose_rows_mean": round(sum(rows_real) / len(rows_real), 1) if rows_real else None,
+                       "pose_rows_run_mean": round(sum(rows_run) / len(rows_run), 1) if rows_run else None})
     steady = passes[1] if len(segments) == 4 else passes[0]
     out = {"config": config, "workload": "%s with a NEW ordering every step: %d pre-resident batches, %d distinct signatures, "
                                           "offsets drawn per sample like mono_dataset.py:87-109, stacked largest offset first"

@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(HERE, "bbd_kernels.hip"), os.path.join(HERE, "bbd_eval.hip"),
-        os.path.join(HERE, "bbd_image.hip"), os.path.join(HERE, "bbd_nn.hip"), os.path.join(HERE, "bbd_vit.hip"), os.path.join(HERE, "bbd_pose.hip"), os.path.join(HERE, "bbd_tokens.hip"), os.path.join(HERE, "bbd_util.hip"), os.path.join(HERE, "bbd_identity_stream.hip")]
+        os.path.join(HERE, "bbd_image.hip"), os.path.join(HERE, "bbd_nn.hip"), os.path.join(HERE, "bbd_vit.hip"), os.path.join(HERE, "bbd_pose.hip"), os.path.join(HERE, "bbd_tokens.hip"), os.path.join(HERE, "bbd_util.hip")]
 OUT = os.path.join(HERE, "libbbd_hip.so")
 DEPS = SRCS + [os.path.abspath(__file__), os.path.join(HERE, "bbd_math.h"), os.path.join(HERE, "bbd_image_math.h"), os.path.join(HERE, "..", "..", "include", "bbd_hip.h")]
 # -fno-slp-vectorize: hipcc otherwise SLP-packs neighbouring scalar fp32 adds / multiplies into v_pk_add/mul_f32 and

@@ -470,10 +470,6 @@ def pose_compose_static(steps, tab, off, refs, NO, pose_error, backend=None):
 
 
 # ---------------------------------------------------------------------------- identity pre-pass
-IDENTITY_FORM = _experiment("BBD_IDENTITY_FORM", "tiled")          # "tiled" (shipped) | "stream" (round 6 A/B)
-IDENTITY_STREAM_ROWS = int(_experiment("BBD_IDENTITY_STREAM_ROWS", "0"))
-
-
 def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     """[NI,H,W] identity photometric losses (no gradient: inputs are images)."""
     backend = backend or default_backend()
@@ -483,12 +479,8 @@ def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     backend._check(target, *_frame_list(frame_tensors))
     frames = frame_pointer_array(frame_tensors)
     # one workgroup per (target sample, tile) walks the sample's identity candidates (round 3).  Round 5 measured a streaming,
-    # LDS-free form against it - slower (tools/experiments/streaming_identity.hip.txt, profiles/r05/identity_forms.txt)
-    form = IDENTITY_FORM
-    if form == "stream" and hasattr(backend, "lib") and backend.lib._dll.bbd_identity_loss_stream_supported(H, W):
-        backend.run("bbd_identity_loss_stream_fwd", target, frames, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
-                    plan.B, int(getattr(plan, "max_ident", 6)), ptr(ident), H, W, int(no_ssim), IDENTITY_STREAM_ROWS)
-        return ident
+    # LDS-free form against it - slower (tools/experiments/streaming_identity.hip.txt, profiles/r05/identity_forms.txt), round 6
+    # the form with aligned 8-byte loads and the halo columns over DPP - slower too (profiles/r06/identity_stream_ab.txt)
     backend.run("bbd_identity_loss_grouped_fwd", target, frames, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
                 plan.B, ptr(ident), H, W, int(no_ssim))
     return ident

@@ -108,7 +108,6 @@ class ReprojectionPlan:
                 self.ident_index[(b, f)] = len(self.ident_items)
                 self.ident_items.append((b, frame_slot(f), self.source_row(f, b), 0))
         self.NI = len(self.ident_items)
-        self.max_ident = max([len(frames) for frames in per_sample] + [0])      # identity candidates of one sample, at most
         # items are sample-major: group g = the identity candidates of target sample g (bbd_identity_loss_grouped_fwd)
         self.ident_off = [0]
         for b in range(self.B):

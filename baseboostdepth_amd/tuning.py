@@ -24,7 +24,7 @@ DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
 # of find mode each).  `Trainer._pose_pairs` rounds the pass up to the next of these (beyond them: to a multiple of 32), so
 # the pose network's convolutions only ever meet problems MIOpen has measured solvers for.  The epoch-15 draws of the
 # boosted recipe need 192-288 rows (24 + 4 * sum(m - 1) per batch of 12), epochs 10-12 about 100-160, the early curriculum 24-48.
-POSE_ROW_COUNTS = (32, 48, 64, 96, 128, 160, 192, 208, 224, 240, 256, 272, 288, 320)
+POSE_ROW_COUNTS = (32, 40, 48, 64, 96, 128, 160, 192, 208, 224, 232, 240, 248, 256, 272, 288, 320)
 
 
 def padded_pose_rows(n, quantum=32):

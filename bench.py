@@ -656,7 +656,7 @@ def main(argv=None):
     #      released in between, never a re-exec
     if world == 1 and args.config == "md2" and not args.no_secondary:
         secondary, t_sec = [], time.perf_counter()
-        frozen = {"md2": res["value"]}
+        frozen, frozen_rows = {"md2": res["value"]}, {}
         for cfg in ("boosted", "boosted15", "boosted15_coherent", "trimin5", "vit", "boosted15_fresh", "trimin5_fresh", "md2_loader"):
             if time.perf_counter() - t_sec > args.secondary_budget:
                 secondary.append({"config": cfg, "skipped": "secondary budget of %.0f s used up" % args.secondary_budget})
@@ -668,6 +668,7 @@ def main(argv=None):
                     ref = frozen.get(cfg.replace("_fresh", "").replace("_loader", ""))
                     if ref:
                         r["frozen_batch_images_per_sec"] = round(ref, 2)
+                        r["frozen_batch_pose_rows"] = frozen_rows.get(cfg.replace("_fresh", ""))
                         r["vs_frozen_batch"] = round(r["value"] / ref, 4)
                         if "passes" in r:
                             r["vs_frozen_batch_seen_signatures"] = round(r["passes"][-1]["images_per_sec"] / ref, 4)
@@ -676,6 +677,8 @@ def main(argv=None):
                     continue
                 r = run_workload(args, ctx, cfg, max(10, args.secondary_steps), 3, want_graph, "graph")
                 frozen[cfg] = r["value"]
+                sched = getattr(getattr(r["trainer"], "tables", None), "schedule", None)
+                frozen_rows[cfg] = sched.total_rows if sched is not None else None      # (exact: a frozen batch is not padded)
                 rf = r["roofline"] or {}
                 secondary.append({
                     "config": cfg, "workload": workload_name(cfg, args.batch, r["S"], r["ms"]),

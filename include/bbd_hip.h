@@ -130,17 +130,6 @@ int bbd_identity_loss_grouped_fwd(const void* const* frames, const float* target
                                   const int32_t* group_off, int G, float* ident, int H, int W, int no_ssim,
                                   void* stream);
 
-/* Streaming form of the grouped identity pre-pass (round 6; csrc/bbd_identity_stream.hip): no LDS, no barrier - a wave
- * marches down a 128-column band of one target sample for TWO of its identity candidates at once (aligned 8-byte loads, the
- * halo columns from the neighbour lanes over the DPP crossbar, the target's window statistics shared by the two).  Same
- * arguments and the same results, bit for bit, as bbd_identity_loss_grouped_fwd; max_items (host) bounds the items of a group
- * (it sizes the grid: 2 for MD2, 6 for the boosted recipe), rows_per_wave = rows a wave walks (0 = default).
- * Needs an even W >= 4 (bbd_identity_loss_stream_supported); otherwise BBD_E_BADARG - callers take the tiled form then. */
-int bbd_identity_loss_stream_supported(int H, int W);
-int bbd_identity_loss_stream_fwd(const void* const* frames, const float* target, const int32_t* items,
-                                 const int32_t* group_off, int G, int max_items, float* ident, int H, int W, int no_ssim,
-                                 int rows_per_wave, void* stream);
-
 /* Fused forward:  back-project -> project -> bilinear border sample -> SSIM+L1 ->
  * per-pixel min/arg-min over the sample's candidate list, for S scales x B samples.
  * Replaces trainer.py:421-442 (warping_block), :477-486, :525-557 and x_min_opt :983-1100,

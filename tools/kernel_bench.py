@@ -97,14 +97,6 @@ def main():
     def k_ident():
         ops.identity_losses(plan, frame_tensors, target, False, be)
 
-    def k_ident_stream(rows):
-        from baseboostdepth_amd._lib import ptr
-        tb = plan.tables(dev)
-        fp = ops.frame_pointer_array(frame_tensors)
-        out = torch.empty(plan.NI, H, W, device=dev)
-        return lambda: be.run("bbd_identity_loss_stream_fwd", target, fp, ptr(target), ptr(tb["items"]), ptr(tb["ident_off"]),
-                              plan.B, plan.max_ident, ptr(out), H, W, 0, rows)
-
     # the training path: disparity-mode launches (low-resolution disparities in, depth + coordinates by-products)
     dd = [disp[s].detach().clone().requires_grad_(True) for s in scales]
     t2 = table.clone().requires_grad_(True)
@@ -138,20 +130,6 @@ def main():
         ms_ = timer.summary()[key][1]
         res[name] = {"ms": round(ms_, 4), "alg_MB": round(nbytes / 1e6, 1), "GBps": round(nbytes / ms_ / 1e6, 1),
                      "frac_of_8TBps": round(nbytes / ms_ / 1e6 / 8000, 4)}
-    if be.lib._dll.bbd_identity_loss_stream_supported(H, W):       # round 6 A/B: the streaming form of the identity pre-pass
-        for rows in (4, 8, 12, 16, 24):
-            fn = k_ident_stream(rows)
-            for _ in range(args.warmup):
-                fn()
-            torch.cuda.synchronize()
-            timer.reset()
-            be.timer = timer
-            for _ in range(args.iters):
-                fn()
-            torch.cuda.synchronize()
-            be.timer = None
-            ms_ = timer.summary()["bbd_identity_loss_stream_fwd"][1]
-            res["identity_stream_rows%d" % rows] = {"ms": round(ms_, 4), "frac_of_8TBps": round(ib / ms_ / 1e6 / 8000, 4)}
     for _ in range(args.warmup):
         fwd()
     res["generate_images_pred_total_ms"] = round(time_it(fwd, args.iters), 4)

@@ -7,7 +7,7 @@ C=baseboostdepth_amd/csrc
 SRC="$C/bbd_kernels.hip $C/bbd_eval.hip $C/bbd_image.hip $C/bbd_nn.hip $C/bbd_vit.hip $C/bbd_pose.hip $C/bbd_tokens.hip"
 mkdir -p build_variants
 # the other translation units do not change between variants: compile them once
-for f in bbd_eval bbd_image bbd_nn bbd_vit bbd_pose bbd_tokens bbd_util bbd_identity_stream; do
+for f in bbd_eval bbd_image bbd_nn bbd_vit bbd_pose bbd_tokens bbd_util; do
   o=build_variants/$f.o
   if [ ! -f $o ] || [ $C/$f.hip -nt $o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -std=c++17 -fPIC -c -o $o $C/$f.hip || exit 1
@@ -18,7 +18,7 @@ for spec in "$@"; do
   src=${BBD_VARIANT_SRC:-$C/bbd_kernels.hip}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -std=c++17 -fPIC -I$C -c $flags \
       -Rpass-analysis=kernel-resource-usage -o build_variants/k_$name.o $src 2> build_variants/k_$name.log || { grep error build_variants/k_$name.log; exit 1; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/libbbd_$name.so build_variants/k_$name.o build_variants/bbd_{eval,image,nn,vit,pose,tokens,util,identity_stream}.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/libbbd_$name.so build_variants/k_$name.o build_variants/bbd_{eval,image,nn,vit,pose,tokens,util}.o || exit 1
   echo -n "$name [$flags]: "
   python3 - "$name" <<'PY'
 import re, sys
