@@ -211,7 +211,7 @@ class FrameCache:
     new ones among them are copied to a resident home (device to device).  No eviction: when the resident area is full,
     further frames are used from the scratch area and decoded again next time (what the reference always does)."""
 
-    def __init__(self, device, capacity_bytes, scratch_bytes=192 << 20, regions=2):
+    def __init__(self, device, capacity_bytes, scratch_bytes=192 << 20, regions=3):
         """`regions` scratch areas of `scratch_bytes` each: every `DeviceCollate` that uses the cache takes one of its own
         (`attach`) - two loaders iterated at the same time (training + validation, each with its own thread and stream) never
         upload into the same bytes."""
@@ -235,6 +235,11 @@ class FrameCache:
         """Byte offset of a scratch area of this cache for the exclusive use of `owner` (a collate) for as long as it lives:
         the area returns to the cache when the owner is garbage-collected (the trainer builds a new collate every epoch)."""
         import weakref
+        with self._lock:
+            free = [i for i in range(self.regions) if i not in self._held]
+        if not free:
+            import gc
+            gc.collect()                # a finished loader's collate may only be waiting for the cycle collector
         with self._lock:
             free = [i for i in range(self.regions) if i not in self._held]
             if not free:

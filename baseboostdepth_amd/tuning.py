@@ -24,7 +24,9 @@ DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
 # of find mode each).  `Trainer._pose_pairs` rounds the pass up to the next of these (beyond them: to a multiple of 32), so
 # the pose network's convolutions only ever meet problems MIOpen has measured solvers for.  The epoch-15 draws of the
 # boosted recipe need 192-288 rows (24 + 4 * sum(m - 1) per batch of 12), epochs 10-12 about 100-160, the early curriculum 24-48.
-POSE_ROW_COUNTS = (32, 40, 48, 64, 96, 128, 160, 192, 208, 224, 232, 240, 248, 256, 272, 288, 320)
+# Round 6 added 40 and 216 / 232 / 248 / 264: where the draws are dense the buckets are 8 rows apart (the padding is the one cost
+# the pooled step graphs still pay against a frozen batch: 3 % of a boosted step at 16-row buckets).
+POSE_ROW_COUNTS = (32, 40, 48, 64, 96, 128, 160, 192, 208, 216, 224, 232, 240, 248, 256, 264, 272, 288, 320)
 
 
 def padded_pose_rows(n, quantum=32):

@@ -262,7 +262,7 @@ def committed_constants(config):
     from baseboostdepth_amd.csrc.build import source_sha16
     now = source_sha16()
     out = {"traffic": None, "traffic_path": None, "isa_mix": {}, "isa_mix_path": None, "source_sha16": now, "stale": []}
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         cand = os.path.join(ROOT, "profiles", rnd, "traffic_%s.json" % config)
         if out["traffic"] is None and os.path.isfile(cand):
             out["traffic"], out["traffic_path"] = json.load(open(cand)), os.path.relpath(cand, ROOT)
