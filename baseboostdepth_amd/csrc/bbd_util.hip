@@ -1,25 +1,43 @@
 // bbd_util.hip - measurement aid: the on-box stream-copy ceiling bench.py quotes beside the 8 TB/s specification
 // ("also record an on-box measured stream-copy ceiling and quote both fractions").  A plain float4 copy:
-// one 16-byte load and one 16-byte store per thread per step, grid-stride, enough workgroups to fill 256 CUs.
+// U independent 16-byte loads per thread in flight, then their U stores, grid-stride over chunks of 256 * U float4,
+// 32 workgroups per CU.  bench.py times U = 1, 4, 8 and quotes the best.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/bbd_hip.h"
 
 namespace {
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
-  const long stride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int U>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f4* __restrict__ src, f4* __restrict__ dst, long n4) {
+  const long chunk = 256L * U, stride = (long)gridDim.x * chunk;
+  for (long base = (long)blockIdx.x * chunk + threadIdx.x; base < n4; base += stride) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + 256L * u < n4) v[u] = __builtin_nontemporal_load(src + base + 256L * u);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + 256L * u < n4) __builtin_nontemporal_store(v[u], dst + base + 256L * u);
+  }
 }
 }  // namespace
 
-extern "C" int bbd_stream_copy(const float* src, float* dst, long n_floats, void* stream) {
+extern "C" int bbd_stream_copy(const float* src, float* dst, long n_floats, int unroll, void* stream) {
   if (!src || !dst || n_floats <= 0 || (n_floats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return BBD_E_BADARG;
   const long n4 = n_floats / 4;
-  long blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;          // 32 workgroups per CU, each thread a few KB in flight over its loop
-  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+  const int U = unroll >= 8 ? 8 : (unroll >= 4 ? 4 : (unroll >= 2 ? 2 : 1));
+  long blocks = (n4 + 256L * U - 1) / (256L * U);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const f4* s4 = reinterpret_cast<const f4*>(src);
+  f4* d4 = reinterpret_cast<f4*>(dst);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 g((unsigned)blocks), b(256);
+  if (U == 8) hipLaunchKernelGGL(stream_copy_kernel<8>, g, b, 0, st, s4, d4, n4);
+  else if (U == 4) hipLaunchKernelGGL(stream_copy_kernel<4>, g, b, 0, st, s4, d4, n4);
+  else if (U == 2) hipLaunchKernelGGL(stream_copy_kernel<2>, g, b, 0, st, s4, d4, n4);
+  else hipLaunchKernelGGL(stream_copy_kernel<1>, g, b, 0, st, s4, d4, n4);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -411,8 +411,9 @@ int bbd_dispconv_bwd(const float* x, const float* weight, const float* grad_y, f
                      float* grad_bias, double* scratch, int N, int C, int H, int W, void* stream);
 
 /* Measurement aid (bench.py, SURVEY 8d "on-box measured stream-copy ceiling"): dst[i] = src[i] as a float4 grid-stride
- * copy of n_floats floats (multiple of 4, both pointers 16-byte aligned); 2 * 4 * n_floats bytes of HBM traffic. */
-int bbd_stream_copy(const float* src, float* dst, long n_floats, void* stream);
+ * copy of n_floats floats (multiple of 4, both pointers 16-byte aligned) with `unroll` (1, 2, 4, 8) independent 16-byte
+ * loads per thread in flight; 2 * 4 * n_floats bytes of HBM traffic. */
+int bbd_stream_copy(const float* src, float* dst, long n_floats, int unroll, void* stream);
 
 /* Device self-test: the kernels replace hipcc's IEEE division sequence by a cheaper one that is
  * exact for moderate exponents (bbd_math.h).  Runs blocks*256*iters random operand tuples through
