@@ -237,7 +237,12 @@ def test_pose_pass_is_padded_to_measured_row_counts():
     32, else that multiple; every epoch-15 row count of the boosted recipe (24 + 4 k) lands on a measured one with at most
     15 padding rows."""
     from baseboostdepth_amd import tuning
-    assert [tuning.padded_pose_rows(n) for n in (9, 24, 33, 48, 50, 100, 129, 180, 292, 330)] == [32, 32, 48, 48, 64, 128, 160, 192, 320, 352]
+    for n in (1, 9, 24, 33, 48, 50, 100, 129, 180, 292, 330, 400):
+        q = -(-n // 32) * 32
+        want = next((r for r in tuning.POSE_ROW_COUNTS if n <= r <= q), q)      # (the table is sorted)
+        assert tuning.padded_pose_rows(n) == want and want >= n and want - n < 32, (n, want)
+    assert list(tuning.POSE_ROW_COUNTS) == sorted(tuning.POSE_ROW_COUNTS)
+    assert [tuning.padded_pose_rows(n) for n in (48, 292, 330)] == [48, 320, 352]
     for k in range(39, 67):                      # 180 .. 288 rows: 99 % of the epoch-15 draws
         n = 24 + 4 * k
         r = tuning.padded_pose_rows(n)

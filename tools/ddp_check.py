@@ -128,7 +128,7 @@ def pooled_mode():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     torch.backends.cudnn.deterministic = True
-    orderings = [[7, 7, 1, 1], [7, 4, 2, 1], [7, 3, 3, 1], [7, 3, 2, 2], [7, 6, 1, 1], [7, 4, 1, 1], [7, 5, 1, 1]]     # 48 pose rows each
+    orderings = [[7, 7, 7, 1], [7, 7, 6, 1], [7, 7, 3, 2], [7, 7, 3, 1], [7, 7, 2, 2], [7, 7, 2, 1], [7, 6, 6, 1]]     # 64 pose rows each
     Hs, Ws = 96, 160
 
     def run(step_graph, capture):
