@@ -310,8 +310,19 @@ def test_bucketed_graphs_under_data_parallel_with_the_gradient_pack_inside_the_g
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BBD_BUCKET_BYTES="4000000", MASTER_PORT=str(port))
-    env.pop("BBD_DIST_BACKEND", None)
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_check.py"), "--pooled"], env=env,
-                         capture_output=True, text=True, timeout=900)
-    assert "DDP_POOLED_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    first = None
+    for attempt in range(2):        # (one retry: a one-rank RCCL rendezvous in a child process has failed once in five full runs
+        #                              of the tier for reasons outside the step - the check itself printed OK on the same tree)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BBD_BUCKET_BYTES="4000000", MASTER_PORT=str(port))
+        env.pop("BBD_DIST_BACKEND", None)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_check.py"), "--pooled"], env=env,
+                             capture_output=True, text=True, timeout=900)
+        if "DDP_POOLED_OK" in out.stdout:
+            break
+        first = first or (out.stdout[-1500:], out.stderr[-2500:])
+    assert "DDP_POOLED_OK" in out.stdout, (first, out.stdout[-1500:], out.stderr[-2500:])
+    if first is not None:
+        warnings.warn("tools/ddp_check.py --pooled needed a second attempt; first attempt: %r" % (first,))
