@@ -148,7 +148,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
             warnings.simplefilter("always")
             torch.cuda.set_sync_debug_mode("warn")
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            t0, cpu0 = time.perf_counter(), time.thread_time()
             done, per_call, rows_real, rows_run = 0, [], [], []
             prof_step = int(os.environ.get("BBD_BENCH_PROFILE_STEP", "-1")) if p == 0 else -1      # (diagnosis: cProfile one call)
             n_seg = len(seg)
@@ -172,6 +172,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                     torch.cuda.synchronize()      # far over budget (e.g. MIOpen compiling solvers for unseen row counts)
                     break
             t_host = time.perf_counter() - t0          # the training thread is done enqueueing here
+            t_cpu = time.thread_time() - cpu0          # ... and this is how much of that it spent ON the CPU (not waiting)
             torch.cuda.set_sync_debug_mode("default")
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -186,6 +187,9 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                        # how long the training thread took to ENQUEUE the steps (if this is well below ms_per_step the loop is
                        # bound by the GPU, not by the host)
                        "host_enqueue_ms_per_step": round(t_host / done * 1e3, 3),
+                       # CPU time of the training thread per step (time.thread_time): with graph replays the wall time above is
+                       # mostly the thread WAITING in a launch call for room in the queue - it runs two steps ahead of the GPU
+                       "host_cpu_ms_per_step": round(t_cpu / done * 1e3, 3),
                        # the train_step CALLS one by one: a few slow ones (a first use of something) or all of them?
                        "host_call_ms_median": round(sorted(per_call)[len(per_call) // 2] * 1e3, 2),
                        "host_call_ms_slowest3": [round(v * 1e3, 1) for v in sorted(per_call)[-3:]],

@@ -669,6 +669,14 @@ def main(argv=None):
                     if ref:
                         r["frozen_batch_images_per_sec"] = round(ref, 2)
                         r["frozen_batch_pose_rows"] = frozen_rows.get(cfg.replace("_fresh", ""))
+                        # the frozen batch is ONE ordering; the fresh draws ask for other (on average more) pose rows: the same
+                        # comparison per row of the pose pass - per row the batches asked for (padding counts against the fresh
+                        # line) and per row that ran
+                        fr, steady = r["frozen_batch_pose_rows"], (r["passes"][1] if len(r.get("passes", [])) == 4 else (r.get("passes") or [None])[0])
+                        if fr and steady and steady.get("pose_rows_mean"):
+                            per_row_frozen = (args.batch / ref * 1e3) / fr
+                            r["vs_frozen_batch_per_pose_row_asked"] = round(per_row_frozen / (steady["ms_per_step"] / steady["pose_rows_mean"]), 4)
+                            r["vs_frozen_batch_per_pose_row_run"] = round(per_row_frozen / (steady["ms_per_step"] / steady["pose_rows_run_mean"]), 4)
                         r["vs_frozen_batch"] = round(r["value"] / ref, 4)
                         if "passes" in r:
                             r["vs_frozen_batch_seen_signatures"] = round(r["passes"][-1]["images_per_sec"] / ref, 4)

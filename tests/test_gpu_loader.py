@@ -96,3 +96,43 @@ def test_frame_cache_in_hbm_feeds_the_same_batches(tmp_path):
         decoded.append(cache.misses - before)
     st = cache.stats()
     assert st["passed_through"] == 0 and st["hits"] > 0 and decoded[1] <= 0.5 * decoded[0], (st, decoded)
+
+
+def test_loader_batches_replay_bucket_graphs_at_a_late_epoch(tmp_path):
+    """The KITTI device loader at epoch 12 (frame offsets up to +-7 per sample, incremental + partial pose modes) feeding the
+    pooled step with step graphs (`train.py --rand`'s default): after `prewarm()` every loader batch - a new ordering each -
+    is ONE table upload and a graph replay (or, for a bucket the seeded draws of `prewarm()` did not meet, one capture), no
+    batch falls back to the per-signature form, losses stay finite."""
+    import warnings
+    from test_gpu_trainer import make_opt
+    from baseboostdepth_amd import datasets, steptables
+    from baseboostdepth_amd.trainer import Trainer
+    H, W, B = 96, 320, 4
+    lines = image_checks.make_kitti_tree(str(tmp_path), frames=24)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.rand, opt.step_graph = True, True
+    torch.manual_seed(0)
+    tr = Trainer(opt)
+    tr.opt.scales = [0]
+    tr.set_train()
+    tr.epoch = 12
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        info = tr.prewarm(epoch=12)
+        assert info["buckets"] >= 3
+        ds = datasets.KITTIRAWDataset(lines, 12, H, W, kt_path=str(tmp_path), rand=True, is_train=True, scales=[0], kt=True,
+                                      naive_mix=True, trimin=True, seed=5)
+        loader = datasets.DeviceLoader(ds, B, datasets.DeviceCollate(H, W, [0], "cuda:0"), num_workers=4, seed=2, workers="process")
+        captures0, losses, orderings = tr.graph_stats["captures"], [], set()
+        for step, batch in enumerate(loader):
+            orderings.add(str(batch["ordering"]))
+            steptables.reset_stats()
+            _, l = tr.train_step(batch)
+            assert steptables.STATS["packed_uploads"] == 1 and steptables.STATS["single_uploads"] == 0, steptables.STATS
+            losses.append(l["loss"].detach())
+            if step == 7:
+                break
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(x)) for x in losses) and len(losses) == 8 and len(orderings) >= 4
+    assert tr.graph_stats["eager"] == 0 and tr.graph_stats["replays"] == 8 and tr._pooled.stats["fallbacks"] == 0
+    assert tr.graph_stats["captures"] - captures0 <= 2
