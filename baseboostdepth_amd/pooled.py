@@ -19,8 +19,8 @@ enqueue work in an 89 ms step).  Here:
   the device table (`ops.bn_call_groups_device`, bbd_bn_act_grouped_dev_*), the pose matrices, composed poses, pose
   table, `grad_P` partials and identity maps are sized by the maxima.
 
-The step's launches then depend on `(R, group grid, scales, lr)` only: <= 14 graphs for epochs >= 10, one for the early
-curriculum (`Trainer._graph_step`), captured up front by `Trainer.prewarm()`.
+The step's launches then depend on `(R, group grid, scales, lr)` only: 14-19 graphs per epoch from epoch 10 on, seven for the early
+curriculum (24 .. 48 pose rows in steps of 4) (`Trainer._graph_step`), captured up front by `Trainer.prewarm()`.
 
 What is computed does not change: the padding rows are zero images in call groups of their own that take no part in
 the running statistics, nobody reads their outputs and their gradient contributions are exact zeros; no-op composition

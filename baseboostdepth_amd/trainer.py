@@ -179,7 +179,7 @@ class Trainer:
     def _graph_signature(self, inputs):
         """(pooled tables | None, graph key, noise handed in?) of a batch.  In pooled form (`--rand`) the step's launches
         depend on the batch through the padded pose rows, the group grid of the pose pass's BatchNorms and its row bound only:
-        ONE graph per row-count bucket, whatever the ordering (<= 14 for epochs >= 10, one for the early curriculum);
+        ONE graph per row-count bucket, whatever the ordering (14-19 per epoch from epoch 10 on, seven for the early curriculum);
         otherwise the key is the whole signature."""
         tab = None
         if self.pooled_step:
@@ -382,7 +382,7 @@ class Trainer:
 
     def prewarm(self, epoch=None, seed=0):
         """Before the first step of a `--rand` curriculum phase: capture the step graph of EVERY pose-row bucket the phase
-        can meet (the pooled form's graph keys: <= 14 for epochs >= 10, one for the early curriculum) on synthetic batches,
+        can meet (the pooled form's graph keys: a few dozen for epochs >= 10, seven for the early curriculum) on synthetic batches,
         so that no training step pays for a capture, for the allocator meeting a new activation size or for MIOpen loading
         a row count's solvers (round 5: a fresh process ran its first 30 steps at half speed).  The warm-up steps inside a
         capture restore parameters, buffers, optimizer state and the step counter: nothing is trained.  Without step

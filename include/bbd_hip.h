@@ -348,7 +348,7 @@ int bbd_bn_scratch_doubles(int N, int C, int HW);
  * untracked_groups (ABI 6; 0 <= . < G): the LAST that many groups are normalised like the others but take no part in the
  * running statistics or num_batches_tracked - padding rows.  Boosted batches change the batched pose pass's row count
  * almost every step (mono_dataset.py:87-109), and every new row count is a new convolution problem for MIOpen (tens of
- * seconds of solver compilation at first sight); the trainer rounds the pass up to a multiple of 32 rows with one
+ * seconds of solver compilation at first sight); the trainer rounds the pass up to a row count with shipped find results (else a multiple of 32) with one
  * trailing group of zero rows whose outputs nobody reads (their gradients are exact zeros). */
 #define BBD_BN_MAX_GROUPS 32
 int bbd_bn_grouped_scratch_doubles(int max_group_rows, int G, int C, int HW);
