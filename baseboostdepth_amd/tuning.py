@@ -24,11 +24,11 @@ DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
 # of find mode each).  `Trainer._pose_pairs` rounds the pass up to the next of these (beyond them: to a multiple of 32), so
 # the pose network's convolutions only ever meet problems MIOpen has measured solvers for.  The epoch-15 draws of the
 # boosted recipe need 192-288 rows (24 + 4 * sum(m - 1) per batch of 12), epochs 10-12 about 100-160, the early curriculum 24-48.
-# Round 6 added 24-44 in steps of 4 (the early curriculum's pass has 2 * sum(m) rows), 112 / 136 / 144 / 152 / 168 / 176 (epochs 10-13)
-# and 216 / 232 / 248 / 264: where a phase's draws are dense the buckets are 8 rows apart (the padding is the one cost
+# Round 6 added 24-44 in steps of 4 (the early curriculum's pass has 2 * sum(m) rows), 104-176 in steps of 8 (epochs 10-13) and 200 /
+# 216 / 232 / 248 / 264 / 280: where a phase's draws are dense the buckets are 8 rows apart (the padding is the one cost
 # the pooled step graphs still pay against a frozen batch: 3 % of a boosted step at 16-row buckets).
-POSE_ROW_COUNTS = (24, 28, 32, 36, 40, 44, 48, 64, 96, 112, 128, 136, 144, 152, 160, 168, 176, 192, 208, 216, 224, 232, 240, 248, 256, 264,
-                   272, 288, 320)
+POSE_ROW_COUNTS = (24, 28, 32, 36, 40, 44, 48, 64, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 192, 200, 208, 216, 224, 232, 240,
+                   248, 256, 264, 272, 280, 288, 320)
 
 
 def padded_pose_rows(n, quantum=32):
