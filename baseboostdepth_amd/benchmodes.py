@@ -143,7 +143,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                 ("2", batches[:30]), ("3", batches[:30])] if len(batches) > 30 else [("1", batches), ("2", batches), ("3", batches)]
     for p, (label, seg) in enumerate(segments):
         steptables.reset_stats()
-        g0 = dict(tr.graph_stats)
+        g0, launch0 = dict(tr.graph_stats), tr.launch_wait_s
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             torch.cuda.set_sync_debug_mode("warn")
@@ -181,7 +181,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
         sync_where = sorted({"%s:%d" % (os.path.relpath(w.filename, ROOT) if w.filename.startswith(ROOT) else os.path.basename(w.filename),
                                         w.lineno) for w in sync_w})
         st = dict(steptables.STATS)
-        g1 = tr.graph_stats
+        g1 = dict(tr.graph_stats)
         passes.append({"pass": label, "steps": done, "ms_per_step": round(dt / done * 1e3, 3),
                        "images_per_sec": round(args.batch * done / dt, 2),
                        # how long the training thread took to ENQUEUE the steps (if this is well below ms_per_step the loop is
@@ -190,6 +190,9 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
                        # CPU time of the training thread per step (time.thread_time): with graph replays the wall time above is
                        # mostly the thread WAITING in a launch call for room in the queue - it runs two steps ahead of the GPU
                        "host_cpu_ms_per_step": round(t_cpu / done * 1e3, 3),
+                       # the training thread's time OUTSIDE hipGraphLaunch (table look-up / build, the copies into the pool,
+                       # Python): what the step costs the host; the launch call itself waits (busily) for room in the queue
+                       "host_ms_outside_graph_launch_per_step": round((t_host - (tr.launch_wait_s - launch0)) / done * 1e3, 3),
                        # the train_step CALLS one by one: a few slow ones (a first use of something) or all of them?
                        "host_call_ms_median": round(sorted(per_call)[len(per_call) // 2] * 1e3, 2),
                        "host_call_ms_slowest3": [round(v * 1e3, 1) for v in sorted(per_call)[-3:]],

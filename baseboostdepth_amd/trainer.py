@@ -11,6 +11,7 @@ only on request (`opt.materialize_warps`) because nothing in the loss needs them
 """
 import json
 import os
+import time
 
 import torch
 import torch.optim as optim
@@ -33,6 +34,7 @@ class Trainer:
     pooled_step = False      # `--rand`: the step in pooled form (`pooled.PooledStep`), one step graph per pose-row bucket
     _pooled = None
     last_pooled = None       # `pooled.PooledTables` of the last batch that ran in pooled form
+    launch_wait_s = 0.0      # seconds spent inside hipGraphLaunch (graph.replay) so far
 
     def __init__(self, options, backend=None):
         self.opt = options
@@ -349,7 +351,11 @@ class Trainer:
             for k, v in inputs.items():
                 if torch.is_tensor(v) and v.is_cuda:
                     static[k].copy_(v, non_blocking=True)
+        t_launch = time.perf_counter()
         graph.replay()
+        # (hipGraphLaunch returns when the runtime has room for the graph's ~1 300 nodes: with the thread two steps ahead of the
+        # GPU that is a busy wait inside the call, not host work - kept apart so that a benchmark can tell the two)
+        self.launch_wait_s += time.perf_counter() - t_launch
         if tail is not None:
             self.grad_sync.exchange()
             tail.replay()
