@@ -76,6 +76,34 @@ def test_vit_train_steps_reduce_the_loss():
     assert sum(hist[-5:]) / 5 < sum(hist[:5]) / 5, (hist[:5], hist[-5:])
 
 
+def test_vit_boosted_recipe_in_pooled_form_with_step_graphs():
+    """MonoViT (`--ViT`, trainer.py:52-58) under the boosted `--rand` recipe: the step runs in pooled form (the depth
+    network is the only thing that differs from the ResNet path) and its bucket graph replays for new orderings."""
+    import warnings
+    from test_gpu_trainer import make_opt
+    from baseboostdepth_amd.trainer import Trainer
+    from baseboostdepth_amd.synthetic import synthetic_batch
+    H, W, B = 96, 160, 4
+    torch.manual_seed(0)
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.ViT, opt.rand, opt.step_graph = True, True, True
+    tr = Trainer(opt)
+    tr.opt.scales = [0]
+    tr.set_train()
+    losses = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, ms in enumerate([[7, 7, 7, 1], [7, 7, 6, 1], [7, 7, 3, 2], [7, 6, 6, 1]]):      # 64 pose rows each
+            b = synthetic_batch(ms, H, W, [0], device=DEV, seed=50 + i)
+            b.pop("noise")
+            b["cutt"] = torch.tensor(1.35)
+            _, l = tr.train_step(b)
+            losses.append(l["loss"].detach())
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(x)) for x in losses)
+    assert tr.graph_stats == {"eager": 0, "captures": 1, "replays": 4} and tr._pooled.stats["fallbacks"] == 0
+
+
 @pytest.mark.parametrize("B,H,W,C,splits,add", [
     (2, 12, 40, 216, (54, 81, 81), False),       # stage-2 ConvRelPosEnc: 27-channel heads, windows 3/5/7
     (3, 6, 20, 64, (16, 24, 24), False),
