@@ -114,7 +114,7 @@ class PooledTables:
         # early curriculum (at most 4 calls: frames +-1, +-2): the small group grid whatever the ordering, the padding in at
         # most 4 groups.  `early_rows` > 0 pads every batch of the phase to that ONE row count (one graph, but the pose pass
         # then always runs the phase's maximum: measured 0.79 of the frozen batch at 48 rows for a mean of 31 real ones);
-        # the default rounds up to the next measured row count like the later epochs do (32 | 48 rows for batch 12)
+        # the default rounds up to the next measured row count like the later epochs do (24 .. 48 in steps of 4 for batch 12)
         early = not maxing and len(sched.requests) <= SMALL_GROUPS // 2
         pad_groups = SMALL_GROUPS - SMALL_GROUPS // 2 if early else MAX_PAD_GROUPS
         if early and early_rows and n_real <= early_rows:
@@ -286,7 +286,7 @@ class PooledStep:
 
     def bucket_orderings(self, early, draws=600):
         """Per-sample offsets whose batches between them meet the graph keys (padded pose rows, group grid) of a curriculum
-        phase: the early curriculum has one; from epoch 10 on, two walks from the smallest to the largest pass (all samples
+        phase: the early curriculum's row counts (2 * sum(m): 24 .. 48 for batch 12), one ordering each; from epoch 10 on, two walks from the smallest to the largest pass (all samples
         alike; one sample at the largest offset) plus seeded draws from the loader's offset distributions - the
         pass's row count depends on WHICH frames a batch's samples use, not only on how many.  A bucket none of them meets
         is captured when training first meets it."""
