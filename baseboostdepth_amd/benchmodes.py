@@ -98,6 +98,7 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
     # count and the captures themselves happen HERE, not in the first minute of training.  `pooled_step = False` in the
     # options (BBD_POOLED_STEP=0) gives round 5's per-signature loop for A/B: it warms the same things on orderings outside
     # the draw.  Then every per-signature cache is dropped: the first timed step of every signature is cold
+    torch.cuda.reset_peak_memory_stats(dev)
     t_pre = time.perf_counter()
     if tr.pooled_step:
         prewarm = tr.prewarm(epoch=15 if base.startswith("boosted") else 5, seed=7)
@@ -218,6 +219,9 @@ def run_fresh(args, ctx, config, want_graph, n_batches=30, pass_budget=20.0):
            "pose_pad_rows": pad_rows, "pooled_step": bool(tr.pooled_step), "prewarm": prewarm,
            "step_graphs_in_use": len(tr._graphs),
            "pooled_fallbacks": tr._pooled.stats["fallbacks"] if tr._pooled is not None else None,
+           # device memory with every bucket graph of the phase captured (the graphs share one pool)
+           "max_memory_allocated_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
+           "memory_reserved_GB": round(torch.cuda.memory_reserved(dev) / 1e9, 2),
            "what": ("value = every signature new, per-signature caches cold: steps 31-90 of pass 1; cold_start_images_per_sec = "
                     "its first 30 steps, right after Trainer.prewarm() (pooled form: the step graphs of the phase's pose-row "
                     "buckets, captured before the first step - `prewarm`); last pass = every signature seen before"
