@@ -239,6 +239,31 @@ def test_prewarm_captures_every_bucket_and_trains_nothing(monkeypatch):
     assert tr.graph_stats["captures"] - captures <= 1          # (a bucket the seeded draws of prewarm() did not meet)
 
 
+def test_graphs_of_an_old_learning_rate_are_dropped():
+    """The learning rate is part of a graph key (fused Adam bakes it in) and MultiStepLR only moves forward: when it changes,
+    the next capture drops every graph of the old rate - a phase of the boosted recipe holds dozens of bucket graphs, and
+    generations of them must not pile up in device memory."""
+    from baseboostdepth_amd.trainer import Trainer
+    H, W, B = 96, 160, 4
+    opt = make_opt(H, W, B, [0, 1, 2, 3], True)
+    opt.rand, opt.step_graph = True, True
+    torch.manual_seed(2)
+    tr = Trainer(opt)
+    tr.opt.scales = [0]
+    tr.set_train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr.train_step(_batch([7, 7, 7, 1], H, W, [0], 1, 1.35))
+        tr.train_step(_batch([3, 2, 1, 1], H, W, [0], 2, 1.35))
+        assert len(tr._graphs) == 2
+        for g in tr.model_optimizer.param_groups:
+            g["lr"] = g["lr"] * 0.4
+        _, losses = tr.train_step(_batch([7, 7, 6, 1], H, W, [0], 3, 1.35))
+    torch.cuda.synchronize()
+    lrs = tuple(g["lr"] for g in tr.model_optimizer.param_groups)
+    assert len(tr._graphs) == 1 and all(k[-1] == lrs for k in tr._graphs) and bool(torch.isfinite(losses["loss"]))
+
+
 # ------------------------------------------------------------------------------------------ golden vectors through the pool
 @pytest.mark.parametrize("name", ["pose_plain_3105_32x64", "pose_incr_3215_32x64", "pose_incr_partial_4327_32x64",
                                   "pose_md2_b2_32x64"])
