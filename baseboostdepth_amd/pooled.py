@@ -307,8 +307,8 @@ class PooledStep:
                 R = self.early_rows() if self.early_rows() and n <= self.early_rows() else tuning.padded_pose_rows(max(n, 1), quantum)
                 if R not in seen:
                     seen.add(R)
-                    out.append(ms)
-            return out
+                    out.append((R, ms))
+            return [ms for _, ms in sorted(out, key=lambda e: -e[0])]
         top = 7 if trimin else 5
         quantum = max(self.trainer.pose_pad_rows, 1)
         seen, out = set(), []
@@ -327,7 +327,7 @@ class PooledStep:
             key = (R, SMALL_GROUPS if groups <= SMALL_GROUPS else ops.BN_MAX_GROUPS)
             if R <= self.caps.R and key not in seen:
                 seen.add(key)
-                out.append(ms)
+                out.append((R, ms))
 
         for first in (1, top):
             ms = [first] + [1] * (B - 1)
@@ -342,7 +342,9 @@ class PooledStep:
         weights = ([.050, .050, .077, .094, .139, .142, .448], [.108, .287, .277, .135, .068, .040, .084], [1.0] * 7)
         for i in range(draws):
             visit(rnd.choices(range(1, top + 1), weights[i % 3][:top], k=B))
-        return out
+        # largest pass first: the graphs share one memory pool, and a later, smaller capture then fits into the blocks an
+        # earlier one freed instead of growing the pool
+        return [ms for _, ms in sorted(out, key=lambda e: -e[0])]
 
     # ------------------------------------------------------------------ static buffers
     def allocate(self, scales):

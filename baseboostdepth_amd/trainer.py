@@ -223,7 +223,7 @@ class Trainer:
     def _capture(self, key, inputs, tab, has_noise, first_checked_capture=False):
         """Warm-up (that must not train) + capture of `process_batch + backward + optimizer.step` for a graph key."""
         # graphs of another learning rate can never replay again (MultiStepLR only moves forward): they go first - a phase of
-        # the boosted recipe holds ~35 bucket graphs (47 GB allocated / 99 GB reserved at batch 12), three generations of
+        # the boosted recipe holds ~35 bucket graphs (42 GB allocated / 59 GB reserved at batch 12), a few generations of
         # them would not fit the device
         lrs = tuple(g["lr"] for g in self.model_optimizer.param_groups)
         for k in [k for k in self._graphs if k[-1] != lrs]:
