@@ -191,3 +191,38 @@ def test_row_count_buckets():
         assert tab.R == tuning.padded_pose_rows(tab.n_real, 32) and tab.R in tuning.POSE_ROW_COUNTS
         seen.add((tab.R, tab.G, tab.bound))
     assert len(seen) <= len(tuning.POSE_ROW_COUNTS) and {b for _, _, b in seen} == {12}
+
+
+def test_prewarm_orderings_cover_the_buckets_the_loader_draws_meet():
+    """`PooledStep.bucket_orderings` (what `Trainer.prewarm` captures): the early curriculum's row counts 24 .. 48 one
+    ordering each, largest first; from epoch 10 on every bucket that 300 draws from the epoch-10 / -15 / -19 offset
+    distributions land in is among the prewarmed ones (a bucket it misses would be captured on first sight)."""
+    import random
+    import types
+    from baseboostdepth_amd import steptables
+    from baseboostdepth_amd.plan import ReprojectionPlan
+    tr = types.SimpleNamespace(opt=types.SimpleNamespace(batch_size=12, height=192, width=640, trimin=True, decomp=True,
+                                                         incremental_skip=True, partial_skip=True),
+                               device=torch.device("cpu"), pose_pad_rows=32)
+    ps = pooled.PooledStep(tr)
+    early = ps.bucket_orderings(True)
+    rows = [tuning.padded_pose_rows(sum(2 * m for m in ms), 32) for ms in early]
+    assert rows == [48, 44, 40, 36, 32, 28, 24]
+
+    def bucket(ms):
+        ms = sorted(ms, reverse=True)
+        plan = ReprojectionPlan([[0, m, -m] for m in ms], True, True)
+        sched = steptables.PoseSchedule(plan, sorted(range(-max(ms), max(ms) + 1), key=abs), True, True, True, 1 << 30)
+        R = tuning.padded_pose_rows(sched.total_rows, 32)
+        groups = len(sched.rows) + -(-(R - sched.total_rows) // 12)
+        return R, (8 if groups <= 8 else 32)
+    late = ps.bucket_orderings(False)
+    have = {bucket(ms) for ms in late}
+    assert [bucket(ms)[0] for ms in late] == sorted((bucket(ms)[0] for ms in late), reverse=True)      # largest pass first
+    rnd = random.Random(99)
+    missed = 0
+    for w in ([.108, .287, .277, .135, .068, .040, .084], [.050, .050, .077, .094, .139, .142, .448],
+              [.050, .050, .050, .059, .070, .078, .644]):
+        for _ in range(100):
+            missed += bucket(rnd.choices(range(1, 8), w, k=12)) not in have
+    assert missed <= 3, missed
