@@ -136,7 +136,7 @@ class PooledTables:
             inv[at:at + n] = int(invert)
             at += n
         # call groups: one per pose-network call, then the padding in chunks of at most `bound` rows, then empty ones
-        self.bound = max(B, -(-max_pad // pad_groups))
+        self.bound = min(R, max(B, -(-max_pad // pad_groups)))      # (the launches refuse a bound above the row count)
         rows = list(sched.rows)
         pad = R - n_real
         while pad > 0:
@@ -322,7 +322,7 @@ class PooledStep:
             if len(sched.requests) > MAX_REQUESTS:
                 return
             R = tuning.padded_pose_rows(max(sched.total_rows, 1), quantum)
-            bound = max(B, -(-(R - lowest_rows(R, quantum)) // MAX_PAD_GROUPS))
+            bound = min(R, max(B, -(-(R - lowest_rows(R, quantum)) // MAX_PAD_GROUPS)))
             groups = len(sched.rows) + -(-(R - sched.total_rows) // bound)
             key = (R, SMALL_GROUPS if groups <= SMALL_GROUPS else ops.BN_MAX_GROUPS)
             if R <= self.caps.R and key not in seen:
