@@ -2,8 +2,8 @@
 a NEW batch ordering every step (`run_fresh`: the `--rand` recipe redraws every sample's frame set per item,
 mono_dataset.py:87-109, trainer.py:250, 867-886) and the loader in the loop (`run_loader_fed`) - plus what
 they share with the headline (`make_options`, `workload_name`) and the on-box ceilings the bench line quotes
-(`stream_copy_ceiling`, `cpu_model`).  Measurement only; nothing here is on the product path and nothing here touches the
-oracle (the CPU baseline and the eager A/B stay in bench.py)."""
+(`stream_copy_ceiling`, `cpu_model`).  Measurement only; nothing here is on the product path, and the legs of the benchmark that run the CPU checker
+(the CPU baseline, the eager A/B) stay in bench.py."""
 import json
 import os
 import sys
