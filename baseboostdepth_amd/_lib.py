@@ -88,6 +88,7 @@ SIGNATURES = {
     "bbd_bias_elu_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "bbd_selftest_div": [_i, _i, ctypes.c_uint, _p, _p],
     "bbd_stream_copy": [_p, _p, ctypes.c_long, _i, _p],
+    "bbd_gather_pairs": [_p, _p, _p, _p, _i, ctypes.c_long, _d, _d, _p],
     "bbd_dwconv_tokens_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "bbd_factor_att_supported": [_i, _i],
     "bbd_factor_att_segments": [_i, _i],

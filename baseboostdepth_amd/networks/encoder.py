@@ -146,9 +146,11 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
-    def forward(self, input_image):
+    def forward(self, input_image, normalized=False):
+        """`normalized`: the caller hands in `(image - 0.45) / 0.225` already (the pooled step's pair gather does it in the
+        same pass, `ops.gather_pairs`)."""
         e = self.encoder
-        x = (input_image - 0.45) / 0.225
+        x = input_image if normalized else (input_image - 0.45) / 0.225
         f0 = e.bn1(e.conv1(x), relu=True)
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)

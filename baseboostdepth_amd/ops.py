@@ -486,6 +486,23 @@ def identity_losses(plan, frame_tensors, target, no_ssim=False, backend=None):
     return ident
 
 
+def gather_pairs(pool, idx_a, idx_b, normalize=None, backend=None):
+    """[R, 6, H, W]: row r = cat(pool[idx_a[r]], pool[idx_b[r]]) of the frame pool [F, 3, H, W] - the batched pose pass's input
+    in the pooled form - in one launch; `normalize = (mean, std)` folds the encoder's `(x - mean) / std` in (evaluated like
+    PyTorch-ROCm does: subtract, then multiply by the float reciprocal of std).  No gradient: the pool holds images."""
+    import numpy as np
+    backend = backend or default_backend()
+    F, C, H, W = pool.shape
+    R = idx_a.numel()
+    assert pool.is_contiguous() and idx_a.dtype == torch.int32 and idx_b.dtype == torch.int32 and idx_b.numel() == R
+    backend._check(pool, idx_a, idx_b)
+    out = torch.empty(R, 2 * C, H, W, device=pool.device, dtype=torch.float32)
+    sub, mul = (0.0, 1.0) if normalize is None else (float(np.float32(normalize[0])),
+                                                     float(np.float32(1.0) / np.float32(normalize[1])))
+    backend.run("bbd_gather_pairs", pool, ptr(pool), ptr(idx_a.contiguous()), ptr(idx_b.contiguous()), ptr(out), R, C * H * W, sub, mul)
+    return out
+
+
 # ---------------------------------------------------------------------------- pose table
 def pose_table(plan, K, inv_K, poses):
     """[NP,40] rows  K[:3,:] | T | inv_K[:3,:3] | pad, differentiable w.r.t. the poses.

@@ -403,9 +403,17 @@ class PooledStep:
         """The batched pose pass + pose matrices + composition on the static buffers -> (M [R,4,4], composed [NO_cap,4,4])."""
         tr, opt, v, c = self.trainer, self.trainer.opt, self.v, self.caps
         be = tr._backend()
-        x = torch.cat([self.pool_aug.index_select(0, v["idx_a"][:R]), self.pool_aug.index_select(0, v["idx_b"][:R])], 1)
-        with ops.bn_call_groups_device(v["groups"], G, bound):
-            feats = [tr.models["pose_encoder"](x)]
+        enc = tr.models["pose_encoder"]
+        from .networks.encoder import ResnetEncoder
+        if isinstance(enc, ResnetEncoder) and ops.FUSED_NN:
+            # the pairs of every pose-network call, gathered from the pool AND normalised like the encoder does, in one pass
+            x = ops.gather_pairs(self.pool_aug, v["idx_a"][:R], v["idx_b"][:R], normalize=(0.45, 0.225), backend=be)
+            with ops.bn_call_groups_device(v["groups"], G, bound):
+                feats = [enc(x, normalized=True)]
+        else:
+            x = torch.cat([self.pool_aug.index_select(0, v["idx_a"][:R]), self.pool_aug.index_select(0, v["idx_b"][:R])], 1)
+            with ops.bn_call_groups_device(v["groups"], G, bound):
+                feats = [enc(x)]
         axisangle, translation = tr.models["pose"](feats)
         M = ops.pose_matrix(axisangle[:, 0], translation[:, 0], backend=be, invert_rows=v["invert"][:R])
         out = ops.pose_compose_static(M, v["compose_tab"], v["compose_off"][:R + 1], v["compose_refs"], c.NO,

@@ -410,6 +410,15 @@ int bbd_dispconv_fwd(const float* x, const float* weight, const float* bias, flo
 int bbd_dispconv_bwd(const float* x, const float* weight, const float* grad_y, float* grad_x, float* grad_weight,
                      float* grad_bias, double* scratch, int N, int C, int H, int W, void* stream);
 
+/* Input of the batched pose pass in the pooled form of the step: out [R, 2, chw] row r = the image pair
+ * (pool[idx_a[r]], pool[idx_b[r]]) of the frame pool [F, chw] (chw = 3*H*W floats, multiple of 4), every texel (v - sub) * mul.
+ * Replaces the reference's per-call `torch.cat([frame_a, frame_b], 1)` (trainer.py:352-358, 394-400) over masked sub-batches
+ * plus the pose encoder's input normalisation `(x - 0.45) / 0.225` (networks/resnet_encoder.py:83; PyTorch-ROCm divides by a
+ * Python scalar as a multiplication by its float reciprocal: pass mul = (float)1 / (float)0.225): same bits, one pass.
+ * idx_a / idx_b: device int32 [R] (sections of the step's static table buffer).  sub = 0, mul = 1: a plain gather. */
+int bbd_gather_pairs(const float* pool, const int32_t* idx_a, const int32_t* idx_b, float* out, int R, long chw, double sub,
+                     double mul, void* stream);
+
 /* Measurement aid (bench.py, SURVEY 8d "on-box measured stream-copy ceiling"): dst[i] = src[i] as a float4 grid-stride
  * copy of n_floats floats (multiple of 4, both pointers 16-byte aligned) with `unroll` (1, 2, 4, 8) independent 16-byte
  * loads per thread in flight; 2 * 4 * n_floats bytes of HBM traffic. */

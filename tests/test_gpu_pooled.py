@@ -75,6 +75,21 @@ def test_grouped_batch_norm_with_a_device_table_equals_the_host_table_form(N, C,
             assert torch.equal(u, v), (name, float((u.float() - v.float()).abs().max()))
 
 
+def test_pair_gather_with_folded_normalisation_equals_the_torch_ops():
+    """`ops.gather_pairs`: cat(pool[idx_a], pool[idx_b]) and the encoder's `(x - 0.45) / 0.225` in one launch - the bits of the
+    torch expression the per-signature form evaluates (PyTorch-ROCm: subtract, multiply by the float reciprocal), with repeated
+    and out-of-order rows and the all-zero padding row."""
+    from baseboostdepth_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    pool = torch.round(torch.rand(9, 3, 32, 64, device=DEV, generator=gen) * 255) / 255
+    pool[8] = 0.0
+    ia = torch.tensor([3, 0, 0, 7, 8, 8, 2], dtype=torch.int32, device=DEV)
+    ib = torch.tensor([1, 5, 0, 6, 8, 4, 2], dtype=torch.int32, device=DEV)
+    want = torch.cat([pool.index_select(0, ia), pool.index_select(0, ib)], 1)
+    assert torch.equal(ops.gather_pairs(pool, ia, ib), want)
+    assert torch.equal(ops.gather_pairs(pool, ia, ib, normalize=(0.45, 0.225)), (want - 0.45) / 0.225)
+
+
 # ------------------------------------------------------------------------------------------ pooled step == per-signature step
 @pytest.mark.parametrize("scales,cutt,ms", [
     ([0], 1.35, [7, 5, 4, 3]), ([0], 1.35, [3, 1, 2, 5]), ([0], 1.35, [1, 1, 1, 1]),
