@@ -82,6 +82,11 @@ def check_pose_case(name, backend, device, pooled=False):
         # a near-tie pixel whose arg-min flipped (poses differ by round-off) re-routes gradient inside its
         # 3x3 window and the 2x2 bilinear footprints below it: <= 25 texels per flip (observed <= 23)
         flips = report.get("flips/%d" % s, 0)
-        assert int((rel > 5e-3).sum()) <= 25 * flips, (s, flips, int((rel > 5e-3).sum()), float(rel.max()))
+        # ... and, without any flip, a sampling coordinate that the poses' round-off moves across an integer boundary changes
+        # which texel pair ONE bilinear derivative differences (DESIGN.md 4, round 4 addition 3): seen once in eight runs of the
+        # GPU tier (pose_md2_b2, scale 1: one texel at 1.06e-2 of the maximum, no flip).  Two such texels are allowed, each
+        # below 5e-2 of the maximum - a wrong gradient moves thousands
+        n_bad = int((rel > 5e-3).sum())
+        assert n_bad <= 25 * flips + 2 and (flips > 0 or float(rel.max()) < 5e-2), (s, flips, n_bad, float(rel.max()))
 
 
